@@ -1,0 +1,150 @@
+/*
+ * mistral_water.h -- C ABI of libmistral_water.so, the MI355X (gfx950) ocean heightfield synthesiser.
+ *
+ * The reference (AlphaMistral/Mistral-Water, a Unity C# project) has NO native plugin / P/Invoke
+ * interface: the boundary is cut here at the seam between the MonoBehaviour drivers
+ * and the private numerical methods they call on themselves.  Every entry point cites the reference
+ * code it replaces (S/ = Assets/Mistral Water/Scripts/, F/ = .../Shaders/FFT/, W/ = .../Shaders/).
+ *
+ * Conventions
+ *  - plain C, no C++ types, no callbacks; status codes only (never exceptions / aborts);
+ *    mw_last_error() returns a thread-local description of the last failure.
+ *  - arrays use the reference's layouts: Vector2 = 2 x f32, Vector3 = 3 x f32, Color = 4 x f32,
+ *    grid index idx = i*N + j with i along x and j along z (S/FFTMesh.cs:110).
+ *  - "host" entry points take host pointers and are synchronous (kernels + D2H done on return);
+ *    "_device" entry points take device pointers, enqueue on the handle's stream and return at once.
+ *  - one mw_ocean must not be used from two threads at once; distinct handles may be.
+ *  - the library is HIP-only: there is NO CPU fallback.  mw_ocean_create fails with MW_EDEVICE when
+ *    no gfx950 device is usable.
+ */
+#ifndef MISTRAL_WATER_H
+#define MISTRAL_WATER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MW_ABI_VERSION 1
+
+typedef struct mw_ocean mw_ocean; /* opaque; one per FFTMesh / OceanRenderer instance */
+
+typedef enum {
+    MW_OK = 0,
+    MW_EINVAL = 1,           /* bad argument / NULL pointer / unsupported resolution */
+    MW_ENOTPOW2 = 2,         /* OceanRenderer semantics needs a power-of-two texture size (S/OceanRenderer.cs:231) */
+    MW_ENOTCOMMENSURATE = 3, /* reserved: (unit_width != length/N is served by the direct-sum kernel instead) */
+    MW_ENOMEM = 4,
+    MW_EDEVICE = 5,          /* no usable HIP device / HIP runtime error */
+    MW_ESTATE = 6            /* call order violation (e.g. evaluate before a spectrum exists) */
+} mw_status;
+
+typedef enum {
+    MW_SEM_FFTMESH = 0,       /* S/FFTMesh.cs: centred k, quantised dispersion, closed-form time, spectral normals */
+    MW_SEM_OCEANRENDERER = 1  /* S/OceanRenderer.cs + the F/ shaders: FFT-order k, capillary dispersion, iterated phase */
+} mw_semantics;
+
+/* Public Inspector fields of S/FFTMesh.cs:9-23 and S/OceanRenderer.cs:10-19, plus the constants the
+ * reference hard-codes (gravity = G = 9.81f, S/FFTMesh.cs:52, F/FFTCommon.cginc:9). */
+typedef struct {
+    int32_t resolution; /* FFTMesh: grid is resolution^2.  OceanRenderer: textures are (8*resolution)^2 (S/OceanRenderer.cs:136) */
+    float unit_width;   /* unitWidth */
+    float length;       /* length */
+    float wind_x, wind_y; /* wind */
+    float amplitude;    /* amplitude (OceanRenderer divides by 10000 itself, S/OceanRenderer.cs:149) */
+    float choppiness;   /* choppiness */
+    float gravity;      /* 9.81f in the reference */
+    float t_division;   /* FFTMesh.tDivision  (S/FFTMesh.cs:70) */
+    float mult;         /* OceanRenderer.mult (S/OceanRenderer.cs:223) */
+    uint64_t seed;      /* seed of the library's documented counter RNG (the reference never seeds Unity's) */
+    int32_t semantics;  /* mw_semantics */
+    int32_t device;     /* HIP device ordinal */
+} mw_params;
+
+/* flags of mw_ocean_evaluate_device */
+#define MW_OUT_WHITE_SCALAR 0u /* whitecap written as 1 float per vertex (the canonical 28 B/point output) */
+#define MW_OUT_COLOR_RGBA 1u   /* whitecap replicated into a Unity Color (S/FFTMesh.cs:274), 16 B per vertex */
+
+int32_t mw_abi_version(void);
+const char* mw_last_error(void);
+int32_t mw_device_count(void);
+void mw_params_default(mw_params* p, int32_t semantics); /* Inspector defaults of the two MonoBehaviours */
+
+/* ---- lifecycle --------------------------------------------------------------------------------
+ * mw_ocean_create = SetParams + GenerateMesh's spectrum fill (S/FFTMesh.cs:90-99,114-116;
+ * S/OceanRenderer.cs:116-170,209-214): allocates device state and generates h0 / h0conj on the GPU
+ * from params->seed (Phillips, S/FFTMesh.cs:149-166; Box-Muller htilde0, :168-176).                */
+mw_status mw_ocean_create(const mw_params* params, mw_ocean** out);
+void mw_ocean_destroy(mw_ocean* o);
+
+/* Run all subsequent work of this handle on an existing hipStream_t (e.g. torch's current stream).
+ * NULL = the library's own stream (default).                                                       */
+mw_status mw_ocean_set_stream(mw_ocean* o, void* hip_stream);
+void* mw_ocean_get_stream(mw_ocean* o);
+mw_status mw_ocean_synchronize(mw_ocean* o);
+
+/* choppiness / tDivision / mult may change between frames without regenerating the spectrum
+ * (S/FFTMesh.cs:244-245 reads choppiness every frame; S/OceanRenderer.cs:96).                      */
+mw_status mw_ocean_set_choppiness(mw_ocean* o, float choppiness);
+
+/* Inject / read back verttilde and vertConj (S/FFTMesh.cs:35-36,114-116), N*N*2 floats each,
+ * idx = i*N + j.  Injection is how a caller reproduces a Unity-generated spectrum exactly, and
+ * how the parity tests feed identical inputs to the oracle and to the GPU.                         */
+mw_status mw_ocean_set_spectrum(mw_ocean* o, const float* h0_xy, const float* h0conj_xy);
+mw_status mw_ocean_get_spectrum(mw_ocean* o, float* h0_xy, float* h0conj_xy);
+
+/* GenerateMesh outputs (S/FFTMesh.cs:101-139, S/OceanRenderer.cs:172-207): rest vertices [N*N*3],
+ * normals [N*N*3], uvs [N*N*2], triangle indices [(N-1)^2*6].  Any pointer may be NULL.            */
+mw_status mw_ocean_rest_mesh(mw_ocean* o, float* vertices_xyz, float* normals_xyz, float* uvs_xy, int32_t* indices);
+int64_t mw_ocean_index_count(const mw_ocean* o);
+int32_t mw_ocean_grid_size(const mw_ocean* o); /* N of the synthesis grid (8*resolution in OceanRenderer mode) */
+
+/* ---- per-frame: FFTMesh.EvaluateWaves(t)  (S/FFTMesh.cs:224-280) -------------------------------
+ * host outputs: mesh.vertices [N*N*3], mesh.normals [N*N*3], mesh.colors [N*N*4].                  */
+mw_status mw_ocean_evaluate(mw_ocean* o, float t, float* vertices_xyz, float* normals_xyz, float* colors_rgba);
+
+/* FFTMesh.Update (S/FFTMesh.cs:60-73): timer += delta_time / tDivision; EvaluateWaves(timer).      */
+mw_status mw_ocean_update(mw_ocean* o, float delta_time, float* vertices_xyz, float* normals_xyz, float* colors_rgba);
+float mw_ocean_timer(const mw_ocean* o);
+mw_status mw_ocean_reset_timer(mw_ocean* o); /* the `generate` tick of S/FFTMesh.cs:62-68 */
+
+/* Throughput form: nsteps independent time-steps t[0..nsteps) of the same ocean in one enqueue
+ * (FFTMesh semantics is a pure function of (h0, h0conj, t), S/FFTMesh.cs:178-190).  Outputs stay in
+ * device memory: d_vertices [nsteps][N*N*3], d_normals [nsteps][N*N*3], d_white [nsteps][N*N] or
+ * [nsteps][N*N*4] with MW_OUT_COLOR_RGBA.  t is a HOST array.  Asynchronous on the handle's stream. */
+mw_status mw_ocean_evaluate_device(mw_ocean* o, const float* t, int32_t nsteps, void* d_vertices, void* d_normals,
+                                   void* d_white, uint32_t flags);
+int32_t mw_ocean_max_batch(const mw_ocean* o); /* largest nsteps one enqueue accepts */
+
+/* ---- per-frame: OceanRenderer.GenerateTexture()  (S/OceanRenderer.cs:216-316) ------------------
+ * advances the stateful phase by delta_time*mult and produces the four result textures, host side:
+ * height [M*M] (= heightTexture.r), disp_xz [M*M*2] (= displacementTexture.rb),
+ * normal_xyz [M*M*3] (= normalTexture.rgb), white [M*M] (= whiteTexture.r); M = 8*resolution,
+ * texel (px,py) at index py*M + px.  Any pointer may be NULL.                                      */
+mw_status mw_ocean_generate_texture(mw_ocean* o, float delta_time, float* height, float* disp_xz, float* normal_xyz,
+                                    float* white);
+mw_status mw_ocean_generate_texture_device(mw_ocean* o, float delta_time, void* d_height, void* d_disp_xz,
+                                           void* d_normal_xyz, void* d_white);
+
+/* ---- measurement hook (bench.py): times each kernel of one FFTMesh step with hipEvents on the
+ * handle's stream.  ms_out[k] = mean duration of kernel k over iters launches of `nsteps` batched
+ * time-steps; names_out[k] = static kernel name.  Returns the kernel count through *nkernels.      */
+mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, const char** names_out,
+                                   int32_t* nkernels);
+
+/* ---- pond: Gerstner vertex displacement  (W/MistralWaterLib.cginc:71-99,154-180) ---------------
+ * pos_xyz/out_xyz [nverts*3] world positions; waves [nwaves*3] = {dir.x, dir.y, speed}; amplitude is
+ * the already x0.01-scaled _Amplitude (:172).  out = pos + offsets (:176).  Host pointers, synchronous. */
+mw_status mw_gerstner_displace(const float* pos_xyz, int64_t nverts, const float* waves, int32_t nwaves,
+                               float amplitude, float frequency, float steepness, float t, float* out_xyz,
+                               int32_t device);
+/* device-pointer form, asynchronous on hip_stream (NULL = default stream) */
+mw_status mw_gerstner_displace_device(const void* d_pos_xyz, int64_t nverts, const float* waves, int32_t nwaves,
+                                      float amplitude, float frequency, float steepness, float t, void* d_out_xyz,
+                                      void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISTRAL_WATER_H */

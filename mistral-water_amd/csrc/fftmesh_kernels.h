@@ -1,0 +1,397 @@
+// fftmesh_kernels.h -- thread-level bodies of the FFTMesh-semantics kernels (MW_SEM_FFTMESH).
+//
+// Replaces the O(N^4) hot loop of the reference's CPU path
+//   S/FFTMesh.cs:178-190 (htilde), :192-220 (Displacement), :224-280 (EvaluateWaves)
+// by two LDS-staged Stockham passes over a Hermitian-packed spectrum (DESIGN.md sections 3-5).
+//
+// Each kernel is written as a sequence of *phases* separated by workgroup barriers.  A phase is
+// an MW_HD function of (block index, thread index, per-thread register state, LDS pointer), so
+// the same code is launched by fftmesh.hip on the GPU and stepped in lock-step by the host
+// emulation in tests/emul (test infrastructure only).
+#pragma once
+#include "mw_math.h"
+
+namespace mw {
+
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
+
+struct OceanConsts {
+    int N;
+    float length, gravity, unit_width, choppiness;
+};
+
+#define MW_MAX_BATCH 32
+struct StepTimes {
+    float t[MW_MAX_BATCH];
+};
+
+MW_HD void mw_sincos(float x, float* s, float* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincosf(x, s, c);  // ocml accurate path (full range reduction), not __sincosf
+#else
+    *s = sinf(x);
+    *c = cosf(x);
+#endif
+}
+
+// =============================== init-time element kernels ==================================
+
+// S/FFTMesh.cs:149-166 Phillips(n,m) in float32 (device libm; tolerance-checked vs the oracle)
+MW_HD float phillips_f32(int N, float length, float wind_x, float wind_y, float amplitude, float gravity, int n, int m) {
+    float kx = sdiv((float)(2 * n - N), length) * MW_PI_F;
+    float kz = sdiv((float)(2 * m - N), length) * MW_PI_F;
+    float k_length = sqrtf(kx * kx + kz * kz);
+    if (k_length < MW_EPS_F) return 0.0f;
+    float k2 = k_length * k_length, k4 = k2 * k2;
+    float knx = 0.f, knz = 0.f;
+    if (k_length > 1e-5f) { knx = kx / k_length; knz = kz / k_length; }
+    float w_length = sqrtf(wind_x * wind_x + wind_y * wind_y);
+    float wnx = 0.f, wny = 0.f;
+    if (w_length > 1e-5f) { wnx = wind_x / w_length; wny = wind_y / w_length; }
+    float kDotW = knx * wnx + knz * wny;
+    float l = w_length * w_length / gravity;
+    float l2 = l * l;
+    float damping = 0.001f;  // :163
+    float L2 = l2 * damping * damping;
+    return amplitude * expf(-1.f / (k2 * l2)) / k4 * (kDotW * kDotW) * expf(-k2 * L2);
+}
+
+// S/FFTMesh.cs:168-176 htilde0 with the library RNG; :114-116 fill order (4 draws / point)
+MW_HD void spectrum_element(int N, float length, float wind_x, float wind_y, float amplitude, float gravity,
+                            uint64_t seed, int i, int j, cf* h0, cf* h0c) {
+    uint64_t idx = (uint64_t)i * N + j;
+    float ph[2] = {phillips_f32(N, length, wind_x, wind_y, amplitude, gravity, i, j),
+                   phillips_f32(N, length, wind_x, wind_y, amplitude, gravity, N - i, N - j)};
+    cf out[2];
+    for (int d = 0; d < 2; d++) {
+        float z1 = uniform01(seed, 4 * idx + 2 * d), z2 = uniform01(seed, 4 * idx + 2 * d + 1);
+        float rad = sqrtf(-2.f * logf(z1));
+        float s, c;
+        mw_sincos(2.0f * MW_PI_F * z2, &s, &c);
+        float sc = sqrtf(ph[d] / 2.f);
+        out[d] = mk(rad * c * sc, rad * s * sc);
+    }
+    h0[idx] = out[0];
+    h0c[idx] = mk(out[1].x, -out[1].y);  // :116
+}
+
+// S/FFTMesh.cs:101-139 GenerateMesh, one vertex (and its up-to-two triangles) per call
+MW_HD void rest_mesh_element(int N, float unit_width, int i, int j, float* vertices, float* normals, float* uvs,
+                             int32_t* indices) {
+    int cur = i * N + j;
+    if (vertices) {
+        vertices[3 * cur + 0] = rest_coord(N, unit_width, i);
+        vertices[3 * cur + 1] = 0.f;
+        vertices[3 * cur + 2] = rest_coord(N, unit_width, j);
+    }
+    if (normals) { normals[3 * cur] = 0.f; normals[3 * cur + 1] = 1.f; normals[3 * cur + 2] = 0.f; }
+    if (uvs) {
+        uvs[2 * cur + 0] = sdiv(smul((float)i, 1.0f), (float)(N - 1));  // :117
+        uvs[2 * cur + 1] = sdiv(smul((float)j, 1.0f), (float)(N - 1));
+    }
+    if (!indices || j == N - 1) return;  // :118
+    // the reference appends sequentially; closed form of indiceCount at (i,j):
+    //   row 0 and row N-1 emit 3 indices per cell, interior rows 6.
+    int64_t base;
+    if (i == 0) base = 3 * (int64_t)j;
+    else base = 3 * (int64_t)(N - 1) + (int64_t)(i - 1) * 6 * (N - 1) + (i == N - 1 ? 3 : 6) * (int64_t)j;
+    if (i != N - 1) {  // :120-125
+        indices[base++] = cur; indices[base++] = cur + 1; indices[base++] = cur + N;
+    }
+    if (i != 0) {  // :126-131
+        indices[base++] = cur; indices[base++] = cur - N + 1; indices[base++] = cur + 1;
+    }
+}
+
+// Hermitian packing tables.  k = (i,j), mk = mirror, s = -1 when exactly one
+// index is the Nyquist index 0.  Real output fields only need
+//   Hh(k,t) = 1/2 [h~(k,t) + s conj h~(mk,t)] = P e^{i w t} + Q e^{-i w t}
+// with P = 1/2 (h0(k) + s conj h0c(mk)), Q = 1/2 (h0c(k) + s conj h0(mk)); on the two Nyquist lines
+// the odd multipliers need Ha = Hh + D, D = dP e^{iwt} + dQ e^{-iwt}, dP = -s conj h0c(mk), dQ = -s conj h0(mk).
+// PQt is stored TRANSPOSED ([j][i]) so that pass 1 (transform along i) reads contiguous rows.
+MW_HD void prep_element(int N, int i, int j, const cf* h0, const cf* h0c, f4* PQt, f4* dPQ_i0, f4* dPQ_j0) {
+    int mi = (N - i) & (N - 1), mj = (N - j) & (N - 1);
+    float s = ((i == 0) != (j == 0)) ? -1.f : 1.f;
+    cf a = h0[(size_t)i * N + j], b = h0c[(size_t)i * N + j];
+    cf am = h0[(size_t)mi * N + mj], bm = h0c[(size_t)mi * N + mj];
+    f4 pq;
+    pq.x = 0.5f * (a.x + s * bm.x);
+    pq.y = 0.5f * (a.y - s * bm.y);
+    pq.z = 0.5f * (b.x + s * am.x);
+    pq.w = 0.5f * (b.y - s * am.y);
+    PQt[(size_t)j * N + i] = pq;
+    f4 d;
+    d.x = -s * bm.x; d.y = s * bm.y; d.z = -s * am.x; d.w = s * am.y;
+    if (i == 0) dPQ_i0[j] = d;
+    if (j == 0) dPQ_j0[i] = d;
+}
+
+// =============================== pass 1: transform along i ===================================
+// grid (N/4, nsteps); block 4*T threads; block jb owns spectrum columns j = 4 jb .. 4 jb + 3.
+struct P1Args {
+    const f4* PQt;
+    const f4* dPQ_i0;
+    const f4* dPQ_j0;
+    const cf* W;     // e^{+2 pi i k/N}, k < N
+    const cf* Wpre;  // (-1)^m e^{i pi m/N}, m < 2N
+    cf* E;           // exchange buffer [step][3][N/4][N][4]
+    OceanConsts c;
+};
+
+template <int N>
+struct P1Geom {
+    static constexpr int T = FftGeom<N>::T;
+    static constexpr int NTHREADS = 4 * T;
+    static constexpr int BUFSTRIDE = FftGeom<N>::LBUF + 4;
+    static constexpr int LDS_BYTES = 4 * BUFSTRIDE * (int)sizeof(cf);
+};
+
+// h~-like packed spectrum Hh(k,t) times the pre-twiddle, 16 points per thread (column w, i = u + T q)
+template <int N>
+MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, cf (&hh)[16]) {
+    constexpr int T = FftGeom<N>::T;
+    const int w = tid / T, u = tid % T, j = 4 * jb + w;
+    f4 pq[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) pq[q] = A.PQt[(size_t)j * N + u + T * q];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int i = u + T * q;
+        float th = omega_t_f32(N, A.c.length, A.c.gravity, i, j, t);
+        float s, c;
+        mw_sincos(th, &s, &c);
+        hh[q] = cmul(animate(pq[q].x, pq[q].y, pq[q].z, pq[q].w, c, s), A.Wpre[i + j]);
+    }
+}
+
+// multipliers of the packed fields: Z_f = (cx + cz) * Hh   (cx acts on the kx-odd part, cz on kz-odd)
+//   f=0: H                       Z1 = Hh
+//   f=1: Dx + i Dz               cx = -i kx/|k|, cz = -kz/|k|      (S/FFTMesh.cs:215, with its z sign)
+//   f=2: Sx + i Sz (slopes)      cx = -i kx,     cz = +kz          (S/FFTMesh.cs:212)
+MW_HD void field_coeffs(int f, float kx, float kz, cf* cx, cf* cz) {
+    if (f == 1) {
+        float kl = sqrtf(kx * kx + kz * kz);
+        float ux = 0.f, uz = 0.f;
+        if (!(kl < MW_EPS_F)) {  // :213
+            float inv = 1.0f / kl;
+            ux = kx * inv;
+            uz = kz * inv;
+        }
+        *cx = mk(0.f, -ux);
+        *cz = mk(-uz, 0.f);
+    } else {
+        *cx = mk(0.f, -kx);
+        *cz = mk(kz, 0.f);
+    }
+}
+
+template <int N>
+MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, float t, const cf (&hh)[16], cf (&x)[16]) {
+    constexpr int T = FftGeom<N>::T;
+    const int w = tid / T, u = tid % T, j = 4 * jb + w;
+    if (f == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) x[q] = hh[q];
+        return;
+    }
+    const float kz = wave_k(N, A.c.length, j);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int i = u + T * q;
+        cf cx, cz;
+        field_coeffs(f, wave_k(N, A.c.length, i), kz, &cx, &cz);
+        x[q] = cmul(cx + cz, hh[q]);
+    }
+    // Nyquist-line corrections (index 0 mirrors onto itself with a sign flip)
+    if (j == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int i = u + T * q;
+            f4 d = A.dPQ_j0[i];
+            float s, c;
+            mw_sincos(omega_t_f32(N, A.c.length, A.c.gravity, i, j, t), &s, &c);
+            cf dl = cmul(animate(d.x, d.y, d.z, d.w, c, s), A.Wpre[i + j]);
+            cf cx, cz;
+            field_coeffs(f, wave_k(N, A.c.length, i), kz, &cx, &cz);
+            x[q] = x[q] + cmul(cz, dl);
+        }
+    }
+    if (u == 0) {  // i == 0 lives in slot 0 of thread u == 0
+        f4 d = A.dPQ_i0[j];
+        float s, c;
+        mw_sincos(omega_t_f32(N, A.c.length, A.c.gravity, 0, j, t), &s, &c);
+        cf dl = cmul(animate(d.x, d.y, d.z, d.w, c, s), A.Wpre[j]);
+        cf cx, cz;
+        field_coeffs(f, wave_k(N, A.c.length, 0), kz, &cx, &cz);
+        x[0] = x[0] + cmul(cx, dl);
+    }
+}
+
+// final pass in the column-interleaved mapping + coalesced store of the exchange buffer
+template <int N>
+MW_HD void p1_finish(const P1Args& A, int jb, int step, int tid, int f, cf (&x)[16], const cf* lds) {
+    constexpr int T = FftGeom<N>::T;
+    const int w2 = tid & 3, u2 = tid >> 2;
+    load_slots<N>(x, u2, lds + w2 * P1Geom<N>::BUFSTRIDE);
+    final_stage<N, +1>(x, u2, A.W);
+    cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)jb * N * 4;
+#pragma unroll
+    for (int q = 0; q < 16; q++) Ef[(size_t)(u2 + T * q) * 4 + w2] = x[q];
+}
+
+// =============================== pass 2: transform along j + epilogue ========================
+// grid (N/R2, nsteps); block (R2+1)*T threads: groups 0..R2-1 own rows a0..a0+R2-1, group R2 is the
+// halo row a0+R2 (displacement field only) that the forward-difference Jacobian needs (S/FFTMesh.cs:262).
+struct P2Args {
+    const cf* E;
+    const cf* W;
+    float* vertices;  // [step][N*N*3]
+    float* normals;   // [step][N*N*3]
+    float* white;     // [step][N*N*white_stride]
+    int white_stride; // 1 (scalar) or 4 (Unity Color, S/FFTMesh.cs:274)
+    OceanConsts c;
+};
+
+template <int N, int R2>
+struct P2Geom {
+    static constexpr int T = FftGeom<N>::T;
+    static constexpr int NTHREADS = (R2 + 1) * T;
+    static constexpr int BUFSTRIDE = FftGeom<N>::LBUF + 4;
+    static constexpr int LDS_BYTES = (R2 + 1) * BUFSTRIDE * (int)sizeof(cf);
+};
+
+template <int N>
+struct P2State {
+    float noise[16];  // |0.3 n.xz| per slot (S/FFTMesh.cs:269-270)
+    float h[16];      // height
+    cf d[16];         // hds = (d.x, d.z), un-scaled by choppiness (S/FFTMesh.cs:247)
+};
+
+// field processing order in pass 2: slopes, height, displacement (displacement last: its LDS buffers
+// are then recycled as the hds neighbour exchange)
+MW_HD int p2_field(int k) { return k == 0 ? 2 : (k == 1 ? 0 : 1); }
+
+template <int N, int R2>
+MW_HD bool p2_active(int ab, int tid, int f) {
+    constexpr int T = FftGeom<N>::T;
+    const int g = tid / T;
+    return g < R2 || (f == 1 && ab * R2 + R2 < N);
+}
+
+// stage-A load in the row-interleaved mapping: 16 consecutive lanes read one full 128-B line
+template <int N, int R2>
+MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[16], cf* lds) {
+    constexpr int T = FftGeom<N>::T;
+    int r1, u1;
+    if (tid < R2 * T) { r1 = tid % R2; u1 = tid / R2; }
+    else { r1 = R2; u1 = tid - R2 * T; }
+    const cf* Ef = A.E + ((size_t)step * 3 + f) * N * N;
+    const int row = ab * R2 + r1;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int j = u1 + T * q;
+        x[q] = Ef[((size_t)(j >> 2) * N + row) * 4 + (j & 3)];
+    }
+    stageA_store<N, +1>(x, u1, lds + r1 * P2Geom<N, R2>::BUFSTRIDE);
+}
+template <int N, int R2>
+MW_HD void p2_mid_load(int tid, cf (&x)[16], const cf* lds) {
+    constexpr int T = FftGeom<N>::T;
+    int r1, u1;
+    if (tid < R2 * T) { r1 = tid % R2; u1 = tid / R2; }
+    else { r1 = R2; u1 = tid - R2 * T; }
+    load_slots<N>(x, u1, lds + r1 * P2Geom<N, R2>::BUFSTRIDE);
+}
+template <int N, int R2>
+MW_HD void p2_mid_store(const P2Args& A, int tid, cf (&x)[16], cf* lds) {
+    constexpr int T = FftGeom<N>::T;
+    int r1, u1;
+    if (tid < R2 * T) { r1 = tid % R2; u1 = tid / R2; }
+    else { r1 = R2; u1 = tid - R2 * T; }
+    stageB_store<N, +1>(x, u1, lds + r1 * P2Geom<N, R2>::BUFSTRIDE, A.W);
+}
+
+// final pass in the row-major mapping (thread (g,u) owns row a0+g, columns b = u + T q)
+template <int N, int R2>
+MW_HD void p2_finish(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[16], P2State<N>& st, const cf* lds) {
+    constexpr int T = FftGeom<N>::T;
+    const int g = tid / T, u = tid % T, a = ab * R2 + g;
+    load_slots<N>(x, u, lds + g * P2Geom<N, R2>::BUFSTRIDE);
+    final_stage<N, +1>(x, u, A.W);
+    if (f == 2) {  // slopes -> unit normal (S/FFTMesh.cs:218), stored at once
+        float* nout = A.normals + ((size_t)step * N * N + (size_t)a * N) * 3;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int b = u + T * q;
+            const float sg = post_sign(a, b);
+            const float sx = sg * x[q].x, sz = sg * x[q].y;
+            const float mag = sqrtf(sx * sx + 1.0f + sz * sz);
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            if (mag > 1e-5f) { nx = sx / mag; ny = 1.0f / mag; nz = sz / mag; }  // Vector3.Normalize [unity]
+            nout[3 * b + 0] = nx;
+            nout[3 * b + 1] = ny;
+            nout[3 * b + 2] = nz;
+            const float n0 = smul(fabsf(nx), 0.3f), n1 = smul(fabsf(nz), 0.3f);
+            st.noise[q] = ssqrt(sadd(smul(n0, n0), smul(n1, n1)));
+        }
+    } else if (f == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) st.h[q] = post_sign(a, u + T * q) * x[q].x;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const float sg = post_sign(a, u + T * q);
+            st.d[q] = mk(sg * x[q].x, sg * x[q].y);
+        }
+    }
+}
+
+// hds rows into LDS (plain index b) so that neighbours (a+1,b) and (a,b+1) can be read back
+template <int N, int R2>
+MW_HD void p2_publish_hds(int tid, const P2State<N>& st, cf* lds) {
+    constexpr int T = FftGeom<N>::T;
+    const int g = tid / T, u = tid % T;
+    cf* row = lds + g * P2Geom<N, R2>::BUFSTRIDE;
+#pragma unroll
+    for (int q = 0; q < 16; q++) row[u + T * q] = st.d[q];
+}
+
+// S/FFTMesh.cs:243-247 (vertex), :251-276 (Jacobian / whitecap)
+template <int N, int R2>
+MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State<N>& st, const cf* lds) {
+    constexpr int T = FftGeom<N>::T;
+    const int g = tid / T, u = tid % T, a = ab * R2 + g;
+    const cf* row = lds + g * P2Geom<N, R2>::BUFSTRIDE;
+    const cf* nxt = lds + (g + 1) * P2Geom<N, R2>::BUFSTRIDE;
+    float* vout = A.vertices + ((size_t)step * N * N + (size_t)a * N) * 3;
+    float* wout = A.white + ((size_t)step * N * N + (size_t)a * N) * A.white_stride;
+    const float rx = rest_coord(N, A.c.unit_width, a);
+    const bool has_i = (a != N - 1);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int b = u + T * q;
+        const bool has_j = (b != N - 1);
+        const cf d = st.d[q];
+        const cf dn_i = has_i ? nxt[b] : mk(0.f, 0.f);
+        const cf dn_j = has_j ? row[b + 1] : mk(0.f, 0.f);
+        vout[3 * b + 0] = ssub(rx, smul(d.x, A.c.choppiness));                             // :245
+        vout[3 * b + 1] = st.h[q];                                                         // :243
+        vout[3 * b + 2] = ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness));  // :244
+        // whitecap() wants |n.x|,|n.z| only through the noise magnitude, which p2_finish already formed
+        float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
+        if (has_i) { ax = smul(0.5f, ssub(d.x, dn_i.x)); ay = smul(0.5f, ssub(d.y, dn_i.y)); }  // :260-263
+        if (has_j) { bx = smul(0.5f, ssub(d.x, dn_j.x)); by = smul(0.5f, ssub(d.y, dn_j.y)); }  // :264-267
+        const float jac = ssub(smul(sadd(1.f, ax), sadd(1.f, by)), smul(ay, bx));          // :268
+        const float turb = fmaxf(sadd(ssub(1.f, jac), st.noise[q]), 0.f);                  // :270
+        const float xx = smoothstep01(turb);                                               // :273
+        if (A.white_stride == 1) {
+            wout[b] = xx;
+        } else {
+            wout[4 * b + 0] = xx; wout[4 * b + 1] = xx; wout[4 * b + 2] = xx; wout[4 * b + 3] = xx;  // :274
+        }
+    }
+}
+
+}  // namespace mw

@@ -1,0 +1,81 @@
+// gerstner_kernels.h -- pond path: Gerstner vertex displacement (BASELINE config 5).
+// Replaces W/MistralWaterLib.cginc:71-99 Gerstner() as called from :154-180 Displacement().
+// Streaming kernel, 24 B/vertex algorithmic (read position 12 B + write displaced position 12 B).
+#pragma once
+#include "fftmesh_kernels.h"
+
+#define MW_GERSTNER_MAX_WAVES 16
+
+namespace mw {
+
+struct GerstnerWaves {
+    float dx[MW_GERSTNER_MAX_WAVES], dy[MW_GERSTNER_MAX_WAVES], speed[MW_GERSTNER_MAX_WAVES];
+};
+
+// one vertex: offsets of W/MistralWaterLib.cginc:77-88, added to the position (:176)
+MW_HD void gerstner_vertex(const GerstnerWaves& wv, int nwaves, float amplitude, float frequency, float steepness, float t,
+                           float px, float py, float pz, float* ox, float* oy, float* oz) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    const float sa = steepness * amplitude;  // :77-78
+    for (int i = 0; i < nwaves; i++) {
+        const float th = frequency * (wv.dx[i] * px + wv.dy[i] * pz) + t * wv.speed[i];  // :80-84 (sVertex.xz = world x,z)
+        float s, c;
+        mw_sincos(th, &s, &c);
+        sx += c * (sa * wv.dx[i]);  // :86
+        sz += c * (sa * wv.dy[i]);  // :87
+        sy += s;                    // :88
+    }
+    *ox = px + sx;
+    *oy = py + amplitude * sy;
+    *oz = pz + sz;
+}
+
+#if defined(__HIPCC__)
+// 4 vertices (= 3 x float4) per thread: every load/store is a 16-B access, lanes contiguous.
+__global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts,
+                                                  GerstnerWaves wv, int nwaves, float amplitude, float frequency,
+                                                  float steepness, float t) {
+    const int64_t nquads = nverts >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquads; qd += stride) {
+        const f4* p = reinterpret_cast<const f4*>(pos) + qd * 3;
+        f4 a = p[0], b = p[1], c = p[2];
+        float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            gerstner_vertex(wv, nwaves, amplitude, frequency, steepness, t, v[3 * k], v[3 * k + 1], v[3 * k + 2], &v[3 * k],
+                            &v[3 * k + 1], &v[3 * k + 2]);
+        f4* o = reinterpret_cast<f4*>(out) + qd * 3;
+        f4 r0 = {v[0], v[1], v[2], v[3]}, r1 = {v[4], v[5], v[6], v[7]}, r2 = {v[8], v[9], v[10], v[11]};
+        o[0] = r0; o[1] = r1; o[2] = r2;
+    }
+    // tail (nverts % 4) by the first few threads of block 0
+    const int64_t tail0 = nquads << 2;
+    if (blockIdx.x == 0 && threadIdx.x < (nverts - tail0)) {
+        const int64_t vtx = tail0 + threadIdx.x;
+        float ox, oy, oz;
+        gerstner_vertex(wv, nwaves, amplitude, frequency, steepness, t, pos[3 * vtx], pos[3 * vtx + 1], pos[3 * vtx + 2], &ox,
+                        &oy, &oz);
+        out[3 * vtx] = ox; out[3 * vtx + 1] = oy; out[3 * vtx + 2] = oz;
+    }
+}
+
+static inline hipError_t gerstner_launch(const float* d_pos, int64_t nverts, const float* waves, int nwaves, float amplitude,
+                                         float frequency, float steepness, float t, float* d_out, hipStream_t st) {
+    GerstnerWaves wv;
+    for (int i = 0; i < MW_GERSTNER_MAX_WAVES; i++) {
+        wv.dx[i] = i < nwaves ? waves[3 * i] : 0.f;
+        wv.dy[i] = i < nwaves ? waves[3 * i + 1] : 0.f;
+        wv.speed[i] = i < nwaves ? waves[3 * i + 2] : 0.f;
+    }
+    int64_t nquads = nverts >> 2;
+    int64_t blocks = (nquads + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
+    hipLaunchKernelGGL(k_gerstner, dim3((unsigned)blocks), dim3(256), 0, st, d_pos, d_out, nverts, wv, nwaves, amplitude,
+                       frequency, steepness, t);
+    return hipGetLastError();
+}
+#endif
+
+}  // namespace mw

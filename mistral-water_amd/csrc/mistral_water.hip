@@ -1,0 +1,624 @@
+// mistral_water.hip -- libmistral_water.so: gfx950 kernels + the C ABI of include/mistral_water.h.
+//
+// HIP-only product path: there is no CPU fallback anywhere in this file.  The CPU oracle lives in
+// /oracle and is never linked here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mistral_water.h"
+#include "fftmesh_kernels.h"
+#include "direct_kernels.h"
+#include "ocean_renderer_kernels.h"
+#include "gerstner_kernels.h"
+
+using namespace mw;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static mw_status fail(mw_status s, const std::string& m) {
+    g_err = m;
+    return s;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(MW_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// __global__ wrappers: FFTMesh semantics
+// ------------------------------------------------------------------------------------------------
+__global__ void k_spectrum(int N, float length, float wind_x, float wind_y, float amplitude, float gravity,
+                           uint64_t seed, cf* h0, cf* h0c) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * N) return;
+    spectrum_element(N, length, wind_x, wind_y, amplitude, gravity, seed, idx / N, idx % N, h0, h0c);
+}
+
+__global__ void k_rest_mesh(int N, float unit_width, float* vertices, float* normals, float* uvs, int32_t* indices) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * N) return;
+    rest_mesh_element(N, unit_width, idx / N, idx % N, vertices, normals, uvs, indices);
+}
+
+__global__ void k_prep(int N, const cf* h0, const cf* h0c, f4* PQt, f4* dPQ_i0, f4* dPQ_j0) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * N) return;
+    // idx enumerates the TRANSPOSED array so that the writes are the coalesced side
+    prep_element(N, idx % N, idx / N, h0, h0c, PQt, dPQ_i0, dPQ_j0);
+}
+
+__global__ void k_omega_t(int N, float length, float gravity, float t, float* out) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * N) return;
+    out[idx] = omega_t_f32(N, length, gravity, idx / N, idx % N, t);
+}
+
+template <int N>
+__global__ __launch_bounds__(P1Geom<N>::NTHREADS) void k_pass1(P1Args A, StepTimes times) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = FftGeom<N>::T;
+    constexpr int BS = P1Geom<N>::BUFSTRIDE;
+    const int tid = threadIdx.x, jb = blockIdx.x, step = blockIdx.y;
+    const float t = times.t[step];
+    const int w = tid / T, u = tid % T;
+    cf hh[16], x[16];
+    p1_animate<N>(A, jb, tid, t, hh);
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        p1_build<N>(A, jb, tid, f, t, hh, x);
+        if (f) __syncthreads();
+        stageA_store<N, +1>(x, u, lds + w * BS);
+        __syncthreads();
+        if (FftGeom<N>::HAS_B) {
+            load_slots<N>(x, u, lds + w * BS);
+            __syncthreads();
+            stageB_store<N, +1>(x, u, lds + w * BS, A.W);
+            __syncthreads();
+        }
+        p1_finish<N>(A, jb, step, tid, f, x, lds);
+    }
+}
+
+template <int N, int R2>
+__global__ __launch_bounds__((P2Geom<N, R2>::NTHREADS)) void k_pass2(P2Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = FftGeom<N>::T;
+    const int tid = threadIdx.x, ab = blockIdx.x, step = blockIdx.y;
+    const int g = tid / T;
+    P2State<N> st;
+    cf x[16];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int f = p2_field(k);
+        const bool active = p2_active<N, R2>(ab, tid, f);
+        if (k) __syncthreads();
+        if (active) p2_load<N, R2>(A, ab, step, tid, f, x, lds);
+        __syncthreads();
+        if (FftGeom<N>::HAS_B) {
+            if (active) p2_mid_load<N, R2>(tid, x, lds);
+            __syncthreads();
+            if (active) p2_mid_store<N, R2>(A, tid, x, lds);
+            __syncthreads();
+        }
+        if (active) p2_finish<N, R2>(A, ab, step, tid, f, x, st, lds);
+    }
+    __syncthreads();
+    if (p2_active<N, R2>(ab, tid, 1)) p2_publish_hds<N, R2>(tid, st, lds);
+    __syncthreads();
+    if (g < R2) p2_epilogue<N, R2>(A, ab, step, tid, st, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct mw_ocean {
+    mw_params p;
+    int N = 0;          // synthesis grid size
+    int sem = 0;
+    int device = 0;
+    bool use_fft = false;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    float timer = 0.f;
+    // FFTMesh state
+    cf *h0 = nullptr, *h0c = nullptr;
+    f4 *PQt = nullptr, *dPQ_i0 = nullptr, *dPQ_j0 = nullptr;
+    cf *W = nullptr, *Wpre = nullptr;
+    cf* E = nullptr;
+    int e_cap = 0;  // steps the exchange buffer holds
+    float *s_vert = nullptr, *s_norm = nullptr, *s_white = nullptr;  // 1-step scratch for the host API
+    DirectState direct;
+    // OceanRenderer state
+    OrState orr;
+};
+
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+template <typename T>
+static mw_status dmalloc(T** p, size_t count) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return MW_OK;
+}
+
+static mw_status upload_twiddles(mw_ocean* o) {
+    const int N = o->N;
+    std::vector<cf> W(N), Wpre(2 * N);
+    for (int k = 0; k < N; k++) {
+        double a = 2.0 * M_PI * (double)k / (double)N;
+        W[k] = mk((float)cos(a), (float)sin(a));
+    }
+    for (int m = 0; m < 2 * N; m++) {
+        double a = M_PI * (double)m / (double)N;  // (-1)^m e^{i pi m/N}
+        double sg = (m & 1) ? -1.0 : 1.0;
+        Wpre[m] = mk((float)(sg * cos(a)), (float)(sg * sin(a)));
+    }
+    mw_status s;
+    if ((s = dmalloc(&o->W, N)) != MW_OK) return s;
+    if ((s = dmalloc(&o->Wpre, 2 * N)) != MW_OK) return s;
+    HIP_TRY(hipMemcpy(o->W, W.data(), sizeof(cf) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(o->Wpre, Wpre.data(), sizeof(cf) * 2 * N, hipMemcpyHostToDevice));
+    return MW_OK;
+}
+
+static OceanConsts consts_of(const mw_ocean* o) {
+    OceanConsts c;
+    c.N = o->N;
+    c.length = o->p.length;
+    c.gravity = o->p.gravity;
+    c.unit_width = o->p.unit_width;
+    c.choppiness = o->p.choppiness;
+    return c;
+}
+
+// ---- kernel dispatch over N ----------------------------------------------------------------------
+template <int N>
+static constexpr int rows_per_block() { return N >= 4096 ? 2 : 4; }
+
+template <int N>
+static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nsteps, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<N>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, P1Geom<N>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_pass1<N>, dim3(N / 4, nsteps), dim3(P1Geom<N>::NTHREADS), P1Geom<N>::LDS_BYTES, st, A, tm);
+    return hipGetLastError();
+}
+template <int N>
+static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
+    constexpr int R2 = rows_per_block<N>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<N, R2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, P2Geom<N, R2>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    constexpr int NT = P2Geom<N, R2>::NTHREADS, LB = P2Geom<N, R2>::LDS_BYTES;
+    k_pass2<N, R2><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
+    return hipGetLastError();
+}
+
+#define MW_DISPATCH_N(N_, CALL)                  \
+    switch (N_) {                                \
+        case 64: { constexpr int NN = 64; CALL; } break;     \
+        case 128: { constexpr int NN = 128; CALL; } break;   \
+        case 256: { constexpr int NN = 256; CALL; } break;   \
+        case 512: { constexpr int NN = 512; CALL; } break;   \
+        case 1024: { constexpr int NN = 1024; CALL; } break; \
+        case 2048: { constexpr int NN = 2048; CALL; } break; \
+        case 4096: { constexpr int NN = 4096; CALL; } break; \
+        default: return fail(MW_EINVAL, "unsupported FFT size"); \
+    }
+
+static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps) {
+    P1Args A;
+    A.PQt = o->PQt; A.dPQ_i0 = o->dPQ_i0; A.dPQ_j0 = o->dPQ_j0; A.W = o->W; A.Wpre = o->Wpre; A.E = o->E;
+    A.c = consts_of(o);
+    hipError_t e = hipSuccess;
+    MW_DISPATCH_N(o->N, e = launch_pass1_n<NN>(A, tm, nsteps, o->stream));
+    if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pass1 launch: ") + hipGetErrorString(e));
+    return MW_OK;
+}
+static mw_status launch_pass2(mw_ocean* o, int nsteps, float* dv, float* dn, float* dw, int white_stride) {
+    P2Args A;
+    A.E = o->E; A.W = o->W; A.vertices = dv; A.normals = dn; A.white = dw; A.white_stride = white_stride;
+    A.c = consts_of(o);
+    hipError_t e = hipSuccess;
+    MW_DISPATCH_N(o->N, e = launch_pass2_n<NN>(A, nsteps, o->stream));
+    if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pass2 launch: ") + hipGetErrorString(e));
+    return MW_OK;
+}
+
+static mw_status ensure_exchange(mw_ocean* o, int nsteps) {
+    if (o->e_cap >= nsteps) return MW_OK;
+    if (o->E) {
+        HIP_TRY(hipStreamSynchronize(o->stream));
+        HIP_TRY(hipFree(o->E));
+        o->E = nullptr;
+        o->e_cap = 0;
+    }
+    mw_status s = dmalloc(&o->E, (size_t)nsteps * 3 * o->N * o->N);
+    if (s != MW_OK) return s;
+    o->e_cap = nsteps;
+    return MW_OK;
+}
+
+static mw_status run_prep(mw_ocean* o) {
+    const int N = o->N;
+    if (o->use_fft) {
+        hipLaunchKernelGGL(k_prep, dim3((N * N + 255) / 256), dim3(256), 0, o->stream, N, o->h0, o->h0c, o->PQt,
+                           o->dPQ_i0, o->dPQ_j0);
+        HIP_TRY(hipGetLastError());
+    }
+    return MW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int32_t mw_abi_version(void) { return MW_ABI_VERSION; }
+const char* mw_last_error(void) { return g_err.c_str(); }
+
+int32_t mw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void mw_params_default(mw_params* p, int32_t semantics) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->semantics = semantics;
+    p->gravity = 9.81f;  // S/FFTMesh.cs:52
+    p->seed = 1;
+    if (semantics == MW_SEM_OCEANRENDERER) {  // S/OceanRenderer.cs:10-19
+        p->mult = 2.f; p->unit_width = 1.f; p->resolution = 256; p->length = 256.f; p->choppiness = 1.5f;
+        p->amplitude = 1.f; p->wind_x = 0.f; p->wind_y = 0.f; p->t_division = 1.f;
+    } else {  // S/FFTMesh.cs:9-23
+        p->choppiness = 1.f; p->t_division = 1.f; p->resolution = 50; p->unit_width = 1.f; p->length = 1.f;
+        p->wind_x = 1.f; p->wind_y = 1.f; p->amplitude = 1.f; p->mult = 1.f;
+    }
+}
+
+void mw_ocean_destroy(mw_ocean* o) {
+    if (!o) return;
+    hipSetDevice(o->device);
+    if (o->stream) hipStreamSynchronize(o->stream);
+    hipFree(o->h0); hipFree(o->h0c); hipFree(o->PQt); hipFree(o->dPQ_i0); hipFree(o->dPQ_j0);
+    hipFree(o->W); hipFree(o->Wpre); hipFree(o->E); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white);
+    direct_free(o->direct);
+    or_free(o->orr);
+    if (o->own_stream) hipStreamDestroy(o->own_stream);
+    delete o;
+}
+
+mw_status mw_ocean_create(const mw_params* params, mw_ocean** out) {
+    if (!params || !out) return fail(MW_EINVAL, "mw_ocean_create: NULL argument");
+    *out = nullptr;
+    if (params->semantics != MW_SEM_FFTMESH && params->semantics != MW_SEM_OCEANRENDERER)
+        return fail(MW_EINVAL, "mw_ocean_create: unknown semantics");
+    if (params->resolution < 2) return fail(MW_EINVAL, "mw_ocean_create: resolution must be >= 2");
+    if (!(params->length > 0.f) || !(params->gravity > 0.f))
+        return fail(MW_EINVAL, "mw_ocean_create: length and gravity must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MW_EDEVICE, "mw_ocean_create: no HIP device visible (this library has no CPU fallback)");
+    if (params->device < 0 || params->device >= ndev) return fail(MW_EINVAL, "mw_ocean_create: bad device ordinal");
+    HIP_TRY(hipSetDevice(params->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, params->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MW_EDEVICE, std::string("mw_ocean_create: device is ") + prop.gcnArchName +
+                                    ", this library carries gfx950 (MI355X) code only");
+
+    mw_ocean* o = new (std::nothrow) mw_ocean();
+    if (!o) return fail(MW_ENOMEM, "mw_ocean_create: out of host memory");
+    o->p = *params;
+    o->sem = params->semantics;
+    o->device = params->device;
+    mw_status s = MW_OK;
+    hipError_t he = hipStreamCreateWithFlags(&o->own_stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { delete o; return fail(MW_EDEVICE, "hipStreamCreate failed"); }
+    o->stream = o->own_stream;
+
+    if (o->sem == MW_SEM_FFTMESH) {
+        const int N = params->resolution;
+        if (N > 4096) { mw_ocean_destroy(o); return fail(MW_EINVAL, "FFTMesh: resolution > 4096 unsupported"); }
+        o->N = N;
+        // FFT path precondition: power of two and unit_width == length / N exactly.
+        o->use_fft = is_pow2(N) && N >= 64 && (params->unit_width * (float)N == params->length);
+        const size_t NN = (size_t)N * N;
+        if ((s = dmalloc(&o->h0, NN)) != MW_OK || (s = dmalloc(&o->h0c, NN)) != MW_OK ||
+            (s = dmalloc(&o->s_vert, NN * 3)) != MW_OK || (s = dmalloc(&o->s_norm, NN * 3)) != MW_OK ||
+            (s = dmalloc(&o->s_white, NN * 4)) != MW_OK) { mw_ocean_destroy(o); return s; }
+        if (o->use_fft) {
+            if ((s = dmalloc(&o->PQt, NN)) != MW_OK || (s = dmalloc(&o->dPQ_i0, (size_t)N)) != MW_OK ||
+                (s = dmalloc(&o->dPQ_j0, (size_t)N)) != MW_OK || (s = upload_twiddles(o)) != MW_OK) {
+                mw_ocean_destroy(o); return s;
+            }
+        } else {
+            if (direct_alloc(o->direct, N) != 0) { mw_ocean_destroy(o); return fail(MW_ENOMEM, "direct path alloc failed"); }
+        }
+        hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, o->stream, N, params->length,
+                           params->wind_x, params->wind_y, params->amplitude, params->gravity, params->seed, o->h0, o->h0c);
+        if (hipGetLastError() != hipSuccess) { mw_ocean_destroy(o); return fail(MW_EDEVICE, "k_spectrum launch failed"); }
+        if ((s = run_prep(o)) != MW_OK) { mw_ocean_destroy(o); return s; }
+    } else {
+        const int M = params->resolution * 8;  // S/OceanRenderer.cs:136
+        if (!is_pow2(M)) { mw_ocean_destroy(o); return fail(MW_ENOTPOW2, "OceanRenderer: 8*resolution must be a power of two"); }
+        if (M < 64 || M > 4096) { mw_ocean_destroy(o); return fail(MW_EINVAL, "OceanRenderer: texture size must be in [64,4096]"); }
+        o->N = M;
+        if ((s = or_create(o->orr, *params, M, o->stream)) != MW_OK) {
+            std::string m = or_last_error();
+            mw_ocean_destroy(o);
+            return fail(s, m);
+        }
+    }
+    he = hipStreamSynchronize(o->stream);
+    if (he != hipSuccess) { mw_ocean_destroy(o); return fail(MW_EDEVICE, std::string("create sync: ") + hipGetErrorString(he)); }
+    *out = o;
+    return MW_OK;
+}
+
+mw_status mw_ocean_set_stream(mw_ocean* o, void* hip_stream) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    HIP_TRY(hipSetDevice(o->device));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    o->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : o->own_stream;
+    return MW_OK;
+}
+void* mw_ocean_get_stream(mw_ocean* o) { return o ? reinterpret_cast<void*>(o->stream) : nullptr; }
+mw_status mw_ocean_synchronize(mw_ocean* o) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    HIP_TRY(hipSetDevice(o->device));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
+}
+mw_status mw_ocean_set_choppiness(mw_ocean* o, float c) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    o->p.choppiness = c;
+    return MW_OK;
+}
+
+int32_t mw_ocean_grid_size(const mw_ocean* o) { return o ? o->N : 0; }
+int64_t mw_ocean_index_count(const mw_ocean* o) {
+    if (!o) return 0;
+    int64_t n = o->p.resolution;  // the MESH is resolution^2 in both modes (S/OceanRenderer.cs:132-135)
+    return (n - 1) * (n - 1) * 6;
+}
+int32_t mw_ocean_max_batch(const mw_ocean* o) { return (o && o->sem == MW_SEM_FFTMESH && o->use_fft) ? MW_MAX_BATCH : 1; }
+float mw_ocean_timer(const mw_ocean* o) { return o ? o->timer : 0.f; }
+mw_status mw_ocean_reset_timer(mw_ocean* o) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    o->timer = 0.f;
+    return MW_OK;
+}
+
+mw_status mw_ocean_set_spectrum(mw_ocean* o, const float* h0_xy, const float* h0conj_xy) {
+    if (!o || !h0_xy || !h0conj_xy) return fail(MW_EINVAL, "mw_ocean_set_spectrum: NULL argument");
+    if (o->sem != MW_SEM_FFTMESH) return fail(MW_ESTATE, "mw_ocean_set_spectrum: FFTMesh semantics only");
+    HIP_TRY(hipSetDevice(o->device));
+    const size_t bytes = sizeof(cf) * (size_t)o->N * o->N;
+    HIP_TRY(hipMemcpyAsync(o->h0, h0_xy, bytes, hipMemcpyHostToDevice, o->stream));
+    HIP_TRY(hipMemcpyAsync(o->h0c, h0conj_xy, bytes, hipMemcpyHostToDevice, o->stream));
+    mw_status s = run_prep(o);
+    if (s != MW_OK) return s;
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
+}
+mw_status mw_ocean_get_spectrum(mw_ocean* o, float* h0_xy, float* h0conj_xy) {
+    if (!o || !h0_xy || !h0conj_xy) return fail(MW_EINVAL, "mw_ocean_get_spectrum: NULL argument");
+    if (o->sem != MW_SEM_FFTMESH) return fail(MW_ESTATE, "mw_ocean_get_spectrum: FFTMesh semantics only");
+    HIP_TRY(hipSetDevice(o->device));
+    const size_t bytes = sizeof(cf) * (size_t)o->N * o->N;
+    HIP_TRY(hipMemcpyAsync(h0_xy, o->h0, bytes, hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipMemcpyAsync(h0conj_xy, o->h0c, bytes, hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
+}
+
+mw_status mw_ocean_rest_mesh(mw_ocean* o, float* vertices_xyz, float* normals_xyz, float* uvs_xy, int32_t* indices) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    HIP_TRY(hipSetDevice(o->device));
+    const int N = o->p.resolution;  // mesh resolution (not the 8x texture size in OceanRenderer mode)
+    const size_t NN = (size_t)N * N;
+    float *dv = nullptr, *dn = nullptr, *du = nullptr;
+    int32_t* di = nullptr;
+    const size_t nidx = (size_t)(N - 1) * (N - 1) * 6;
+    mw_status s = MW_OK;
+    if (vertices_xyz && (s = dmalloc(&dv, NN * 3)) != MW_OK) goto done;
+    if (normals_xyz && (s = dmalloc(&dn, NN * 3)) != MW_OK) goto done;
+    if (uvs_xy && (s = dmalloc(&du, NN * 2)) != MW_OK) goto done;
+    if (indices && (s = dmalloc(&di, nidx)) != MW_OK) goto done;
+    hipLaunchKernelGGL(k_rest_mesh, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, o->stream, N, o->p.unit_width, dv,
+                       dn, du, di);
+    if (hipGetLastError() != hipSuccess) { s = fail(MW_EDEVICE, "k_rest_mesh launch failed"); goto done; }
+    if (dv) hipMemcpyAsync(vertices_xyz, dv, NN * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream);
+    if (dn) hipMemcpyAsync(normals_xyz, dn, NN * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream);
+    if (du) hipMemcpyAsync(uvs_xy, du, NN * 2 * sizeof(float), hipMemcpyDeviceToHost, o->stream);
+    if (di) hipMemcpyAsync(indices, di, nidx * sizeof(int32_t), hipMemcpyDeviceToHost, o->stream);
+    if (hipStreamSynchronize(o->stream) != hipSuccess) s = fail(MW_EDEVICE, "rest_mesh sync failed");
+done:
+    hipFree(dv); hipFree(dn); hipFree(du); hipFree(di);
+    return s;
+}
+
+mw_status mw_ocean_evaluate_device(mw_ocean* o, const float* t, int32_t nsteps, void* d_vertices, void* d_normals,
+                                   void* d_white, uint32_t flags) {
+    if (!o || !t || !d_vertices || !d_normals || !d_white) return fail(MW_EINVAL, "mw_ocean_evaluate_device: NULL argument");
+    if (o->sem != MW_SEM_FFTMESH) return fail(MW_ESTATE, "mw_ocean_evaluate_device: FFTMesh semantics only");
+    if (nsteps < 1 || nsteps > mw_ocean_max_batch(o)) return fail(MW_EINVAL, "mw_ocean_evaluate_device: nsteps out of range");
+    HIP_TRY(hipSetDevice(o->device));
+    const int white_stride = (flags & MW_OUT_COLOR_RGBA) ? 4 : 1;
+    if (!o->use_fft) {
+        return direct_evaluate(o->direct, consts_of(o), o->h0, o->h0c, t[0], (float*)d_vertices, (float*)d_normals,
+                               (float*)d_white, white_stride, o->stream) == hipSuccess
+                   ? MW_OK
+                   : fail(MW_EDEVICE, "direct-sum kernels failed to launch");
+    }
+    mw_status s = ensure_exchange(o, nsteps);
+    if (s != MW_OK) return s;
+    StepTimes tm;
+    for (int k = 0; k < nsteps; k++) tm.t[k] = t[k];
+    if ((s = launch_pass1(o, tm, nsteps)) != MW_OK) return s;
+    return launch_pass2(o, nsteps, (float*)d_vertices, (float*)d_normals, (float*)d_white, white_stride);
+}
+
+mw_status mw_ocean_evaluate(mw_ocean* o, float t, float* vertices_xyz, float* normals_xyz, float* colors_rgba) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    if (o->sem != MW_SEM_FFTMESH) return fail(MW_ESTATE, "mw_ocean_evaluate: FFTMesh semantics only");
+    mw_status s = mw_ocean_evaluate_device(o, &t, 1, o->s_vert, o->s_norm, o->s_white, MW_OUT_COLOR_RGBA);
+    if (s != MW_OK) return s;
+    const size_t NN = (size_t)o->N * o->N;
+    if (vertices_xyz) HIP_TRY(hipMemcpyAsync(vertices_xyz, o->s_vert, NN * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (normals_xyz) HIP_TRY(hipMemcpyAsync(normals_xyz, o->s_norm, NN * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (colors_rgba) HIP_TRY(hipMemcpyAsync(colors_rgba, o->s_white, NN * 4 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
+}
+
+mw_status mw_ocean_update(mw_ocean* o, float delta_time, float* vertices_xyz, float* normals_xyz, float* colors_rgba) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    o->timer += delta_time / o->p.t_division;  // S/FFTMesh.cs:70
+    return mw_ocean_evaluate(o, o->timer, vertices_xyz, normals_xyz, colors_rgba);
+}
+
+mw_status mw_ocean_generate_texture_device(mw_ocean* o, float delta_time, void* d_height, void* d_disp_xz,
+                                           void* d_normal_xyz, void* d_white) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_generate_texture: OceanRenderer semantics only");
+    HIP_TRY(hipSetDevice(o->device));
+    o->orr.choppiness = o->p.choppiness;
+    mw_status s = or_generate(o->orr, delta_time, (float*)d_height, (float*)d_disp_xz, (float*)d_normal_xyz, (float*)d_white,
+                              o->stream);
+    if (s != MW_OK) return fail(s, or_last_error());
+    return MW_OK;
+}
+
+mw_status mw_ocean_generate_texture(mw_ocean* o, float delta_time, float* height, float* disp_xz, float* normal_xyz,
+                                    float* white) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_generate_texture: OceanRenderer semantics only");
+    mw_status s = mw_ocean_generate_texture_device(o, delta_time, nullptr, nullptr, nullptr, nullptr);
+    if (s != MW_OK) return s;
+    const size_t MM = (size_t)o->N * o->N;
+    if (height) HIP_TRY(hipMemcpyAsync(height, o->orr.out_height, MM * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (disp_xz) HIP_TRY(hipMemcpyAsync(disp_xz, o->orr.out_disp, MM * 2 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (normal_xyz) HIP_TRY(hipMemcpyAsync(normal_xyz, o->orr.out_normal, MM * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (white) HIP_TRY(hipMemcpyAsync(white, o->orr.out_white, MM * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
+}
+
+mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, const char** names_out,
+                                   int32_t* nkernels) {
+    if (!o || !ms_out || !nkernels || iters < 1) return fail(MW_EINVAL, "mw_ocean_profile_kernels: bad argument");
+    if (o->sem != MW_SEM_FFTMESH || !o->use_fft) return fail(MW_ESTATE, "mw_ocean_profile_kernels: FFT path only");
+    if (nsteps < 1 || nsteps > MW_MAX_BATCH) return fail(MW_EINVAL, "nsteps out of range");
+    HIP_TRY(hipSetDevice(o->device));
+    mw_status s = ensure_exchange(o, nsteps);
+    if (s != MW_OK) return s;
+    const size_t NN = (size_t)o->N * o->N;
+    float *dv = nullptr, *dn = nullptr, *dw = nullptr;
+    if (nsteps == 1) { dv = o->s_vert; dn = o->s_norm; dw = o->s_white; }
+    else {
+        if ((s = dmalloc(&dv, NN * 3 * nsteps)) != MW_OK || (s = dmalloc(&dn, NN * 3 * nsteps)) != MW_OK ||
+            (s = dmalloc(&dw, NN * nsteps)) != MW_OK) { hipFree(dv); hipFree(dn); hipFree(dw); return s; }
+    }
+    StepTimes tm;
+    for (int k = 0; k < nsteps; k++) tm.t[k] = 1.0f + (float)k / 60.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    static const char* names[2] = {"k_pass1 (h~ + transform along i)", "k_pass2 (transform along j + epilogue)"};
+    for (int k = 0; k < 2 && s == MW_OK; k++) {
+        // warm-up
+        s = (k == 0) ? launch_pass1(o, tm, nsteps) : launch_pass2(o, nsteps, dv, dn, dw, 1);
+        if (s != MW_OK) break;
+        hipEventRecord(e0, o->stream);
+        for (int it = 0; it < iters && s == MW_OK; it++)
+            s = (k == 0) ? launch_pass1(o, tm, nsteps) : launch_pass2(o, nsteps, dv, dn, dw, 1);
+        hipEventRecord(e1, o->stream);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        ms_out[k] = ms / (float)iters;
+        if (names_out) names_out[k] = names[k];
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (nsteps != 1) { hipFree(dv); hipFree(dn); hipFree(dw); }
+    *nkernels = 2;
+    return s;
+}
+
+// test hook: omega(i,j)*t exactly as the kernels form it (bit-exactness check vs the oracle)
+mw_status mw_debug_omega_t(mw_ocean* o, float t, float* out_host) {
+    if (!o || !out_host) return fail(MW_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(o->device));
+    const int N = o->N;
+    float* d = nullptr;
+    mw_status s = dmalloc(&d, (size_t)N * N);
+    if (s != MW_OK) return s;
+    hipLaunchKernelGGL(k_omega_t, dim3((N * N + 255) / 256), dim3(256), 0, o->stream, N, o->p.length, o->p.gravity, t, d);
+    hipMemcpyAsync(out_host, d, sizeof(float) * N * N, hipMemcpyDeviceToHost, o->stream);
+    hipError_t e = hipStreamSynchronize(o->stream);
+    hipFree(d);
+    return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, "mw_debug_omega_t failed");
+}
+
+// ---- pond -------------------------------------------------------------------------------------
+mw_status mw_gerstner_displace_device(const void* d_pos_xyz, int64_t nverts, const float* waves, int32_t nwaves,
+                                      float amplitude, float frequency, float steepness, float t, void* d_out_xyz,
+                                      void* hip_stream) {
+    if (!d_pos_xyz || !d_out_xyz || !waves) return fail(MW_EINVAL, "mw_gerstner_displace_device: NULL argument");
+    if (nwaves < 1 || nwaves > MW_GERSTNER_MAX_WAVES) return fail(MW_EINVAL, "nwaves must be in [1,16]");
+    if (nverts < 0) return fail(MW_EINVAL, "nverts < 0");
+    if (nverts == 0) return MW_OK;
+    hipError_t e = gerstner_launch((const float*)d_pos_xyz, nverts, waves, nwaves, amplitude, frequency, steepness, t,
+                                   (float*)d_out_xyz, reinterpret_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail(MW_EDEVICE, std::string("gerstner launch: ") + hipGetErrorString(e));
+    return MW_OK;
+}
+
+mw_status mw_gerstner_displace(const float* pos_xyz, int64_t nverts, const float* waves, int32_t nwaves, float amplitude,
+                               float frequency, float steepness, float t, float* out_xyz, int32_t device) {
+    if (!pos_xyz || !out_xyz || !waves) return fail(MW_EINVAL, "mw_gerstner_displace: NULL argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MW_EDEVICE, "mw_gerstner_displace: no HIP device visible (no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(MW_EINVAL, "bad device ordinal");
+    if (nverts <= 0) return nverts == 0 ? MW_OK : fail(MW_EINVAL, "nverts < 0");
+    HIP_TRY(hipSetDevice(device));
+    float *dp = nullptr, *dq = nullptr;
+    const size_t bytes = (size_t)nverts * 3 * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&dp, bytes));
+    if (hipMalloc((void**)&dq, bytes) != hipSuccess) { hipFree(dp); return fail(MW_ENOMEM, "hipMalloc failed"); }
+    mw_status s = MW_OK;
+    if (hipMemcpy(dp, pos_xyz, bytes, hipMemcpyHostToDevice) != hipSuccess) s = fail(MW_EDEVICE, "H2D failed");
+    if (s == MW_OK) s = mw_gerstner_displace_device(dp, nverts, waves, nwaves, amplitude, frequency, steepness, t, dq, nullptr);
+    if (s == MW_OK && hipDeviceSynchronize() != hipSuccess) s = fail(MW_EDEVICE, "gerstner kernel failed");
+    if (s == MW_OK && hipMemcpy(out_xyz, dq, bytes, hipMemcpyDeviceToHost) != hipSuccess) s = fail(MW_EDEVICE, "D2H failed");
+    hipFree(dp);
+    hipFree(dq);
+    return s;
+}
+
+}  // extern "C"

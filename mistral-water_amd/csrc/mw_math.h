@@ -1,0 +1,270 @@
+// mw_math.h -- arithmetic shared by every kernel of libmistral_water.so.
+//
+// Everything here is `__host__ __device__` so that tests/emul (a g++-compiled, host-side
+// lock-step emulation of the kernels' thread/LDS choreography) can exercise exactly the
+// code the GPU runs.  The emulation is test infrastructure; the product library contains
+// device code only and has no CPU fallback.
+//
+// Reference citations: S/ = /root/reference/Assets/Mistral Water/Scripts/.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MW_HD __host__ __device__ __forceinline__
+#else
+#define MW_HD inline
+#endif
+
+#define MW_PI_F 3.1415926536f  /* S/FFTMesh.cs:50 */
+#define MW_EPS_F 0.0001f       /* S/FFTMesh.cs:54 */
+
+namespace mw {
+
+// ---- complex helper ---------------------------------------------------------------------
+struct cf {
+    float x, y;
+};
+MW_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+MW_HD cf operator+(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+MW_HD cf operator-(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+MW_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+MW_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
+MW_HD cf cconj(cf a) { return mk(a.x, -a.y); }
+template <int SGN>
+MW_HD cf mul_si(cf a) {  // a * (SGN * i)
+    return SGN > 0 ? mk(-a.y, a.x) : mk(a.y, -a.x);
+}
+
+// ---- strict IEEE float32 (no FMA contraction): the "index-like" scalars ------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+MW_HD float smul(float a, float b) { return __fmul_rn(a, b); }
+MW_HD float sadd(float a, float b) { return __fadd_rn(a, b); }
+MW_HD float ssub(float a, float b) { return __fsub_rn(a, b); }
+MW_HD float sdiv(float a, float b) { return __fdiv_rn(a, b); }
+MW_HD float ssqrt(float a) { return __fsqrt_rn(a); }
+#else
+// host build of this header must use -ffp-contract=off
+MW_HD float smul(float a, float b) { return a * b; }
+MW_HD float sadd(float a, float b) { return a + b; }
+MW_HD float ssub(float a, float b) { return a - b; }
+MW_HD float sdiv(float a, float b) { return a / b; }
+MW_HD float ssqrt(float a) { return sqrtf(a); }
+#endif
+
+// S/FFTMesh.cs:141-147 Dispersion(n,m) * t  (:183) -- bit-for-bit the reference's float sequence.
+MW_HD float omega_f32(int N, float length, float gravity, int n, int m) {
+    float w = sdiv(smul(2.0f, MW_PI_F), length);
+    float kx = sdiv(smul(MW_PI_F, (float)(2 * n - N)), length);
+    float kz = sdiv(smul(MW_PI_F, (float)(2 * m - N)), length);
+    float s = sadd(smul(kx, kx), smul(kz, kz));
+    float r = ssqrt(smul(gravity, ssqrt(s)));
+    return smul(floorf(sdiv(r, w)), w);
+}
+MW_HD float omega_t_f32(int N, float length, float gravity, int n, int m, float t) {
+    return smul(omega_f32(N, length, gravity, n, m), t);
+}
+
+// S/FFTMesh.cs:201,204  kx = 2*PI*(i - resolution/2.0f)/length
+MW_HD float wave_k(int N, float length, int i) {
+    return sdiv(smul(smul(2.0f, MW_PI_F), ssub((float)i, sdiv((float)N, 2.0f))), length);
+}
+
+// S/FFTMesh.cs:107-112 rest coordinate of grid line a
+MW_HD float rest_coord(int N, float unit_width, int a) {
+    float base = smul((float)(a - N / 2), unit_width);
+    return (N % 2 == 0) ? sadd(base, sdiv(unit_width, 2.0f)) : base;
+}
+
+// output sign of the shifted 2-D inverse DFT: -(-1)^(a+b)   (DESIGN.md "transform identity")
+MW_HD float post_sign(int a, int b) { return ((a + b) & 1) ? 1.0f : -1.0f; }
+
+// Mathf.SmoothStep(0,1,t) [unity], S/FFTMesh.cs:273
+MW_HD float smoothstep01(float t) {
+    t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+    // -2 t^3 + 3 t^2, evaluated left to right like the C# expression
+    return sadd(smul(smul(smul(-2.0f, t), t), t), smul(smul(3.0f, t), t));
+}
+
+// S/FFTMesh.cs:258-274: whitecap scalar from hds (centre, +1 row, +1 col) and the unit normal.
+// has_next_i / has_next_j encode the edge rules  i != N-1 (:260)  and  j != N-1 (:264).
+MW_HD float whitecap(cf d, cf d_next_i, cf d_next_j, bool has_next_i, bool has_next_j, float nx, float nz) {
+    float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
+    if (has_next_i) { ax = smul(0.5f, ssub(d.x, d_next_i.x)); ay = smul(0.5f, ssub(d.y, d_next_i.y)); }
+    if (has_next_j) { bx = smul(0.5f, ssub(d.x, d_next_j.x)); by = smul(0.5f, ssub(d.y, d_next_j.y)); }
+    float jac = ssub(smul(sadd(1.f, ax), sadd(1.f, by)), smul(ay, bx));           // :268
+    float n0 = smul(fabsf(nx), 0.3f), n1 = smul(fabsf(nz), 0.3f);                 // :269
+    float turb = fmaxf(sadd(ssub(1.f, jac), ssqrt(sadd(smul(n0, n0), smul(n1, n1)))), 0.f);  // :270
+    return smoothstep01(turb);                                                    // :273
+}
+
+// ---- the library's counter RNG (documented in DESIGN.md; mirrors oracle/fftmesh_oracle.c) ---
+MW_HD uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+MW_HD float uniform01(uint64_t seed, uint64_t counter) {  // in (0,1]
+    uint64_t bits = mix64(seed * 0xD1342543DE82EF95ull + counter);
+    return (float)((uint32_t)(bits >> 40) + 1u) * (1.0f / 16777216.0f);
+}
+
+// ---- small in-register DFTs, natural-order in, natural-order out -------------------------
+// SGN = +1: kernel e^{+2 pi i nk/R} (unnormalised inverse);  SGN = -1: forward.
+template <int SGN>
+MW_HD void dft2(cf& a, cf& b) {
+    cf t = a;
+    a = t + b;
+    b = t - b;
+}
+template <int SGN>
+MW_HD void dft4(cf& a0, cf& a1, cf& a2, cf& a3) {
+    cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_si<SGN>(a1 - a3);
+    a0 = t0 + t2;
+    a1 = t1 + t3;
+    a2 = t0 - t2;
+    a3 = t1 - t3;
+}
+#define MW_SQRT1_2 0.70710678118654752440f
+#define MW_COS_PI_8 0.92387953251128675613f
+#define MW_SIN_PI_8 0.38268343236508977173f
+template <int SGN>
+MW_HD cf tw8(cf a, int m) {  // a * e^{SGN 2 pi i m/8}, m compile-time after unrolling
+    switch (m & 7) {
+        case 0: return a;
+        case 1: return mk((a.x - SGN * a.y) * MW_SQRT1_2, (SGN * a.x + a.y) * MW_SQRT1_2);
+        case 2: return mul_si<SGN>(a);
+        case 3: return mk((-a.x - SGN * a.y) * MW_SQRT1_2, (SGN * a.x - a.y) * MW_SQRT1_2);
+        case 4: return mk(-a.x, -a.y);
+        case 5: return mk((-a.x + SGN * a.y) * MW_SQRT1_2, (-SGN * a.x - a.y) * MW_SQRT1_2);
+        case 6: return mul_si<-SGN>(a);
+        default: return mk((a.x + SGN * a.y) * MW_SQRT1_2, (-SGN * a.x + a.y) * MW_SQRT1_2);
+    }
+}
+template <int SGN>
+MW_HD cf tw16(cf a, int m) {  // a * e^{SGN 2 pi i m/16}
+    m &= 15;
+    if ((m & 1) == 0) return tw8<SGN>(a, m >> 1);
+    // odd m: rotate by the multiple of 4 (quarter turns) then by +-pi/8 or +-3pi/8
+    float c, s;
+    switch (m) {
+        case 1: c = MW_COS_PI_8; s = MW_SIN_PI_8; break;
+        case 3: c = MW_SIN_PI_8; s = MW_COS_PI_8; break;
+        case 5: c = -MW_SIN_PI_8; s = MW_COS_PI_8; break;
+        case 7: c = -MW_COS_PI_8; s = MW_SIN_PI_8; break;
+        case 9: c = -MW_COS_PI_8; s = -MW_SIN_PI_8; break;
+        case 11: c = -MW_SIN_PI_8; s = -MW_COS_PI_8; break;
+        case 13: c = MW_SIN_PI_8; s = -MW_COS_PI_8; break;
+        default: c = MW_COS_PI_8; s = -MW_SIN_PI_8; break;
+    }
+    return cmul(a, mk(c, SGN * s));
+}
+template <int SGN>
+MW_HD void dft8(cf (&x)[8]) {
+    // n = 2 n1 + n2 ; X[k1 + 4 k2]
+#pragma unroll
+    for (int n2 = 0; n2 < 2; n2++) dft4<SGN>(x[n2], x[n2 + 2], x[n2 + 4], x[n2 + 6]);  // A[n2][k1] at x[n2+2k1]
+#pragma unroll
+    for (int k1 = 1; k1 < 4; k1++) x[1 + 2 * k1] = tw8<SGN>(x[1 + 2 * k1], k1);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) dft2<SGN>(x[2 * k1], x[2 * k1 + 1]);  // X[k1 + 4k2] at x[2k1+k2]
+    cf y[8];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++) y[k1 + 4 * k2] = x[2 * k1 + k2];
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = y[k];
+}
+template <int SGN>
+MW_HD void dft16(cf (&x)[16]) {
+    // n = 4 n1 + n2 ; X[k1 + 4 k2]
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft4<SGN>(x[n2], x[n2 + 4], x[n2 + 8], x[n2 + 12]);  // A[n2][k1] at x[n2+4k1]
+#pragma unroll
+    for (int n2 = 1; n2 < 4; n2++)
+#pragma unroll
+        for (int k1 = 1; k1 < 4; k1++) x[n2 + 4 * k1] = tw16<SGN>(x[n2 + 4 * k1], n2 * k1);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) dft4<SGN>(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
+    cf y[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) y[k1 + 4 * k2] = x[4 * k1 + k2];
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = y[k];
+}
+
+// ---- Stockham autosort passes, 16 points per thread ------------------------------------------
+// An N-point transform is carried by T = N/16 threads; thread u keeps element u + T*q in slot q
+// before AND after the whole transform.  Passes: radix 16 (p=1) [, radix 16 (p=16)] [, radix RL].
+// Between passes the data goes through an LDS buffer of N + N/16 complex (one pad per 16).
+template <int N>
+struct FftGeom {
+    static constexpr int T = N / 16;
+    static constexpr bool HAS_B = (N >= 256);
+    static constexpr int P_DONE = HAS_B ? 256 : 16;
+    static constexpr int RL = N / P_DONE;  // radix of the final pass (1 = none)
+    static constexpr int NB = 16 / RL;     // butterflies per thread in the final pass
+    static constexpr int LBUF = N + N / 16;
+    static_assert(N >= 16 && (N & (N - 1)) == 0 && N <= 4096, "N must be a power of two in [16,4096]");
+};
+MW_HD int lds_pad(int idx) { return idx + (idx >> 4); }
+
+template <int N, int SGN>
+MW_HD void stageA_store(cf (&x)[16], int u, cf* buf) {
+    dft16<SGN>(x);
+#pragma unroll
+    for (int r = 0; r < 16; r++) buf[lds_pad(16 * u + r)] = x[r];
+}
+template <int N>
+MW_HD void load_slots(cf (&x)[16], int u, const cf* buf) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) x[q] = buf[lds_pad(u + FftGeom<N>::T * q)];
+}
+// W[k] = e^{SGN 2 pi i k/N}, k = 0..N-1
+template <int N, int SGN>
+MW_HD void stageB_store(cf (&x)[16], int u, cf* buf, const cf* __restrict__ W) {
+    const int k = u & 15;
+#pragma unroll
+    for (int r = 1; r < 16; r++) x[r] = cmul(x[r], W[(N / 256) * r * k]);
+    dft16<SGN>(x);
+    const int j = ((u - k) << 4) + k;
+#pragma unroll
+    for (int r = 0; r < 16; r++) buf[lds_pad(j + 16 * r)] = x[r];
+}
+template <int N, int SGN>
+MW_HD void final_stage(cf (&x)[16], int u, const cf* __restrict__ W) {
+    constexpr int RL = FftGeom<N>::RL, NB = FftGeom<N>::NB, T = FftGeom<N>::T;
+    if (RL == 1) return;
+#pragma unroll
+    for (int m = 0; m < NB; m++) {
+        const int v = u + T * m;
+#pragma unroll
+        for (int r = 1; r < RL; r++) x[m + r * NB] = cmul(x[m + r * NB], W[r * v]);
+        if (RL == 2) {
+            dft2<SGN>(x[m], x[m + NB]);
+        } else if (RL == 4) {
+            dft4<SGN>(x[m], x[m + NB], x[m + 2 * NB], x[m + 3 * NB]);
+        } else if (RL == 8) {
+            cf y[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) y[r] = x[(m + r * NB) & 15];
+            dft8<SGN>(y);
+#pragma unroll
+            for (int r = 0; r < 8; r++) x[(m + r * NB) & 15] = y[r];
+        } else {  // 16
+            dft16<SGN>(x);
+        }
+    }
+}
+
+// ---- spectrum algebra (DESIGN.md "Hermitian packing") ---------------------------------------
+// h(k,t) = P e^{i th} + Q e^{-i th}
+MW_HD cf animate(float px, float py, float qx, float qy, float c, float s) {
+    return mk(px * c - py * s + qx * c + qy * s, px * s + py * c - qx * s + qy * c);
+}
+
+}  // namespace mw

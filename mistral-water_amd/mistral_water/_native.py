@@ -1,0 +1,121 @@
+"""ctypes binding of libmistral_water.so (the C ABI declared in include/mistral_water.h).
+
+The library is HIP-only.  Loading fails loudly when the shared object has not been built, and
+``mw_ocean_create`` fails with MW_EDEVICE when no MI355X is visible -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+AMD_DIR = os.path.dirname(PKG_DIR)                      # .../mistral-water_amd
+REPO_DIR = os.path.dirname(AMD_DIR)
+CSRC_DIR = os.path.join(AMD_DIR, "csrc")
+LIB_PATH = os.path.join(AMD_DIR, "libmistral_water.so")
+HEADER_PATH = os.path.join(REPO_DIR, "include", "mistral_water.h")
+
+MW_OK, MW_EINVAL, MW_ENOTPOW2, MW_ENOTCOMMENSURATE, MW_ENOMEM, MW_EDEVICE, MW_ESTATE = range(7)
+MW_SEM_FFTMESH, MW_SEM_OCEANRENDERER = 0, 1
+MW_OUT_WHITE_SCALAR, MW_OUT_COLOR_RGBA = 0, 1
+STATUS_NAMES = {0: "MW_OK", 1: "MW_EINVAL", 2: "MW_ENOTPOW2", 3: "MW_ENOTCOMMENSURATE", 4: "MW_ENOMEM",
+                5: "MW_EDEVICE", 6: "MW_ESTATE"}
+
+
+class MwParams(C.Structure):
+    _fields_ = [("resolution", C.c_int32), ("unit_width", C.c_float), ("length", C.c_float), ("wind_x", C.c_float),
+                ("wind_y", C.c_float), ("amplitude", C.c_float), ("choppiness", C.c_float), ("gravity", C.c_float),
+                ("t_division", C.c_float), ("mult", C.c_float), ("seed", C.c_uint64), ("semantics", C.c_int32),
+                ("device", C.c_int32)]
+
+
+class MistralWaterError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)] + [HEADER_PATH]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs)):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+           "-Wno-unused-value", "-o", LIB_PATH, os.path.join(CSRC_DIR, "mistral_water.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout, r.stderr)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed building libmistral_water.so:\n" + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (never falls back) when the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, i32p = C.c_void_p, C.c_void_p, C.c_void_p
+    sig = {
+        "mw_abi_version": (C.c_int32, []),
+        "mw_last_error": (C.c_char_p, []),
+        "mw_device_count": (C.c_int32, []),
+        "mw_params_default": (None, [C.POINTER(MwParams), C.c_int32]),
+        "mw_ocean_create": (C.c_int, [C.POINTER(MwParams), C.POINTER(vp)]),
+        "mw_ocean_destroy": (None, [vp]),
+        "mw_ocean_set_stream": (C.c_int, [vp, vp]),
+        "mw_ocean_get_stream": (vp, [vp]),
+        "mw_ocean_synchronize": (C.c_int, [vp]),
+        "mw_ocean_set_choppiness": (C.c_int, [vp, C.c_float]),
+        "mw_ocean_set_spectrum": (C.c_int, [vp, f32p, f32p]),
+        "mw_ocean_get_spectrum": (C.c_int, [vp, f32p, f32p]),
+        "mw_ocean_rest_mesh": (C.c_int, [vp, f32p, f32p, f32p, i32p]),
+        "mw_ocean_index_count": (C.c_int64, [vp]),
+        "mw_ocean_grid_size": (C.c_int32, [vp]),
+        "mw_ocean_evaluate": (C.c_int, [vp, C.c_float, f32p, f32p, f32p]),
+        "mw_ocean_update": (C.c_int, [vp, C.c_float, f32p, f32p, f32p]),
+        "mw_ocean_timer": (C.c_float, [vp]),
+        "mw_ocean_reset_timer": (C.c_int, [vp]),
+        "mw_ocean_evaluate_device": (C.c_int, [vp, f32p, C.c_int32, vp, vp, vp, C.c_uint32]),
+        "mw_ocean_max_batch": (C.c_int32, [vp]),
+        "mw_ocean_generate_texture": (C.c_int, [vp, C.c_float, f32p, f32p, f32p, f32p]),
+        "mw_ocean_generate_texture_device": (C.c_int, [vp, C.c_float, vp, vp, vp, vp]),
+        "mw_ocean_profile_kernels": (C.c_int, [vp, C.c_int32, C.c_int32, f32p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
+        "mw_gerstner_displace": (C.c_int, [f32p, C.c_int64, f32p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                           f32p, C.c_int32]),
+        "mw_gerstner_displace_device": (C.c_int, [vp, C.c_int64, f32p, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                                  C.c_float, vp, vp]),
+        "mw_debug_omega_t": (C.c_int, [vp, C.c_float, f32p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here = ABI symbol missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+#: every symbol include/mistral_water.h declares (checked by tests/test_abi.py against the header text)
+ABI_SYMBOLS = [
+    "mw_abi_version", "mw_last_error", "mw_device_count", "mw_params_default", "mw_ocean_create", "mw_ocean_destroy",
+    "mw_ocean_set_stream", "mw_ocean_get_stream", "mw_ocean_synchronize", "mw_ocean_set_choppiness",
+    "mw_ocean_set_spectrum", "mw_ocean_get_spectrum", "mw_ocean_rest_mesh", "mw_ocean_index_count",
+    "mw_ocean_grid_size", "mw_ocean_evaluate", "mw_ocean_update", "mw_ocean_timer", "mw_ocean_reset_timer",
+    "mw_ocean_evaluate_device", "mw_ocean_max_batch", "mw_ocean_generate_texture",
+    "mw_ocean_generate_texture_device", "mw_ocean_profile_kernels", "mw_gerstner_displace",
+    "mw_gerstner_displace_device",
+]
+
+
+def check(status: int):
+    if status != MW_OK:
+        raise MistralWaterError(status, lib().mw_last_error().decode("utf-8", "replace"))

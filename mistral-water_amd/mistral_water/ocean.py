@@ -1,0 +1,265 @@
+"""Ocean handle + FFTMesh / OceanRenderer mirrors (reference: Assets/Mistral Water/Scripts/*.cs)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as nat
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class Vector2:
+    x: float = 0.0
+    y: float = 0.0
+
+
+class Ocean:
+    """Thin RAII wrapper of an ``mw_ocean*``."""
+
+    def __init__(self, *, resolution, unit_width=1.0, length=1.0, wind=(1.0, 1.0), amplitude=1.0, choppiness=1.0,
+                 gravity=9.81, t_division=1.0, mult=1.0, seed=1, semantics=nat.MW_SEM_FFTMESH, device=0):
+        self._h = C.c_void_p()
+        self.params = nat.MwParams(int(resolution), float(unit_width), float(length), float(wind[0]), float(wind[1]),
+                                   float(amplitude), float(choppiness), float(gravity), float(t_division), float(mult),
+                                   int(seed), int(semantics), int(device))
+        nat.check(nat.lib().mw_ocean_create(C.byref(self.params), C.byref(self._h)))
+        self.N = nat.lib().mw_ocean_grid_size(self._h)
+        self.mesh_resolution = int(resolution)
+        self.semantics = int(semantics)
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            nat.lib().mw_ocean_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, hip_stream: int | None):
+        nat.check(nat.lib().mw_ocean_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        nat.check(nat.lib().mw_ocean_synchronize(self._h))
+
+    def set_choppiness(self, c: float):
+        nat.check(nat.lib().mw_ocean_set_choppiness(self._h, C.c_float(c)))
+
+    # -- spectrum ----------------------------------------------------------------------------
+    def set_spectrum(self, h0, h0conj):
+        h0 = np.ascontiguousarray(h0, np.float32)
+        h0conj = np.ascontiguousarray(h0conj, np.float32)
+        assert h0.size == 2 * self.N * self.N and h0conj.size == h0.size
+        nat.check(nat.lib().mw_ocean_set_spectrum(self._h, _p(h0), _p(h0conj)))
+
+    def get_spectrum(self):
+        h0 = np.empty((self.N, self.N, 2), np.float32)
+        h0c = np.empty((self.N, self.N, 2), np.float32)
+        nat.check(nat.lib().mw_ocean_get_spectrum(self._h, _p(h0), _p(h0c)))
+        return h0, h0c
+
+    def rest_mesh(self):
+        n = self.mesh_resolution
+        v = np.empty((n * n, 3), np.float32)
+        nr = np.empty((n * n, 3), np.float32)
+        uv = np.empty((n * n, 2), np.float32)
+        idx = np.empty((nat.lib().mw_ocean_index_count(self._h),), np.int32)
+        nat.check(nat.lib().mw_ocean_rest_mesh(self._h, _p(v), _p(nr), _p(uv), _p(idx)))
+        return v, nr, uv, idx
+
+    # -- FFTMesh semantics -------------------------------------------------------------------
+    def evaluate(self, t: float):
+        """EvaluateWaves(t): (vertices [N*N,3], normals [N*N,3], colors [N*N,4]) on the host."""
+        NN = self.N * self.N
+        v = np.empty((NN, 3), np.float32)
+        n = np.empty((NN, 3), np.float32)
+        c = np.empty((NN, 4), np.float32)
+        nat.check(nat.lib().mw_ocean_evaluate(self._h, C.c_float(t), _p(v), _p(n), _p(c)))
+        return v, n, c
+
+    def update(self, delta_time: float):
+        NN = self.N * self.N
+        v = np.empty((NN, 3), np.float32)
+        n = np.empty((NN, 3), np.float32)
+        c = np.empty((NN, 4), np.float32)
+        nat.check(nat.lib().mw_ocean_update(self._h, C.c_float(delta_time), _p(v), _p(n), _p(c)))
+        return v, n, c
+
+    @property
+    def timer(self) -> float:
+        return nat.lib().mw_ocean_timer(self._h)
+
+    def reset_timer(self):
+        nat.check(nat.lib().mw_ocean_reset_timer(self._h))
+
+    @property
+    def max_batch(self) -> int:
+        return nat.lib().mw_ocean_max_batch(self._h)
+
+    def evaluate_device(self, times, d_vertices: int, d_normals: int, d_white: int, rgba: bool = False):
+        """Enqueue len(times) independent time-steps; outputs are raw device pointers (ints)."""
+        tt = np.ascontiguousarray(times, np.float32)
+        nat.check(nat.lib().mw_ocean_evaluate_device(self._h, _p(tt), tt.size, C.c_void_p(d_vertices),
+                                                     C.c_void_p(d_normals), C.c_void_p(d_white),
+                                                     nat.MW_OUT_COLOR_RGBA if rgba else nat.MW_OUT_WHITE_SCALAR))
+
+    def profile_kernels(self, nsteps: int = 1, iters: int = 20):
+        ms = (C.c_float * 8)()
+        names = (C.c_char_p * 8)()
+        nk = C.c_int32(0)
+        nat.check(nat.lib().mw_ocean_profile_kernels(self._h, nsteps, iters, ms, names, C.byref(nk)))
+        return [(names[k].decode(), float(ms[k])) for k in range(nk.value)]
+
+    def debug_omega_t(self, t: float):
+        out = np.empty((self.N, self.N), np.float32)
+        nat.check(nat.lib().mw_debug_omega_t(self._h, C.c_float(t), _p(out)))
+        return out
+
+    # -- OceanRenderer semantics -------------------------------------------------------------
+    def generate_texture(self, delta_time: float):
+        M = self.N
+        h = np.empty((M, M), np.float32)
+        d = np.empty((M, M, 2), np.float32)
+        n = np.empty((M, M, 3), np.float32)
+        w = np.empty((M, M), np.float32)
+        nat.check(nat.lib().mw_ocean_generate_texture(self._h, C.c_float(delta_time), _p(h), _p(d), _p(n), _p(w)))
+        return h, d, n, w
+
+
+class _Mesh:
+    """The handful of UnityEngine.Mesh members the reference assigns (S/FFTMesh.cs:134-138,277-279)."""
+    vertices = normals = colors = uv = indices = None
+
+
+class FFTMesh:
+    """Mirror of ``public class FFTMesh : MonoBehaviour`` (S/FFTMesh.cs): same public fields
+    (:9-23), same Awake()/Update() lifecycle (:60-84); the private numerical methods are the GPU."""
+
+    def __init__(self, device: int = 0, seed: int = 1):
+        self.choppiness = 1.0          # :9
+        self.tDivision = 1.0           # :11
+        self.resolution = 50           # :13
+        self.unitWidth = 1.0           # :15
+        self.generate = False          # :17
+        self.length = 1.0              # :19
+        self.wind = Vector2(1.0, 1.0)  # :21
+        self.amplitude = 1.0           # :23
+        self.gravity = 9.81            # G, :52
+        self.mesh = _Mesh()
+        self._device, self._seed = device, seed
+        self._ocean = None
+        self._timer = 0.0
+
+    # SetParams + GenerateMesh (:90-139)
+    def _regenerate(self):
+        if self._ocean is not None:
+            self._ocean.close()
+        self._ocean = Ocean(resolution=self.resolution, unit_width=self.unitWidth, length=self.length,
+                            wind=(self.wind.x, self.wind.y), amplitude=self.amplitude, choppiness=self.choppiness,
+                            gravity=self.gravity, t_division=self.tDivision, seed=self._seed, device=self._device)
+        v, n, uv, idx = self._ocean.rest_mesh()
+        self.mesh.vertices, self.mesh.normals, self.mesh.uv, self.mesh.indices = v, n, uv, idx
+
+    def Awake(self):  # :75-84
+        self._regenerate()
+
+    def Update(self, deltaTime: float):  # :60-73
+        if self.generate:
+            self._timer = 0.0
+            self._regenerate()
+            self.generate = False
+        self._timer = float(np.float32(self._timer) + np.float32(deltaTime) / np.float32(self.tDivision))  # :70
+        self.EvaluateWaves(self._timer)
+
+    def EvaluateWaves(self, t: float):  # :224-280
+        self._ocean.set_choppiness(self.choppiness)  # :244-245 read the live field
+        v, n, c = self._ocean.evaluate(t)
+        self.mesh.vertices, self.mesh.normals, self.mesh.colors = v, n, c  # :277-279
+
+    @property
+    def timer(self):
+        return self._timer
+
+    @property
+    def ocean(self) -> Ocean:
+        return self._ocean
+
+
+class OceanRenderer:
+    """Mirror of ``public class OceanRenderer : MonoBehaviour`` (S/OceanRenderer.cs:10-19, :76-110)."""
+
+    def __init__(self, device: int = 0, seed: int = 1):
+        self.mult = 2.0            # :11
+        self.unitWidth = 1.0       # :12
+        self.resolution = 256      # :13
+        self.length = 256.0        # :14
+        self.choppiness = 1.5      # :16
+        self.amplitude = 1.0       # :18
+        self.wind = Vector2()      # :19
+        self.gravity = 9.81
+        self.mesh = _Mesh()
+        self.heightTexture = self.displacementTexture = self.normalTexture = self.whiteTexture = None
+        self._device, self._seed = device, seed
+        self._ocean = None
+        self._old = None
+
+    def _key(self):
+        return (self.length, self.wind.x, self.wind.y, self.amplitude)
+
+    def _create(self):
+        if self._ocean is not None:
+            self._ocean.close()
+        self._ocean = Ocean(resolution=self.resolution, unit_width=self.unitWidth, length=self.length,
+                            wind=(self.wind.x, self.wind.y), amplitude=self.amplitude, choppiness=self.choppiness,
+                            gravity=self.gravity, mult=self.mult, seed=self._seed,
+                            semantics=nat.MW_SEM_OCEANRENDERER, device=self._device)
+        self._old = self._key()
+
+    def Awake(self):  # :76-89  SetParams, GenerateMesh, RenderInitial
+        self._create()
+        v, n, uv, idx = self._ocean.rest_mesh()
+        self.mesh.vertices, self.mesh.normals, self.mesh.uv, self.mesh.indices = v, n, uv, idx
+
+    def Update(self, deltaTime: float):  # :91-110
+        self._ocean.set_choppiness(self.choppiness)
+        self.GenerateTexture(deltaTime)
+        if self._old != self._key():  # :98-109 RenderInitial again with the same seeds
+            self._create()
+
+    def GenerateTexture(self, deltaTime: float):  # :216-316
+        h, d, n, w = self._ocean.generate_texture(deltaTime)
+        self.heightTexture, self.displacementTexture, self.normalTexture, self.whiteTexture = h, d, n, w
+
+    @property
+    def ocean(self) -> Ocean:
+        return self._ocean
+
+
+def gerstner_displace(pos_xyz, waves, amplitude: float, frequency: float, steepness: float, t: float, device: int = 0):
+    """W/MistralWaterLib.cginc:154-180 Displacement() in Gerstner mode on host arrays.
+    ``waves`` = [(dir.x, dir.y, speed), ...]; ``amplitude`` is the already x0.01-scaled value (:172)."""
+    pos = np.ascontiguousarray(pos_xyz, np.float32)
+    wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)
+    out = np.empty_like(pos)
+    nat.check(nat.lib().mw_gerstner_displace(_p(pos), pos.size // 3, _p(wv), wv.shape[0], C.c_float(amplitude),
+                                             C.c_float(frequency), C.c_float(steepness), C.c_float(t), _p(out), device))
+    return out

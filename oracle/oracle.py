@@ -1,0 +1,188 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY (never imported by the product package).
+
+ctypes front-end to oracle/liboracle.so (the C restatement of the reference's CPU path,
+see fftmesh_oracle.c for the file:line citations) plus ``eval_fft_f64``: the same f64 model
+with numpy's FFT in the middle, usable at N = 1024 / 4096 where the O(N^3)/O(N^4) forms are
+too slow.  ``eval_fft_f64`` is validated against the literal forms in tests/test_oracle.py.
+
+PARITY UNPINNED -- see the header of fftmesh_oracle.c.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc (make)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return so
+
+
+class _P(C.Structure):
+    _fields_ = [("N", C.c_int32), ("unit_width", C.c_float), ("length", C.c_float), ("wind_x", C.c_float),
+                ("wind_y", C.c_float), ("amplitude", C.c_float), ("choppiness", C.c_float), ("gravity", C.c_float)]
+
+
+@dataclass
+class Params:
+    """Inspector fields of S/FFTMesh.cs:9-23 (+ gravity, a constant 9.81f at :52)."""
+    N: int
+    unit_width: float = 1.0
+    length: float = 1.0
+    wind_x: float = 1.0
+    wind_y: float = 1.0
+    amplitude: float = 1.0
+    choppiness: float = 1.0
+    gravity: float = 9.81
+
+    def c(self) -> _P:
+        return _P(self.N, self.unit_width, self.length, self.wind_x, self.wind_y, self.amplitude,
+                  self.choppiness, self.gravity)
+
+    @property
+    def commensurate(self) -> bool:
+        return np.float32(self.unit_width) * np.float32(self.N) == np.float32(self.length)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_uniform.restype = C.c_float
+        _LIB.orc_uniform.argtypes = [C.c_uint64, C.c_uint64]
+        _LIB.orc_dispersion.restype = C.c_float
+        _LIB.orc_dispersion.argtypes = [C.POINTER(_P), C.c_int, C.c_int]
+        _LIB.orc_phillips.restype = C.c_float
+        _LIB.orc_phillips.argtypes = [C.POINTER(_P), C.c_int, C.c_int]
+        _LIB.orc_rest_mesh.restype = C.c_int
+    return _LIB
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def uniform(seed: int, counter: int) -> float:
+    return lib().orc_uniform(seed, counter)
+
+
+def dispersion(p: Params, n: int, m: int) -> float:
+    return lib().orc_dispersion(C.byref(p.c()), n, m)
+
+
+def phillips(p: Params, n: int, m: int) -> float:
+    return lib().orc_phillips(C.byref(p.c()), n, m)
+
+
+def generate_spectrum(p: Params, seed: int):
+    h0 = np.empty((p.N, p.N, 2), np.float32)
+    h0c = np.empty((p.N, p.N, 2), np.float32)
+    lib().orc_generate_spectrum(C.byref(p.c()), C.c_uint64(seed), _fp(h0), _fp(h0c))
+    return h0, h0c
+
+
+def rest_mesh(p: Params):
+    N = p.N
+    v = np.empty((N * N, 3), np.float32)
+    n = np.empty((N * N, 3), np.float32)
+    uv = np.empty((N * N, 2), np.float32)
+    idx = np.empty(((N - 1) * (N - 1) * 6,), np.int32)
+    cnt = lib().orc_rest_mesh(C.byref(p.c()), _fp(v), _fp(n), _fp(uv), _fp(idx))
+    assert cnt == idx.size
+    return v, n, uv, idx
+
+
+def eval_literal_f32(p: Params, h0, h0c, t: float):
+    """EvaluateWaves(t) exactly as S/FFTMesh.cs:224-280, strict float32, O(N^4)."""
+    N = p.N
+    v = np.empty((N * N, 3), np.float32)
+    n = np.empty((N * N, 3), np.float32)
+    c = np.empty((N * N, 4), np.float32)
+    lib().orc_eval_literal_f32(C.byref(p.c()), _fp(np.ascontiguousarray(h0, np.float32)),
+                               _fp(np.ascontiguousarray(h0c, np.float32)), C.c_float(t), _fp(v), _fp(n), _fp(c))
+    return v, n, c
+
+
+def displacement_subset_f32(p: Params, h0, h0c, t: float, vertex_idx):
+    vi = np.ascontiguousarray(vertex_idx, np.int32)
+    hd = np.empty((vi.size, 3), np.float32)
+    nor = np.empty((vi.size, 3), np.float32)
+    lib().orc_displacement_subset_f32(C.byref(p.c()), _fp(np.ascontiguousarray(h0, np.float32)),
+                                      _fp(np.ascontiguousarray(h0c, np.float32)), C.c_float(t), _fp(vi),
+                                      C.c_int(vi.size), _fp(hd), _fp(nor))
+    return hd, nor
+
+
+def eval_f64(p: Params, h0, h0c, t: float):
+    """f64 separable O(N^3) evaluation; any unit_width/length."""
+    N = p.N
+    v = np.empty((N * N, 3), np.float64)
+    n = np.empty((N * N, 3), np.float64)
+    c = np.empty((N * N, 4), np.float64)
+    lib().orc_eval_f64(C.byref(p.c()), _fp(np.ascontiguousarray(h0, np.float32)),
+                       _fp(np.ascontiguousarray(h0c, np.float32)), C.c_float(t), _fp(v), _fp(n), _fp(c))
+    return v, n, c
+
+
+def htilde_fields_f64(p: Params, h0, h0c, t: float):
+    f = np.empty((5, p.N, p.N, 2), np.float64)
+    lib().orc_htilde_fields_f64(C.byref(p.c()), _fp(np.ascontiguousarray(h0, np.float32)),
+                                _fp(np.ascontiguousarray(h0c, np.float32)), C.c_float(t), _fp(f))
+    return f[..., 0] + 1j * f[..., 1]
+
+
+def assemble_f64(p: Params, spatial):
+    """spatial: complex128 [5,N,N] (H,Dx,Dz,Sx,Sz) -> vertices, normals, colours, hds (f64)."""
+    N = p.N
+    s = np.empty((5, N, N, 2), np.float64)
+    s[..., 0] = spatial.real
+    s[..., 1] = spatial.imag
+    v = np.empty((N * N, 3), np.float64)
+    n = np.empty((N * N, 3), np.float64)
+    c = np.empty((N * N, 4), np.float64)
+    hds = np.empty((N * N, 2), np.float64)
+    lib().orc_assemble_f64(C.byref(p.c()), _fp(s), _fp(v), _fp(n), _fp(c), _fp(hds))
+    return v, n, c, hds
+
+
+def transform_fft_f64(p: Params, fields):
+    """The reference's direct sum  sum_ij F(i,j) e^{i(kx_i x_a + kz_j z_b)}  (S/FFTMesh.cs:199-217)
+    restated as N^2 * ifft2 with separable pre/post twiddles.  Exact iff the grid is commensurate
+    (unit_width == length/N) and N is even:
+        k_i x_a = 2 pi (i - N/2)(a - N/2 + 1/2) / N
+                = 2 pi i a / N  +  pi i (1/N - 1)  -  pi a  +  pi (N/2 - 1/2)          (mod 2 pi)
+    """
+    N = p.N
+    assert p.commensurate and N % 2 == 0
+    i = np.arange(N)
+    pre = np.exp(1j * np.pi * i * (1.0 / N - 1.0))           # (-1)^i e^{i pi i/N}
+    post = np.exp(1j * np.pi * (N / 2.0 - 0.5 - i))          # (-1)^a e^{i pi (N-1)/2}
+    x = fields * pre[None, :, None] * pre[None, None, :]
+    y = np.fft.ifft2(x, axes=(1, 2)) * (N * N)
+    return y * post[None, :, None] * post[None, None, :]
+
+
+def eval_fft_f64(p: Params, h0, h0c, t: float, return_hds: bool = False):
+    """f64 evaluation with numpy's FFT (commensurate grids only) -- the large-N checker."""
+    spatial = transform_fft_f64(p, htilde_fields_f64(p, h0, h0c, t))
+    v, n, c, hds = assemble_f64(p, spatial)
+    return (v, n, c, hds) if return_hds else (v, n, c)
+
+
+def whitecap_f32(N: int, hds, normals):
+    c = np.empty((N * N, 4), np.float32)
+    lib().orc_whitecap_f32(C.c_int32(N), _fp(np.ascontiguousarray(hds, np.float32)),
+                           _fp(np.ascontiguousarray(normals, np.float32)), _fp(c))
+    return c

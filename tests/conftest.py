@@ -1,0 +1,47 @@
+"""pytest configuration: `gpu` marker, import paths, builders for the CPU-side checkers."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "mistral-water_amd"))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """oracle/ -- the CPU restatement of the reference (test infrastructure)."""
+    from oracle import oracle as O
+    O.build()
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def emul():
+    """tests/emul -- host lock-step emulation of the kernels' phase functions."""
+    import emul_build
+    return emul_build.load()
+
+
+@pytest.fixture(scope="session")
+def mw():
+    """The product: ctypes binding of libmistral_water.so (HIP only)."""
+    import mistral_water
+    mistral_water.lib()
+    return mistral_water
+
+
+def has_gpu() -> bool:
+    try:
+        import mistral_water
+        return mistral_water.lib().mw_device_count() > 0
+    except Exception:
+        return False

@@ -1,0 +1,206 @@
+// tests/emul/emul_fftmesh.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Host-side lock-step emulation of the FFTMesh-semantics kernels: the very same MW_HD phase functions
+// that mistral_water.hip launches on the GPU (mistral-water_amd/csrc/fftmesh_kernels.h) are stepped
+// here block by block, phase by phase, thread by thread, with a plain array standing in for LDS and a
+// loop boundary standing in for __syncthreads().  It lets the CPU-only test tier (-m "not gpu") verify
+// the thread/LDS choreography, the Hermitian packing and every index map against the oracle without
+// a GPU.  It is never part of libmistral_water.so and is not a fallback: nothing in the product loads it.
+//
+// build: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared (tests/emul/build.py)
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../mistral-water_amd/csrc/fftmesh_kernels.h"
+#include "../../mistral-water_amd/csrc/gerstner_kernels.h"
+
+using namespace mw;
+
+namespace {
+
+struct Tables {
+    std::vector<cf> W, Wpre;
+    explicit Tables(int N) : W(N), Wpre(2 * N) {
+        for (int k = 0; k < N; k++) {
+            double a = 2.0 * M_PI * (double)k / (double)N;
+            W[k] = mk((float)cos(a), (float)sin(a));
+        }
+        for (int m = 0; m < 2 * N; m++) {
+            double a = M_PI * (double)m / (double)N;
+            double sg = (m & 1) ? -1.0 : 1.0;
+            Wpre[m] = mk((float)(sg * cos(a)), (float)(sg * sin(a)));
+        }
+    }
+};
+
+template <int N>
+void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
+    constexpr int T = FftGeom<N>::T, NT = P1Geom<N>::NTHREADS, BS = P1Geom<N>::BUFSTRIDE;
+    std::vector<cf> lds(4 * BS);
+    struct St { cf hh[16]; cf x[16]; };
+    std::vector<St> st(NT);
+    for (int step = 0; step < nsteps; step++)
+        for (int jb = 0; jb < N / 4; jb++) {
+            const float t = tm.t[step];
+            for (int tid = 0; tid < NT; tid++) p1_animate<N>(A, jb, tid, t, st[tid].hh);
+            for (int f = 0; f < 3; f++) {
+                for (int tid = 0; tid < NT; tid++) {
+                    p1_build<N>(A, jb, tid, f, t, st[tid].hh, st[tid].x);
+                    stageA_store<N, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
+                }
+                if (FftGeom<N>::HAS_B) {
+                    for (int tid = 0; tid < NT; tid++) load_slots<N>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
+                    for (int tid = 0; tid < NT; tid++)
+                        stageB_store<N, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, A.W);
+                }
+                for (int tid = 0; tid < NT; tid++) p1_finish<N>(A, jb, step, tid, f, st[tid].x, lds.data());
+            }
+        }
+}
+
+template <int N, int R2>
+void run_pass2(const P2Args& A, int nsteps) {
+    constexpr int T = FftGeom<N>::T, NT = P2Geom<N, R2>::NTHREADS, BS = P2Geom<N, R2>::BUFSTRIDE;
+    std::vector<cf> lds((R2 + 1) * BS);
+    struct St { P2State<N> s; cf x[16]; };
+    std::vector<St> st(NT);
+    for (int step = 0; step < nsteps; step++)
+        for (int ab = 0; ab < N / R2; ab++) {
+            for (int k = 0; k < 3; k++) {
+                const int f = p2_field(k);
+                for (int tid = 0; tid < NT; tid++)
+                    if (p2_active<N, R2>(ab, tid, f)) p2_load<N, R2>(A, ab, step, tid, f, st[tid].x, lds.data());
+                if (FftGeom<N>::HAS_B) {
+                    for (int tid = 0; tid < NT; tid++)
+                        if (p2_active<N, R2>(ab, tid, f)) p2_mid_load<N, R2>(tid, st[tid].x, lds.data());
+                    for (int tid = 0; tid < NT; tid++)
+                        if (p2_active<N, R2>(ab, tid, f)) p2_mid_store<N, R2>(A, tid, st[tid].x, lds.data());
+                }
+                for (int tid = 0; tid < NT; tid++)
+                    if (p2_active<N, R2>(ab, tid, f)) p2_finish<N, R2>(A, ab, step, tid, f, st[tid].x, st[tid].s, lds.data());
+            }
+            for (int tid = 0; tid < NT; tid++)
+                if (p2_active<N, R2>(ab, tid, 1)) p2_publish_hds<N, R2>(tid, st[tid].s, lds.data());
+            for (int tid = 0; tid < NT; tid++)
+                if (tid / T < R2) p2_epilogue<N, R2>(A, ab, step, tid, st[tid].s, lds.data());
+        }
+}
+
+template <int N>
+int evaluate_n(const OceanConsts& C, const cf* h0, const cf* h0c, const float* times, int nsteps, float* vertices,
+               float* normals, float* white, int white_stride) {
+    constexpr int R2 = (N >= 4096) ? 2 : 4;
+    Tables tb(N);
+    std::vector<f4> PQt((size_t)N * N), d_i0(N), d_j0(N);
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) prep_element(N, i, j, h0, h0c, PQt.data(), d_i0.data(), d_j0.data());
+    std::vector<cf> E((size_t)nsteps * 3 * N * N);
+    P1Args A1;
+    A1.PQt = PQt.data(); A1.dPQ_i0 = d_i0.data(); A1.dPQ_j0 = d_j0.data(); A1.W = tb.W.data(); A1.Wpre = tb.Wpre.data();
+    A1.E = E.data(); A1.c = C;
+    StepTimes tm;
+    for (int k = 0; k < nsteps; k++) tm.t[k] = times[k];
+    run_pass1<N>(A1, tm, nsteps);
+    P2Args A2;
+    A2.E = E.data(); A2.W = tb.W.data(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
+    A2.white_stride = white_stride; A2.c = C;
+    run_pass2<N, R2>(A2, nsteps);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// returns 0 on success, 1 for an unsupported N
+int emul_fftmesh_evaluate(int N, float unit_width, float length, float gravity, float choppiness, const float* h0,
+                          const float* h0c, const float* times, int nsteps, float* vertices, float* normals, float* white,
+                          int white_stride) {
+    OceanConsts C;
+    C.N = N; C.length = length; C.gravity = gravity; C.unit_width = unit_width; C.choppiness = choppiness;
+    const cf* a = reinterpret_cast<const cf*>(h0);
+    const cf* b = reinterpret_cast<const cf*>(h0c);
+    if (nsteps < 1 || nsteps > MW_MAX_BATCH) return 2;
+    switch (N) {
+        case 64: return evaluate_n<64>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 128: return evaluate_n<128>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 256: return evaluate_n<256>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 512: return evaluate_n<512>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 1024: return evaluate_n<1024>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 2048: return evaluate_n<2048>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 4096: return evaluate_n<4096>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        default: return 1;
+    }
+}
+
+// 1-D transform through the Stockham passes exactly as one FFT group of the kernels runs them
+int emul_fft1d(int N, int sgn, const float* in_xy, float* out_xy) {
+    if (sgn != 1) return 2;
+    Tables tb(N);
+#define RUN(NN)                                                                                      \
+    {                                                                                                \
+        constexpr int T = FftGeom<NN>::T;                                                            \
+        std::vector<cf> lds(FftGeom<NN>::LBUF + 8);                                                  \
+        struct S { cf x[16]; };                                                                      \
+        std::vector<S> st(T);                                                                        \
+        for (int u = 0; u < T; u++)                                                                  \
+            for (int q = 0; q < 16; q++) st[u].x[q] = mk(in_xy[2 * (u + T * q)], in_xy[2 * (u + T * q) + 1]); \
+        for (int u = 0; u < T; u++) stageA_store<NN, +1>(st[u].x, u, lds.data());                    \
+        if (FftGeom<NN>::HAS_B) {                                                                    \
+            for (int u = 0; u < T; u++) load_slots<NN>(st[u].x, u, lds.data());                      \
+            for (int u = 0; u < T; u++) stageB_store<NN, +1>(st[u].x, u, lds.data(), tb.W.data());   \
+        }                                                                                            \
+        for (int u = 0; u < T; u++) { load_slots<NN>(st[u].x, u, lds.data()); final_stage<NN, +1>(st[u].x, u, tb.W.data()); } \
+        for (int u = 0; u < T; u++)                                                                  \
+            for (int q = 0; q < 16; q++) { out_xy[2 * (u + T * q)] = st[u].x[q].x; out_xy[2 * (u + T * q) + 1] = st[u].x[q].y; } \
+        return 0;                                                                                    \
+    }
+    switch (N) {
+        case 16: RUN(16)
+        case 32: RUN(32)
+        case 64: RUN(64)
+        case 128: RUN(128)
+        case 256: RUN(256)
+        case 512: RUN(512)
+        case 1024: RUN(1024)
+        case 2048: RUN(2048)
+        case 4096: RUN(4096)
+        default: return 1;
+    }
+#undef RUN
+}
+
+void emul_rest_mesh(int N, float unit_width, float* vertices, float* normals, float* uvs, int32_t* indices) {
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) rest_mesh_element(N, unit_width, i, j, vertices, normals, uvs, indices);
+}
+
+void emul_spectrum(int N, float length, float wind_x, float wind_y, float amplitude, float gravity, uint64_t seed, float* h0,
+                   float* h0c) {
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++)
+            spectrum_element(N, length, wind_x, wind_y, amplitude, gravity, seed, i, j, reinterpret_cast<cf*>(h0),
+                             reinterpret_cast<cf*>(h0c));
+}
+
+void emul_omega_t(int N, float length, float gravity, float t, float* out) {
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) out[i * N + j] = omega_t_f32(N, length, gravity, i, j, t);
+}
+
+void emul_gerstner(const float* pos, long nverts, const float* waves, int nwaves, float amplitude, float frequency,
+                   float steepness, float t, float* out) {
+    GerstnerWaves wv;
+    for (int i = 0; i < MW_GERSTNER_MAX_WAVES; i++) {
+        wv.dx[i] = i < nwaves ? waves[3 * i] : 0.f;
+        wv.dy[i] = i < nwaves ? waves[3 * i + 1] : 0.f;
+        wv.speed[i] = i < nwaves ? waves[3 * i + 2] : 0.f;
+    }
+    for (long v = 0; v < nverts; v++)
+        gerstner_vertex(wv, nwaves, amplitude, frequency, steepness, t, pos[3 * v], pos[3 * v + 1], pos[3 * v + 2], &out[3 * v],
+                        &out[3 * v + 1], &out[3 * v + 2]);
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+"""Builds and loads tests/emul/libemul.so (g++; strict float32, no FMA contraction)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "emul", "emul_fftmesh.cpp")
+SO = os.path.join(HERE, "emul", "libemul.so")
+CSRC = os.path.join(os.path.dirname(HERE), "mistral-water_amd", "csrc")
+
+
+def build():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if os.path.exists(SO) and all(os.path.getmtime(d) <= os.path.getmtime(SO) for d in deps):
+        return SO
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", SO, SRC], check=True)
+    return SO
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Emul:
+    def __init__(self):
+        self.L = C.CDLL(build())
+
+    def evaluate(self, p, h0, h0c, times, white_stride=4):
+        """p: oracle.Params.  Returns (vertices, normals, white) with a leading step axis."""
+        N, ns = p.N, len(times)
+        v = np.empty((ns, N * N, 3), np.float32)
+        n = np.empty((ns, N * N, 3), np.float32)
+        w = np.empty((ns, N * N, white_stride), np.float32)
+        tt = np.asarray(times, np.float32)
+        r = self.L.emul_fftmesh_evaluate(N, C.c_float(p.unit_width), C.c_float(p.length), C.c_float(p.gravity),
+                                         C.c_float(p.choppiness), _p(np.ascontiguousarray(h0, np.float32)),
+                                         _p(np.ascontiguousarray(h0c, np.float32)), _p(tt), ns, _p(v), _p(n), _p(w),
+                                         white_stride)
+        assert r == 0, f"emul_fftmesh_evaluate -> {r}"
+        return v, n, w
+
+    def fft1d(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x)
+        assert self.L.emul_fft1d(x.shape[0], 1, _p(x), _p(y)) == 0
+        return y
+
+    def rest_mesh(self, N, unit_width):
+        v = np.empty((N * N, 3), np.float32)
+        n = np.empty((N * N, 3), np.float32)
+        uv = np.empty((N * N, 2), np.float32)
+        idx = np.full(((N - 1) * (N - 1) * 6,), -1, np.int32)
+        self.L.emul_rest_mesh(N, C.c_float(unit_width), _p(v), _p(n), _p(uv), _p(idx))
+        return v, n, uv, idx
+
+    def spectrum(self, p, seed):
+        h0 = np.empty((p.N, p.N, 2), np.float32)
+        h0c = np.empty((p.N, p.N, 2), np.float32)
+        self.L.emul_spectrum(p.N, C.c_float(p.length), C.c_float(p.wind_x), C.c_float(p.wind_y), C.c_float(p.amplitude),
+                             C.c_float(p.gravity), C.c_uint64(seed), _p(h0), _p(h0c))
+        return h0, h0c
+
+    def omega_t(self, p, t):
+        out = np.empty((p.N, p.N), np.float32)
+        self.L.emul_omega_t(p.N, C.c_float(p.length), C.c_float(p.gravity), C.c_float(t), _p(out))
+        return out
+
+    def gerstner(self, pos, waves, amplitude, frequency, steepness, t):
+        pos = np.ascontiguousarray(pos, np.float32)
+        wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)
+        out = np.empty_like(pos)
+        self.L.emul_gerstner(_p(pos), C.c_long(pos.size // 3), _p(wv), wv.shape[0], C.c_float(amplitude),
+                             C.c_float(frequency), C.c_float(steepness), C.c_float(t), _p(out))
+        return out
+
+
+_E = None
+
+
+def load():
+    global _E
+    if _E is None:
+        _E = Emul()
+    return _E

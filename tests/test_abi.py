@@ -1,0 +1,82 @@
+"""CPU tier: the C-ABI shared library loads, exports every symbol include/mistral_water.h declares,
+and refuses to run without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import REPO, has_gpu
+
+HEADER = os.path.join(REPO, "include", "mistral_water.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mw_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(mw):
+    from mistral_water import _native
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    L = C.CDLL(_native.LIB_PATH)
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/mistral_water.h but not exported"
+    assert sorted(_native.ABI_SYMBOLS) == syms, "python binding list out of date with the header"
+
+
+def test_header_is_plain_c():
+    # the boundary must be consumable from C (and therefore from P/Invoke / cgo / JNI / ctypes)
+    src = '#include "mistral_water.h"\nint main(void){ mw_params p; mw_params_default(&p, MW_SEM_FFTMESH); return (int)sizeof(p) == 0; }\n'
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.dirname(HEADER),
+                        "-x", "c", "-"], input=src, text=True, capture_output=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_params_struct_layout(mw):
+    from mistral_water import _native
+    assert C.sizeof(_native.MwParams) == 56  # 10 x 4 B, seed (8 B, at offset 40), 2 x 4 B
+    p = _native.MwParams()
+    mw.lib().mw_params_default(C.byref(p), mw.MW_SEM_FFTMESH)
+    assert p.resolution == 50 and p.unit_width == 1.0 and p.choppiness == 1.0 and abs(p.gravity - 9.81) < 1e-6
+    mw.lib().mw_params_default(C.byref(p), mw.MW_SEM_OCEANRENDERER)
+    assert p.resolution == 256 and p.mult == 2.0 and p.choppiness == 1.5
+
+
+def test_abi_version_and_error_string(mw):
+    assert mw.lib().mw_abi_version() == 1
+    assert isinstance(mw.lib().mw_last_error(), bytes)
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a GPU-less host")
+def test_no_cpu_fallback_without_gpu(mw):
+    with pytest.raises(mw.MistralWaterError) as e:
+        mw.Ocean(resolution=64, length=64.0)
+    assert e.value.status == mw.MW_EDEVICE
+    import numpy as np
+    with pytest.raises(mw.MistralWaterError) as e:
+        mw.gerstner_displace(np.zeros((4, 3), np.float32), [(1, 0, 1)], 0.1, 1.0, 0.5, 0.0)
+    assert e.value.status == mw.MW_EDEVICE
+
+
+def test_bad_arguments_are_status_codes_not_crashes(mw):
+    L = mw.lib()
+    assert L.mw_ocean_create(None, None) == mw.MW_EINVAL
+    assert L.mw_ocean_evaluate(None, 0.0, None, None, None) == mw.MW_EINVAL
+    assert L.mw_ocean_set_spectrum(None, None, None) == mw.MW_EINVAL
+    L.mw_ocean_destroy(None)  # no-op
+
+
+def test_product_never_references_the_oracle():
+    """The product path must not import, link or execute anything under oracle/."""
+    amd = os.path.join(REPO, "mistral-water_amd")
+    for root, _, files in os.walk(amd):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                txt = open(os.path.join(root, f), errors="replace").read()
+                assert "liboracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+    r = subprocess.run(["ldd", os.path.join(amd, "libmistral_water.so")], capture_output=True, text=True)
+    assert "oracle" not in r.stdout

@@ -1,0 +1,126 @@
+"""CPU tier: the kernels' own phase functions (mistral-water_amd/csrc/*.h), stepped in lock-step on the
+host by tests/emul, against the oracle.  Verifies the Stockham passes, the Hermitian packing with its
+Nyquist-line corrections, the exchange-buffer layout, the halo row and every index map before a GPU is
+involved.  (The emulation is test infrastructure; the product has no CPU path.)"""
+import numpy as np
+import pytest
+
+import workloads
+
+
+@pytest.mark.parametrize("N", [16, 32, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_stockham_passes_equal_unnormalised_inverse_dft(emul, N):
+    rng = np.random.default_rng(N)
+    x = rng.standard_normal((N, 2)).astype(np.float32)
+    y = emul.fft1d(x)
+    ref = np.fft.ifft(x[:, 0].astype(np.float64) + 1j * x[:, 1]) * N
+    err = np.abs((y[:, 0] + 1j * y[:, 1]) - ref).max() / np.abs(ref).max()
+    assert err < 4e-7
+
+
+def test_stockham_impulse_and_linearity(emul):
+    N = 1024
+    for pos in (0, 1, 17, 1023):
+        x = np.zeros((N, 2), np.float32)
+        x[pos, 0] = 1.0
+        y = emul.fft1d(x)
+        k = np.arange(N)
+        want = np.exp(2j * np.pi * pos * k / N)
+        assert np.abs((y[:, 0] + 1j * y[:, 1]) - want).max() < 3e-7
+    rng = np.random.default_rng(1)
+    a, b = rng.standard_normal((2, N, 2)).astype(np.float32)
+    assert np.abs(emul.fft1d(a + b) - (emul.fft1d(a) + emul.fft1d(b))).max() < 2e-4
+
+
+def test_omega_t_bit_exact(emul, oracle):
+    for N, t in [(64, 1.0), (256, 16.65)]:
+        p = workloads.fftmesh_params(N)
+        got = emul.omega_t(p, t)
+        want = np.array([[np.float32(oracle.dispersion(p, i, j)) * np.float32(t) for j in range(N)] for i in range(N)],
+                        np.float32)
+        assert (got == want).all()
+
+
+def test_rest_mesh_bit_exact(emul, oracle):
+    for N, u in [(64, 1.0), (12, 1.0), (7, 0.37)]:
+        p = oracle.Params(N=N, unit_width=u, length=1.0)
+        v, n, uv, idx = oracle.rest_mesh(p)
+        ev, en, euv, eidx = emul.rest_mesh(N, u)
+        assert (ev == v).all() and (en == n).all() and (euv == uv).all() and (eidx == idx).all()
+
+
+def test_spectrum_generation_matches_oracle(emul, oracle):
+    p = workloads.fftmesh_params(64)
+    h0, h0c = oracle.generate_spectrum(p, 9)
+    e0, e0c = emul.spectrum(p, 9)
+    sc = np.abs(h0).max()
+    assert np.abs(e0 - h0).max() < 2e-6 * sc and np.abs(e0c - h0c).max() < 2e-6 * sc
+    assert (e0[32, 32] == 0).all()
+
+
+@pytest.mark.parametrize("N", [64, 128, 256])
+def test_pipeline_vs_oracle_f64(emul, oracle, N):
+    p = workloads.fftmesh_params(N)
+    h0, h0c = oracle.generate_spectrum(p, 1)
+    times = [0.0, 1.0, 16.65]
+    v, n, w = emul.evaluate(p, h0, h0c, times)
+    rest = oracle.rest_mesh(p)[0]
+    for k, t in enumerate(times):
+        vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, t, return_hds=True)
+        workloads.assert_parity(v[k], n[k], w[k], vf, nf, cf, rest, np.abs(hds).max(), tag=f"N={N} t={t}")
+
+
+def test_pipeline_nyquist_lines_only(emul, oracle):
+    """Spectrum supported ONLY on the Nyquist row i=0 and column j=0 (k index 0 mirrors onto itself with a
+    sign flip): exercises the dPQ correction tables in isolation."""
+    N = 64
+    p = workloads.fftmesh_params(N, choppiness=1.0)
+    rng = np.random.default_rng(5)
+    h0 = np.zeros((N, N, 2), np.float32)
+    h0c = np.zeros((N, N, 2), np.float32)
+    h0[0, :, :] = rng.standard_normal((N, 2)) * 0.01
+    h0[:, 0, :] = rng.standard_normal((N, 2)) * 0.01
+    h0c[0, :, :] = rng.standard_normal((N, 2)) * 0.01
+    h0c[:, 0, :] = rng.standard_normal((N, 2)) * 0.01
+    v, n, w = emul.evaluate(p, h0, h0c, [2.25])
+    vf, nf, cf = oracle.eval_fft_f64(p, h0, h0c, 2.25)
+    rest = oracle.rest_mesh(p)[0]
+    workloads.assert_parity(v[0], n[0], w[0], vf, nf, cf, rest, tag="nyquist")
+
+
+def test_pipeline_single_bins_index_maps(emul, oracle):
+    """One non-zero bin at a time (corners, Nyquist lines, interior): any wrong index / sign shows up at O(1)."""
+    N = 64
+    p = workloads.fftmesh_params(N, choppiness=1.0)
+    for (i, j, conj) in [(0, 0, False), (0, 5, True), (7, 0, False), (63, 63, True), (32, 32, False), (33, 31, True),
+                         (1, 62, False)]:
+        h0 = np.zeros((N, N, 2), np.float32)
+        h0c = np.zeros((N, N, 2), np.float32)
+        (h0c if conj else h0)[i, j] = (0.3, -0.2)
+        v, n, w = emul.evaluate(p, h0, h0c, [0.8])
+        vf, nf, cf = oracle.eval_fft_f64(p, h0, h0c, 0.8)
+        workloads.assert_parity(v[0], n[0], w[0], vf, nf, cf, oracle.rest_mesh(p)[0], tag=str((i, j, conj)))
+
+
+def test_white_scalar_layout(emul, oracle):
+    p = workloads.fftmesh_params(64, choppiness=1.5)
+    h0, h0c = oracle.generate_spectrum(p, 2)
+    _, _, w4 = emul.evaluate(p, h0, h0c, [1.0], white_stride=4)
+    _, _, w1 = emul.evaluate(p, h0, h0c, [1.0], white_stride=1)
+    assert (w4[..., 0] == w1[..., 0]).all() and (w4[..., 3] == w1[..., 0]).all()
+
+
+def test_gerstner_vs_numpy(emul):
+    rng = np.random.default_rng(0)
+    pos = rng.uniform(-50, 50, (1000, 3)).astype(np.float32)
+    W = workloads.pond_waves8()
+    P = workloads.POND
+    out = emul.gerstner(pos, W, P["amplitude"], P["frequency"], P["steepness"], 3.25)
+    x, y, z = pos.astype(np.float64).T
+    ox, oy, oz = x.copy(), y.copy(), z.copy()
+    for dx, dy, sp in W:   # W/MistralWaterLib.cginc:77-88
+        th = P["frequency"] * (np.float32(dx) * x + np.float32(dy) * z) + 3.25 * np.float32(sp)
+        ox += np.cos(th) * P["steepness"] * P["amplitude"] * np.float32(dx)
+        oz += np.cos(th) * P["steepness"] * P["amplitude"] * np.float32(dy)
+        oy += P["amplitude"] * np.sin(th)
+    assert np.abs(out - np.stack([ox, oy, oz], 1)).max() < 2e-4

@@ -1,0 +1,266 @@
+"""GPU tier (-m gpu): the parity tests proper.  Everything goes through the C ABI of libmistral_water.so
+(ctypes), with h0/h0conj injected identically into the oracle and the GPU path (mw_ocean_set_spectrum).
+
+Tolerance (north_star: "within a stated float32 tolerance"): workloads.REL_TOL = 4e-6 of max |field| plus one
+f32 ulp of the stored coordinate; index / sign-flip work (rest mesh, triangle indices, uvs, omega*t, the
+whitecap edge rules) is compared bit for bit.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def make(mw, p, seed=1):
+    return mw.Ocean(resolution=p.N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y),
+                    amplitude=p.amplitude, choppiness=p.choppiness, gravity=p.gravity, seed=seed)
+
+
+def test_device_present(mw):
+    assert mw.lib().mw_device_count() >= 1, "the -m gpu tier needs an MI355X"
+
+
+@pytest.mark.parametrize("N", [64, 128, 256, 512, 1024])
+def test_fftmesh_parity_vs_oracle_f64(mw, oracle, N):
+    p = workloads.fftmesh_params(N)
+    h0, h0c = oracle.generate_spectrum(p, 1)
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        for t in (0.0, 1.0, 16.65):
+            v, n, c = o.evaluate(t)
+            vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, t, return_hds=True)
+            workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"N={N} t={t}")
+            assert (c[:, 0] == c[:, 3]).all() and (c[:, 1] == c[:, 2]).all()  # Color(xx,xx,xx,xx) :274
+
+
+def test_fftmesh_256_vs_literal_f32_sample(mw, oracle):
+    """BASELINE config 1 (256^2, one step): distance to the reference's literal float32 O(N^4) loop on a vertex
+    sample (a full literal step is ~4 minutes of CPU).  The literal f32 sum is itself only ~1e-4 accurate."""
+    p = workloads.fftmesh_params(256, choppiness=1.0)
+    h0, h0c = oracle.generate_spectrum(p, 1)
+    rng = np.random.default_rng(0)
+    idx = np.sort(rng.choice(256 * 256, 48, replace=False)).astype(np.int32)
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        v, n, c = o.evaluate(1.0)
+    hd, nor = oracle.displacement_subset_f32(p, h0, h0c, 1.0, idx)
+    rest = oracle.rest_mesh(p)[0]
+    scale = np.abs(hd).max()
+    assert np.abs(v[idx, 1] - hd[:, 1]).max() < 3e-4 * scale                 # height
+    assert np.abs((rest[idx, 0] - v[idx, 0]) - hd[:, 0]).max() < 3e-4 * scale  # d.x * choppiness(=1)
+    assert np.abs((rest[idx, 2] - v[idx, 2]) - hd[:, 2]).max() < 3e-4 * scale
+    assert np.abs(n[idx] - nor).max() < 3e-4
+
+
+@pytest.mark.parametrize("N", [2048, 4096])
+def test_fftmesh_large_grids(mw, oracle, N):
+    """BASELINE config 4 (4096^2): parity at full size against the numpy-FFT f64 oracle."""
+    p = workloads.fftmesh_params(N)
+    h0, h0c = oracle.generate_spectrum(p, 3)
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        v, n, c = o.evaluate(2.5)
+    vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, 2.5, return_hds=True)
+    workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"N={N}")
+
+
+def test_omega_t_bit_exact_on_device(mw, oracle):
+    # the quantised dispersion floor() and the omega*t product are "index work": bit for bit (S/FFTMesh.cs:146,183)
+    for N, t in [(64, 1.0), (256, 16.65), (1024, 7.3)]:
+        p = workloads.fftmesh_params(N)
+        with make(mw, p) as o:
+            got = o.debug_omega_t(t)
+        w = np.array([[oracle.dispersion(p, i, j) for j in range(N)] for i in range(0, N, max(1, N // 64))], np.float32)
+        want = w * np.float32(t)
+        assert (got[::max(1, N // 64)] == want).all()
+
+
+def test_rest_mesh_bit_exact_on_device(mw, oracle):
+    for N, u, L in [(64, 1.0, 64.0), (12, 1.0, 12.39), (7, 0.37, 3.0)]:
+        p = oracle.Params(N=N, unit_width=u, length=L, amplitude=0.01, wind_x=5, wind_y=3)
+        v, n, uv, idx = oracle.rest_mesh(p)
+        with make(mw, p) as o:
+            gv, gn, guv, gidx = o.rest_mesh()
+        assert (gv == v).all() and (gn == n).all() and (guv == uv).all() and (gidx == idx).all()
+
+
+def test_spectrum_generation_on_device(mw, oracle):
+    p = workloads.fftmesh_params(256)
+    h0, h0c = oracle.generate_spectrum(p, 9)
+    with make(mw, p, seed=9) as o:
+        g0, g0c = o.get_spectrum()
+    sc = np.abs(h0).max()
+    assert np.abs(g0 - h0).max() < 4e-6 * sc and np.abs(g0c - h0c).max() < 4e-6 * sc
+    assert (g0[128, 128] == 0).all()  # k = 0 bin, S/FFTMesh.cs:153
+    # round trip of an injected spectrum is exact
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        r0, r0c = o.get_spectrum()
+    assert (r0 == h0).all() and (r0c == h0c).all()
+
+
+def test_single_bins_and_nyquist_lines(mw, oracle):
+    N = 64
+    p = workloads.fftmesh_params(N, choppiness=1.0)
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        for (i, j, conj) in [(0, 0, False), (0, 5, True), (7, 0, False), (63, 63, True), (32, 32, False), (33, 31, True)]:
+            h0 = np.zeros((N, N, 2), np.float32)
+            h0c = np.zeros((N, N, 2), np.float32)
+            (h0c if conj else h0)[i, j] = (0.3, -0.2)
+            o.set_spectrum(h0, h0c)
+            v, n, c = o.evaluate(0.8)
+            vf, nf, cf = oracle.eval_fft_f64(p, h0, h0c, 0.8)
+            workloads.assert_parity(v, n, c, vf, nf, cf, rest, tag=str((i, j, conj)))
+
+
+def test_zero_spectrum_flat_and_white_zero(mw, oracle):
+    p = workloads.fftmesh_params(128)
+    z = np.zeros((128, 128, 2), np.float32)
+    with make(mw, p) as o:
+        o.set_spectrum(z, z)
+        v, n, c = o.evaluate(4.0)
+    assert (v == oracle.rest_mesh(p)[0]).all() and (n == [0, 1, 0]).all() and (c == 0).all()
+
+
+def test_linearity_and_time_reversal_properties_1024(mw, oracle):
+    """Size-independent properties at BASELINE's full 1024^2: (i) the displacement/height fields are linear in
+    (h0, h0conj); (ii) h~(k,-t) with h0 <-> h0conj swapped equals h~(k,t) (S/FFTMesh.cs:188), so outputs agree."""
+    p = workloads.fftmesh_params(1024)
+    rest = oracle.rest_mesh(p)[0]
+    a0, a0c = oracle.generate_spectrum(p, 11)
+    b0, b0c = oracle.generate_spectrum(p, 12)
+    with make(mw, p) as o:
+        o.set_spectrum(a0, a0c); va, _, _ = o.evaluate(3.0)
+        o.set_spectrum(b0, b0c); vb, _, _ = o.evaluate(3.0)
+        o.set_spectrum(a0 + b0, a0c + b0c); vs, _, _ = o.evaluate(3.0)
+        lin = (vs - rest) - ((va - rest) + (vb - rest))
+        assert np.abs(lin).max() < 2e-5 * np.abs(vs - rest).max() + 2.0 ** -21 * np.abs(rest).max()
+        o.set_spectrum(a0c, a0); vr, nr, cr = o.evaluate(-3.0)
+        o.set_spectrum(a0, a0c); v1, n1, c1 = o.evaluate(3.0)
+        assert np.abs(vr - v1).max() < 1e-5 * np.abs(v1 - rest).max() + 2.0 ** -22 * np.abs(rest).max()
+        assert np.abs(nr - n1).max() < 1e-5
+
+
+def test_batched_device_steps_equal_single_steps(mw, oracle):
+    """mw_ocean_evaluate_device with nsteps > 1 == the same steps one at a time, bit for bit."""
+    import torch
+    p = workloads.fftmesh_params(256)
+    h0, h0c = oracle.generate_spectrum(p, 1)
+    NN = 256 * 256
+    times = [0.5 + k / 60.0 for k in range(5)]
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        dv = torch.empty((5, NN, 3), dtype=torch.float32, device="cuda")
+        dn = torch.empty((5, NN, 3), dtype=torch.float32, device="cuda")
+        dw = torch.empty((5, NN), dtype=torch.float32, device="cuda")
+        o.evaluate_device(times, dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+        o.synchronize()
+        for k, t in enumerate(times):
+            v, n, c = o.evaluate(t)
+            assert (dv[k].cpu().numpy() == v).all() and (dn[k].cpu().numpy() == n).all()
+            assert (dw[k].cpu().numpy() == c[:, 0]).all()
+
+
+def test_update_lifecycle_matches_fftmesh_update(mw, oracle):
+    """FFTMesh.Update: timer += deltaTime / tDivision (S/FFTMesh.cs:70), choppiness read live (:244)."""
+    m = mw.FFTMesh()
+    m.resolution, m.unitWidth, m.length, m.amplitude, m.tDivision = 64, 1.0, 64.0, 2e-6, 2.0
+    m.wind = mw.Vector2(14.45, 12.0)
+    m.Awake()
+    p = oracle.Params(N=64, unit_width=1.0, length=64.0, wind_x=14.45, wind_y=12.0, amplitude=2e-6, choppiness=1.0)
+    rv, rn, ruv, ridx = oracle.rest_mesh(p)
+    assert (m.mesh.vertices == rv).all() and (m.mesh.indices == ridx).all() and (m.mesh.uv == ruv).all()
+    h0, h0c = m.ocean.get_spectrum()
+    for _ in range(3):
+        m.Update(0.25)
+    assert m.timer == pytest.approx(0.375)
+    m.choppiness = 0.5
+    m.Update(0.25)
+    p.choppiness = 0.5
+    vf, nf, cf = oracle.eval_fft_f64(p, h0, h0c, 0.5)
+    workloads.assert_parity(m.mesh.vertices, m.mesh.normals, m.mesh.colors, vf, nf, cf, rv, tag="Update")
+    m.generate = True
+    m.Update(0.1)
+    assert m.timer == pytest.approx(0.05)
+
+
+def test_shipped_non_commensurate_scene_direct_path(mw, oracle):
+    """The scene the reference ships (N=12, L=12.39, u=1) is not FFT-expressible: served by the direct-sum kernels."""
+    p = workloads.shipped_fftmesh_scene()
+    h0, h0c = oracle.generate_spectrum(p, 7)
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        for t in (0.0, 2.0):
+            v, n, c = o.evaluate(t)
+            vd, nd, cd = oracle.eval_f64(p, h0, h0c, t)
+            workloads.assert_parity(v, n, c, vd, nd, cd, rest, rel=4e-5, tag=f"shipped t={t}")
+    # and the golden fixture of the literal f32 restatement (tests/golden/make_golden.py)
+    z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "fftmesh_shipped_n12_t2.npz"))
+    with make(mw, p) as o:
+        o.set_spectrum(z["h0"], z["h0c"])
+        v, n, c = o.evaluate(float(z["t"]))
+    assert np.abs(v - z["vertices"]).max() < 2e-5 and np.abs(n - z["normals"]).max() < 2e-5
+    assert np.abs(c - z["colors"]).max() < 2e-4
+
+
+@pytest.mark.parametrize("N", [16, 33, 100])
+def test_direct_path_other_grids(mw, oracle, N):
+    p = oracle.Params(N=N, unit_width=0.9, length=float(N), wind_x=5, wind_y=3, amplitude=1e-3, choppiness=0.8)
+    h0, h0c = oracle.generate_spectrum(p, 2)
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        v, n, c = o.evaluate(1.25)
+    vd, nd, cd = oracle.eval_f64(p, h0, h0c, 1.25)
+    workloads.assert_parity(v, n, c, vd, nd, cd, rest, rel=4e-5, tag=f"direct N={N}")
+
+
+def test_golden_fixture_n16(mw):
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fftmesh_n16_t1p5.npz"))
+    pr = z["params"]
+    with mw.Ocean(resolution=int(pr[0]), unit_width=pr[1], length=pr[2], wind=(pr[3], pr[4]), amplitude=pr[5],
+                  choppiness=pr[6], gravity=pr[7]) as o:
+        o.set_spectrum(z["h0"], z["h0c"])
+        v, n, c = o.evaluate(float(z["t"]))
+    sc = np.abs(z["vertices_f64"][:, 1]).max()
+    assert np.abs(v - z["vertices_f64"]).max() < 1e-5 * max(sc, 1) + 1e-6
+    assert np.abs(n - z["normals_f64"]).max() < 1e-5
+
+
+def test_gerstner_pond(mw, emul):
+    """BASELINE config 5 shape (reduced count here; the 1M case is in bench): 8-wave Gerstner vs numpy f64."""
+    rng = np.random.default_rng(0)
+    for nv in (1000003, 4096, 5):
+        pos = rng.uniform(-50, 50, (nv, 3)).astype(np.float32)
+        W = workloads.pond_waves8()
+        P = workloads.POND
+        out = mw.gerstner_displace(pos, W, P["amplitude"], P["frequency"], P["steepness"], 3.25)
+        x, y, z = pos.astype(np.float64).T
+        ox, oy, oz = x.copy(), y.copy(), z.copy()
+        for dx, dy, sp in W:
+            th = P["frequency"] * (np.float32(dx) * x + np.float32(dy) * z) + 3.25 * np.float32(sp)
+            ox += np.cos(th) * P["steepness"] * P["amplitude"] * np.float32(dx)
+            oz += np.cos(th) * P["steepness"] * P["amplitude"] * np.float32(dy)
+            oy += P["amplitude"] * np.sin(th)
+        assert np.abs(out - np.stack([ox, oy, oz], 1)).max() < 2e-4  # |theta| ~ 400 rad in f32: 3e-5 rad of phase
+
+
+def test_errors_on_gpu(mw):
+    with pytest.raises(mw.MistralWaterError) as e:
+        mw.Ocean(resolution=8192, length=8192.0)
+    assert e.value.status == mw.MW_EINVAL
+    with pytest.raises(mw.MistralWaterError) as e:
+        mw.Ocean(resolution=1, length=1.0)
+    assert e.value.status == mw.MW_EINVAL
+    with pytest.raises(mw.MistralWaterError) as e:
+        mw.Ocean(resolution=64, length=64.0, device=99)
+    assert e.value.status == mw.MW_EINVAL

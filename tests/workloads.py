@@ -1,0 +1,51 @@
+"""Named synthetic workloads (SURVEY.md 8d / BASELINE.json configs) shared by tests and bench.py."""
+from oracle.oracle import Params
+
+
+def fftmesh_params(N: int, choppiness: float = 0.46) -> Params:
+    """BASELINE config 2/4 model at any N: commensurate grid (length = N * unit_width), the shipped
+    OceanRenderer wind (D/Ocean Demo.unity:302) and an amplitude that keeps wave heights O(1) at every N
+    (Phillips ~ A / k^4 with k ~ 1/N, so A scales like N^-2 relative to the N = 1024 value)."""
+    return Params(N=N, unit_width=1.0, length=float(N), wind_x=14.45, wind_y=12.0,
+                  amplitude=1.5e-8 * (1024.0 / N) ** 2, choppiness=choppiness, gravity=9.81)
+
+
+def shipped_fftmesh_scene() -> Params:
+    """The scene the reference ships (D/FFT Mesh.unity:145-152): NOT commensurate, N = 12."""
+    return Params(N=12, unit_width=1.0, length=12.39, wind_x=5.0, wind_y=3.0, amplitude=0.01, choppiness=1.0)
+
+
+# pond material shipped by the reference (M/Pond Water Mat.mat:90,104,122,134-136)
+POND = dict(amplitude=10 * 0.01, frequency=2.58, steepness=0.99,
+            waves=[(0.3, 0.73, 1.2), (0.85, 0.25, 0.71), (-0.25, 1.11, 1.1), (0.5, 0.5, 0.73)])
+
+
+def pond_waves8():
+    """BASELINE config 5 '8 waves': the 4 shipped + the same 4 rotated 90 degrees at half speed."""
+    w = list(POND["waves"])
+    w += [(-dy, dx, 0.5 * sp) for (dx, dy, sp) in POND["waves"]]
+    return w
+
+
+# ---- the float32 parity tolerance, stated once (north_star: "within a stated float32 tolerance") ------
+# A vertex coordinate is rest + displacement stored as f32, so its error budget is one ulp of the stored
+# coordinate (2^-23 relative) plus REL_TOL times the largest displacement/height in the field.
+REL_TOL = 4e-6      # fields (height, displacement) relative to max |field|; ~ 30 ulp of headroom over the
+                    # measured 2e-7..1e-6 of an f32 Stockham transform with f64-rounded twiddles
+NORMAL_TOL = 4e-6   # unit normals, absolute
+WHITE_TOL = 2e-5    # whitecap scalar in [0,1], absolute, per unit of max |hds| (Jacobian amplifies d-errors)
+
+
+def assert_parity(v, n, w, vf, nf, cf, rest, hds_max=None, rel=REL_TOL, tag=""):
+    import numpy as np
+    scale = max(float(np.abs(vf - rest).max()), 1e-3)
+    bound = rel * scale + np.abs(vf) * 2.0 ** -23
+    dv = np.abs(v - vf)
+    assert (dv <= bound).all(), f"{tag} vertices: max excess {float((dv - bound).max()):.3e} (scale {scale:.3g})"
+    dn = float(np.abs(n - nf).max())
+    assert dn < NORMAL_TOL * (rel / REL_TOL), f"{tag} normals: {dn:.3e}"
+    hm = max(1.0, float(hds_max) if hds_max is not None else scale)
+    wv = w[..., 0] if w.ndim == cf.ndim and w.shape[-1] != cf.shape[-1] else w
+    cfv = cf[..., 0] if cf.shape != wv.shape else cf
+    dw = float(np.abs(wv - cfv).max())
+    assert dw < WHITE_TOL * hm * (rel / REL_TOL), f"{tag} whitecap: {dw:.3e}"
