@@ -27,14 +27,16 @@ struct StepTimes {
     float t[MW_MAX_BATCH];
 };
 
-MW_HD void mw_sincos(float x, float* s, float* c) {
+MW_HD void mw_sincos(float x, float* s, float* c) { sincos_f32(x, s, c); }
+MW_HD float mw_rsqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    sincosf(x, s, c);  // ocml accurate path (full range reduction), not __sincosf
+    return __frsqrt_rn(x);
 #else
-    *s = sinf(x);
-    *c = cosf(x);
+    return 1.0f / sqrtf(x);
 #endif
 }
+// multipliers only (tolerance-level, not index work): k = (i - N/2) * 2 pi / L, S/FFTMesh.cs:201
+MW_HD float wave_k_fast(int N, float kscale, int i) { return (float)(i - N / 2) * kscale; }
 
 // =============================== init-time element kernels ==================================
 
@@ -110,8 +112,17 @@ MW_HD void rest_mesh_element(int N, float unit_width, int i, int j, float* verti
 //   Hh(k,t) = 1/2 [h~(k,t) + s conj h~(mk,t)] = P e^{i w t} + Q e^{-i w t}
 // with P = 1/2 (h0(k) + s conj h0c(mk)), Q = 1/2 (h0c(k) + s conj h0(mk)); on the two Nyquist lines
 // the odd multipliers need Ha = Hh + D, D = dP e^{iwt} + dQ e^{-iwt}, dP = -s conj h0c(mk), dQ = -s conj h0(mk).
-// PQt is stored TRANSPOSED ([j][i]) so that pass 1 (transform along i) reads contiguous rows.
-MW_HD void prep_element(int N, int i, int j, const cf* h0, const cf* h0c, f4* PQt, f4* dPQ_i0, f4* dPQ_j0) {
+// PQt is stored TRANSPOSED ([j][i]) so that pass 1 (transform along i) reads contiguous rows, and is
+// pre-multiplied by the transform's separable pre-twiddle pre(i+j) = (-1)^(i+j) e^{i pi (i+j)/N}
+//  so the per-step kernel never touches it.  Om[j][i] = Dispersion(i,j), strict f32.
+MW_HD f4 f4_times(f4 v, cf w) {  // both complex halves times w
+    f4 r;
+    r.x = v.x * w.x - v.y * w.y; r.y = v.x * w.y + v.y * w.x;
+    r.z = v.z * w.x - v.w * w.y; r.w = v.z * w.y + v.w * w.x;
+    return r;
+}
+MW_HD void prep_element(int N, float length, float gravity, int i, int j, const cf* h0, const cf* h0c, const cf* Wpre,
+                        f4* PQt, f4* dPQ_i0, f4* dPQ_j0, float* Om) {
     int mi = (N - i) & (N - 1), mj = (N - j) & (N - 1);
     float s = ((i == 0) != (j == 0)) ? -1.f : 1.f;
     cf a = h0[(size_t)i * N + j], b = h0c[(size_t)i * N + j];
@@ -121,22 +132,30 @@ MW_HD void prep_element(int N, int i, int j, const cf* h0, const cf* h0c, f4* PQ
     pq.y = 0.5f * (a.y - s * bm.y);
     pq.z = 0.5f * (b.x + s * am.x);
     pq.w = 0.5f * (b.y - s * am.y);
-    PQt[(size_t)j * N + i] = pq;
+    const cf pre = Wpre[i + j];
+    PQt[(size_t)j * N + i] = f4_times(pq, pre);
+    Om[(size_t)j * N + i] = omega_f32(N, length, gravity, i, j);
     f4 d;
     d.x = -s * bm.x; d.y = s * bm.y; d.z = -s * am.x; d.w = s * am.y;
+    d = f4_times(d, pre);
     if (i == 0) dPQ_i0[j] = d;
     if (j == 0) dPQ_j0[i] = d;
 }
 
 // =============================== pass 1: transform along i ===================================
-// grid (N/4, nsteps); block 4*T threads; block jb owns spectrum columns j = 4 jb .. 4 jb + 3.
+// grid (N/4 + 1, nsteps); block 4*T threads.  Block jb < N/4 owns spectrum columns j = 4 jb .. 4 jb + 3.
+// The extra block jb == N/4 is the *Nyquist-column job*: it transforms the correction column
+// cz(i,0) * D'(i,0) through the very same code path and writes it to Cj0, which
+// pass 2 adds to element j = 0 of every row.  The i = 0 correction is one element per column: thread
+// u == 0 carries it in `dl0` (zero for every other thread, so no branch).
 struct P1Args {
-    const f4* PQt;
-    const f4* dPQ_i0;
-    const f4* dPQ_j0;
-    const cf* W;     // e^{+2 pi i k/N}, k < N
-    const cf* Wpre;  // (-1)^m e^{i pi m/N}, m < 2N
-    cf* E;           // exchange buffer [step][3][N/4][N][4]
+    const f4* PQt;     // [j][i] (P,Q) * pre
+    const f4* dPQ_i0;  // [j]    (dP,dQ) * pre on the row i = 0
+    const f4* dPQ_j0;  // [i]    (dP,dQ) * pre on the column j = 0
+    const float* Om;   // omega(i,j) at [j][i]
+    Twiddles tw;
+    cf* E;             // exchange buffer [step][3][N/4][N][4]
+    cf* Cj0;           // [step][3][N]  transform of the j = 0 correction column
     OceanConsts c;
 };
 
@@ -146,25 +165,14 @@ struct P1Geom {
     static constexpr int NTHREADS = 4 * T;
     static constexpr int BUFSTRIDE = FftGeom<N>::LBUF + 4;
     static constexpr int LDS_BYTES = 4 * BUFSTRIDE * (int)sizeof(cf);
+    static constexpr int GRID_X = N / 4 + 1;
 };
 
-// h~-like packed spectrum Hh(k,t) times the pre-twiddle, 16 points per thread (column w, i = u + T q)
 template <int N>
-MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, cf (&hh)[16]) {
-    constexpr int T = FftGeom<N>::T;
-    const int w = tid / T, u = tid % T, j = 4 * jb + w;
-    f4 pq[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) pq[q] = A.PQt[(size_t)j * N + u + T * q];
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int i = u + T * q;
-        float th = omega_t_f32(N, A.c.length, A.c.gravity, i, j, t);
-        float s, c;
-        mw_sincos(th, &s, &c);
-        hh[q] = cmul(animate(pq[q].x, pq[q].y, pq[q].z, pq[q].w, c, s), A.Wpre[i + j]);
-    }
-}
+struct P1State {
+    cf hh[16];  // Hh(k,t)*pre for a regular column; D'(i,0) for the Nyquist-column job
+    cf dl0;     // D'(0,j) in thread u == 0 of a regular column, else 0
+};
 
 // multipliers of the packed fields: Z_f = (cx + cz) * Hh   (cx acts on the kx-odd part, cz on kz-odd)
 //   f=0: H                       Z1 = Hh
@@ -172,10 +180,10 @@ MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, cf (&hh)[16]) {
 //   f=2: Sx + i Sz (slopes)      cx = -i kx,     cz = +kz          (S/FFTMesh.cs:212)
 MW_HD void field_coeffs(int f, float kx, float kz, cf* cx, cf* cz) {
     if (f == 1) {
-        float kl = sqrtf(kx * kx + kz * kz);
+        const float k2 = kx * kx + kz * kz;
         float ux = 0.f, uz = 0.f;
-        if (!(kl < MW_EPS_F)) {  // :213
-            float inv = 1.0f / kl;
+        if (!(k2 < MW_EPS_F * MW_EPS_F)) {  // |k| < EPSILON -> skipped, :213
+            const float inv = mw_rsqrt(k2);
             ux = kx * inv;
             uz = kz * inv;
         }
@@ -187,45 +195,53 @@ MW_HD void field_coeffs(int f, float kx, float kz, cf* cx, cf* cz) {
     }
 }
 
+// animated packed spectrum, 16 points per thread (column job w, i = u + T q)
 template <int N>
-MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, float t, const cf (&hh)[16], cf (&x)[16]) {
+MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, P1State<N>& st) {
     constexpr int T = FftGeom<N>::T;
-    const int w = tid / T, u = tid % T, j = 4 * jb + w;
-    if (f == 0) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) x[q] = hh[q];
-        return;
-    }
-    const float kz = wave_k(N, A.c.length, j);
+    const int w = tid / T, u = tid % T;
+    const bool fix = (jb == N / 4);
+    const int j = fix ? 0 : 4 * jb + w;
+    const f4* __restrict__ pqrow = fix ? A.dPQ_j0 + u : A.PQt + (size_t)j * N + u;
+    const float* __restrict__ omrow = A.Om + (size_t)j * N + u;
+    const bool live = !fix || w == 0;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-        const int i = u + T * q;
-        cf cx, cz;
-        field_coeffs(f, wave_k(N, A.c.length, i), kz, &cx, &cz);
-        x[q] = cmul(cx + cz, hh[q]);
+        f4 pq = pqrow[T * q];
+        float s, c;
+        mw_sincos(smul(omrow[T * q], t), &s, &c);  // omega*t: one f32 multiply, S/FFTMesh.cs:183
+        cf h = animate(pq.x, pq.y, pq.z, pq.w, c, s);
+        st.hh[q] = live ? h : mk(0.f, 0.f);
     }
-    // Nyquist-line corrections (index 0 mirrors onto itself with a sign flip)
-    if (j == 0) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int i = u + T * q;
-            f4 d = A.dPQ_j0[i];
-            float s, c;
-            mw_sincos(omega_t_f32(N, A.c.length, A.c.gravity, i, j, t), &s, &c);
-            cf dl = cmul(animate(d.x, d.y, d.z, d.w, c, s), A.Wpre[i + j]);
-            cf cx, cz;
-            field_coeffs(f, wave_k(N, A.c.length, i), kz, &cx, &cz);
-            x[q] = x[q] + cmul(cz, dl);
-        }
-    }
-    if (u == 0) {  // i == 0 lives in slot 0 of thread u == 0
+    st.dl0 = mk(0.f, 0.f);
+    if (u == 0 && !fix) {  // element i = 0 of this column
         f4 d = A.dPQ_i0[j];
         float s, c;
-        mw_sincos(omega_t_f32(N, A.c.length, A.c.gravity, 0, j, t), &s, &c);
-        cf dl = cmul(animate(d.x, d.y, d.z, d.w, c, s), A.Wpre[j]);
+        mw_sincos(smul(A.Om[(size_t)j * N], t), &s, &c);
+        st.dl0 = animate(d.x, d.y, d.z, d.w, c, s);
+    }
+}
+
+template <int N>
+MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, const P1State<N>& st, cf (&x)[16]) {
+    constexpr int T = FftGeom<N>::T;
+    const int w = tid / T, u = tid % T;
+    const bool fix = (jb == N / 4);
+    const int j = fix ? 0 : 4 * jb + w;
+    if (f == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) x[q] = st.hh[q];
+        return;
+    }
+    const float kscale = 2.0f * MW_PI_F / A.c.length;
+    const float kz = wave_k_fast(N, kscale, j);
+    const float fx = fix ? 0.f : 1.f;  // the Nyquist-column job keeps only the cz part
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
         cf cx, cz;
-        field_coeffs(f, wave_k(N, A.c.length, 0), kz, &cx, &cz);
-        x[0] = x[0] + cmul(cx, dl);
+        field_coeffs(f, wave_k_fast(N, kscale, u + T * q), kz, &cx, &cz);
+        x[q] = cmul(cscale(cx, fx) + cz, st.hh[q]);
+        if (q == 0) x[0] = x[0] + cmul(cx, st.dl0);  // i = 0 correction (dl0 == 0 unless u == 0)
     }
 }
 
@@ -235,7 +251,15 @@ MW_HD void p1_finish(const P1Args& A, int jb, int step, int tid, int f, cf (&x)[
     constexpr int T = FftGeom<N>::T;
     const int w2 = tid & 3, u2 = tid >> 2;
     load_slots<N>(x, u2, lds + w2 * P1Geom<N>::BUFSTRIDE);
-    final_stage<N, +1>(x, u2, A.W);
+    final_stage<N, +1>(x, u2, A.tw.TF);
+    if (jb == N / 4) {
+        if (w2 == 0) {
+            cf* C = A.Cj0 + ((size_t)step * 3 + f) * N;
+#pragma unroll
+            for (int q = 0; q < 16; q++) C[u2 + T * q] = x[q];
+        }
+        return;
+    }
     cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)jb * N * 4;
 #pragma unroll
     for (int q = 0; q < 16; q++) Ef[(size_t)(u2 + T * q) * 4 + w2] = x[q];
@@ -246,7 +270,8 @@ MW_HD void p1_finish(const P1Args& A, int jb, int step, int tid, int f, cf (&x)[
 // halo row a0+R2 (displacement field only) that the forward-difference Jacobian needs (S/FFTMesh.cs:262).
 struct P2Args {
     const cf* E;
-    const cf* W;
+    const cf* Cj0;    // [step][3][N]
+    Twiddles tw;
     float* vertices;  // [step][N*N*3]
     float* normals;   // [step][N*N*3]
     float* white;     // [step][N*N*white_stride]
@@ -294,6 +319,7 @@ MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[16
         const int j = u1 + T * q;
         x[q] = Ef[((size_t)(j >> 2) * N + row) * 4 + (j & 3)];
     }
+    if (u1 == 0 && f != 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];  // Nyquist column j = 0
     stageA_store<N, +1>(x, u1, lds + r1 * P2Geom<N, R2>::BUFSTRIDE);
 }
 template <int N, int R2>
@@ -310,7 +336,7 @@ MW_HD void p2_mid_store(const P2Args& A, int tid, cf (&x)[16], cf* lds) {
     int r1, u1;
     if (tid < R2 * T) { r1 = tid % R2; u1 = tid / R2; }
     else { r1 = R2; u1 = tid - R2 * T; }
-    stageB_store<N, +1>(x, u1, lds + r1 * P2Geom<N, R2>::BUFSTRIDE, A.W);
+    stageB_store<N, +1>(x, u1, lds + r1 * P2Geom<N, R2>::BUFSTRIDE, A.tw.TB);
 }
 
 // final pass in the row-major mapping (thread (g,u) owns row a0+g, columns b = u + T q)
@@ -319,7 +345,7 @@ MW_HD void p2_finish(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[
     constexpr int T = FftGeom<N>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
     load_slots<N>(x, u, lds + g * P2Geom<N, R2>::BUFSTRIDE);
-    final_stage<N, +1>(x, u, A.W);
+    final_stage<N, +1>(x, u, A.tw.TF);
     if (f == 2) {  // slopes -> unit normal (S/FFTMesh.cs:218), stored at once
         float* nout = A.normals + ((size_t)step * N * N + (size_t)a * N) * 3;
 #pragma unroll
@@ -327,9 +353,9 @@ MW_HD void p2_finish(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[
             const int b = u + T * q;
             const float sg = post_sign(a, b);
             const float sx = sg * x[q].x, sz = sg * x[q].y;
-            const float mag = sqrtf(sx * sx + 1.0f + sz * sz);
-            float nx = 0.f, ny = 0.f, nz = 0.f;
-            if (mag > 1e-5f) { nx = sx / mag; ny = 1.0f / mag; nz = sz / mag; }  // Vector3.Normalize [unity]
+            // Vector3.Normalize(up - n): |(sx,1,sz)| >= 1, so Unity's 1e-5 zero-guard never fires
+            const float inv = mw_rsqrt(sx * sx + 1.0f + sz * sz);
+            const float nx = sx * inv, ny = inv, nz = sz * inv;
             nout[3 * b + 0] = nx;
             nout[3 * b + 1] = ny;
             nout[3 * b + 2] = nz;

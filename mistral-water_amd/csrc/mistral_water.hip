@@ -17,6 +17,13 @@
 #include "ocean_renderer_kernels.h"
 #include "gerstner_kernels.h"
 
+#ifndef MW_WAVES_P1
+#define MW_WAVES_P1 4
+#endif
+#ifndef MW_WAVES_P2
+#define MW_WAVES_P2 3
+#endif
+
 using namespace mw;
 
 // ------------------------------------------------------------------------------------------------
@@ -50,11 +57,12 @@ __global__ void k_rest_mesh(int N, float unit_width, float* vertices, float* nor
     rest_mesh_element(N, unit_width, idx / N, idx % N, vertices, normals, uvs, indices);
 }
 
-__global__ void k_prep(int N, const cf* h0, const cf* h0c, f4* PQt, f4* dPQ_i0, f4* dPQ_j0) {
+__global__ void k_prep(int N, float length, float gravity, const cf* h0, const cf* h0c, const cf* Wpre, f4* PQt,
+                       f4* dPQ_i0, f4* dPQ_j0, float* Om) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * N) return;
     // idx enumerates the TRANSPOSED array so that the writes are the coalesced side
-    prep_element(N, idx % N, idx / N, h0, h0c, PQt, dPQ_i0, dPQ_j0);
+    prep_element(N, length, gravity, idx % N, idx / N, h0, h0c, Wpre, PQt, dPQ_i0, dPQ_j0, Om);
 }
 
 __global__ void k_omega_t(int N, float length, float gravity, float t, float* out) {
@@ -64,7 +72,7 @@ __global__ void k_omega_t(int N, float length, float gravity, float t, float* ou
 }
 
 template <int N>
-__global__ __launch_bounds__(P1Geom<N>::NTHREADS) void k_pass1(P1Args A, StepTimes times) {
+__global__ __launch_bounds__(P1Geom<N>::NTHREADS) __attribute__((amdgpu_waves_per_eu(MW_WAVES_P1, MW_WAVES_P1))) void k_pass1(P1Args A, StepTimes times) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = FftGeom<N>::T;
@@ -72,18 +80,20 @@ __global__ __launch_bounds__(P1Geom<N>::NTHREADS) void k_pass1(P1Args A, StepTim
     const int tid = threadIdx.x, jb = blockIdx.x, step = blockIdx.y;
     const float t = times.t[step];
     const int w = tid / T, u = tid % T;
-    cf hh[16], x[16];
-    p1_animate<N>(A, jb, tid, t, hh);
+    P1State<N> st;
+    cf x[16];
+    p1_animate<N>(A, jb, tid, t, st);
 #pragma unroll
     for (int f = 0; f < 3; f++) {
-        p1_build<N>(A, jb, tid, f, t, hh, x);
+        if (f == 0 && jb == N / 4) continue;  // the Nyquist-column job has no height term (block-uniform)
+        p1_build<N>(A, jb, tid, f, st, x);
         if (f) __syncthreads();
         stageA_store<N, +1>(x, u, lds + w * BS);
         __syncthreads();
         if (FftGeom<N>::HAS_B) {
             load_slots<N>(x, u, lds + w * BS);
             __syncthreads();
-            stageB_store<N, +1>(x, u, lds + w * BS, A.W);
+            stageB_store<N, +1>(x, u, lds + w * BS, A.tw.TB);
             __syncthreads();
         }
         p1_finish<N>(A, jb, step, tid, f, x, lds);
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(P1Geom<N>::NTHREADS) void k_pass1(P1Args A, StepTim
 }
 
 template <int N, int R2>
-__global__ __launch_bounds__((P2Geom<N, R2>::NTHREADS)) void k_pass2(P2Args A) {
+__global__ __launch_bounds__((P2Geom<N, R2>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(MW_WAVES_P2, MW_WAVES_P2))) void k_pass2(P2Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = FftGeom<N>::T;
@@ -135,8 +145,9 @@ struct mw_ocean {
     // FFTMesh state
     cf *h0 = nullptr, *h0c = nullptr;
     f4 *PQt = nullptr, *dPQ_i0 = nullptr, *dPQ_j0 = nullptr;
-    cf *W = nullptr, *Wpre = nullptr;
-    cf* E = nullptr;
+    float* Om = nullptr;
+    cf *TB = nullptr, *TF = nullptr, *Wpre = nullptr;
+    cf *E = nullptr, *Cj0 = nullptr;
     int e_cap = 0;  // steps the exchange buffer holds
     float *s_vert = nullptr, *s_norm = nullptr, *s_white = nullptr;  // 1-step scratch for the host API
     DirectState direct;
@@ -154,20 +165,29 @@ static mw_status dmalloc(T** p, size_t count) {
 
 static mw_status upload_twiddles(mw_ocean* o) {
     const int N = o->N;
-    std::vector<cf> W(N), Wpre(2 * N);
-    for (int k = 0; k < N; k++) {
-        double a = 2.0 * M_PI * (double)k / (double)N;
-        W[k] = mk((float)cos(a), (float)sin(a));
-    }
+    const int T = N / 16, PD = (N >= 256) ? 256 : 16, RL = N / PD;
+    std::vector<cf> TB(256), TF((size_t)T * RL), Wpre(2 * N);
+    for (int k = 0; k < 16; k++)
+        for (int r = 0; r < 16; r++) {
+            double a = 2.0 * M_PI * (double)(r * k) / 256.0;
+            TB[k * 16 + r] = mk((float)cos(a), (float)sin(a));
+        }
+    for (int u = 0; u < T; u++)
+        for (int r = 0; r < RL; r++) {
+            double a = 2.0 * M_PI * (double)(r * u) / (double)N;
+            TF[(size_t)u * RL + r] = mk((float)cos(a), (float)sin(a));
+        }
     for (int m = 0; m < 2 * N; m++) {
         double a = M_PI * (double)m / (double)N;  // (-1)^m e^{i pi m/N}
         double sg = (m & 1) ? -1.0 : 1.0;
         Wpre[m] = mk((float)(sg * cos(a)), (float)(sg * sin(a)));
     }
     mw_status s;
-    if ((s = dmalloc(&o->W, N)) != MW_OK) return s;
+    if ((s = dmalloc(&o->TB, 256)) != MW_OK) return s;
+    if ((s = dmalloc(&o->TF, (size_t)T * RL)) != MW_OK) return s;
     if ((s = dmalloc(&o->Wpre, 2 * N)) != MW_OK) return s;
-    HIP_TRY(hipMemcpy(o->W, W.data(), sizeof(cf) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(o->TB, TB.data(), sizeof(cf) * 256, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(o->TF, TF.data(), sizeof(cf) * T * RL, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(o->Wpre, Wpre.data(), sizeof(cf) * 2 * N, hipMemcpyHostToDevice));
     return MW_OK;
 }
@@ -195,7 +215,7 @@ static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nstep
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_pass1<N>, dim3(N / 4, nsteps), dim3(P1Geom<N>::NTHREADS), P1Geom<N>::LDS_BYTES, st, A, tm);
+    hipLaunchKernelGGL(k_pass1<N>, dim3(P1Geom<N>::GRID_X, nsteps), dim3(P1Geom<N>::NTHREADS), P1Geom<N>::LDS_BYTES, st, A, tm);
     return hipGetLastError();
 }
 template <int N>
@@ -227,7 +247,8 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
 
 static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps) {
     P1Args A;
-    A.PQt = o->PQt; A.dPQ_i0 = o->dPQ_i0; A.dPQ_j0 = o->dPQ_j0; A.W = o->W; A.Wpre = o->Wpre; A.E = o->E;
+    A.PQt = o->PQt; A.dPQ_i0 = o->dPQ_i0; A.dPQ_j0 = o->dPQ_j0; A.Om = o->Om; A.tw.TB = o->TB; A.tw.TF = o->TF;
+    A.E = o->E; A.Cj0 = o->Cj0;
     A.c = consts_of(o);
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass1_n<NN>(A, tm, nsteps, o->stream));
@@ -236,7 +257,7 @@ static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps) {
 }
 static mw_status launch_pass2(mw_ocean* o, int nsteps, float* dv, float* dn, float* dw, int white_stride) {
     P2Args A;
-    A.E = o->E; A.W = o->W; A.vertices = dv; A.normals = dn; A.white = dw; A.white_stride = white_stride;
+    A.E = o->E; A.Cj0 = o->Cj0; A.tw.TB = o->TB; A.tw.TF = o->TF; A.vertices = dv; A.normals = dn; A.white = dw; A.white_stride = white_stride;
     A.c = consts_of(o);
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass2_n<NN>(A, nsteps, o->stream));
@@ -249,11 +270,13 @@ static mw_status ensure_exchange(mw_ocean* o, int nsteps) {
     if (o->E) {
         HIP_TRY(hipStreamSynchronize(o->stream));
         HIP_TRY(hipFree(o->E));
-        o->E = nullptr;
+        HIP_TRY(hipFree(o->Cj0));
+        o->E = o->Cj0 = nullptr;
         o->e_cap = 0;
     }
     mw_status s = dmalloc(&o->E, (size_t)nsteps * 3 * o->N * o->N);
     if (s != MW_OK) return s;
+    if ((s = dmalloc(&o->Cj0, (size_t)nsteps * 3 * o->N)) != MW_OK) return s;
     o->e_cap = nsteps;
     return MW_OK;
 }
@@ -261,8 +284,8 @@ static mw_status ensure_exchange(mw_ocean* o, int nsteps) {
 static mw_status run_prep(mw_ocean* o) {
     const int N = o->N;
     if (o->use_fft) {
-        hipLaunchKernelGGL(k_prep, dim3((N * N + 255) / 256), dim3(256), 0, o->stream, N, o->h0, o->h0c, o->PQt,
-                           o->dPQ_i0, o->dPQ_j0);
+        hipLaunchKernelGGL(k_prep, dim3((N * N + 255) / 256), dim3(256), 0, o->stream, N, o->p.length, o->p.gravity,
+                           o->h0, o->h0c, o->Wpre, o->PQt, o->dPQ_i0, o->dPQ_j0, o->Om);
         HIP_TRY(hipGetLastError());
     }
     return MW_OK;
@@ -301,8 +324,8 @@ void mw_ocean_destroy(mw_ocean* o) {
     if (!o) return;
     hipSetDevice(o->device);
     if (o->stream) hipStreamSynchronize(o->stream);
-    hipFree(o->h0); hipFree(o->h0c); hipFree(o->PQt); hipFree(o->dPQ_i0); hipFree(o->dPQ_j0);
-    hipFree(o->W); hipFree(o->Wpre); hipFree(o->E); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white);
+    hipFree(o->h0); hipFree(o->h0c); hipFree(o->PQt); hipFree(o->Om); hipFree(o->dPQ_i0); hipFree(o->dPQ_j0);
+    hipFree(o->TB); hipFree(o->TF); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white);
     direct_free(o->direct);
     or_free(o->orr);
     if (o->own_stream) hipStreamDestroy(o->own_stream);
@@ -349,7 +372,8 @@ mw_status mw_ocean_create(const mw_params* params, mw_ocean** out) {
             (s = dmalloc(&o->s_vert, NN * 3)) != MW_OK || (s = dmalloc(&o->s_norm, NN * 3)) != MW_OK ||
             (s = dmalloc(&o->s_white, NN * 4)) != MW_OK) { mw_ocean_destroy(o); return s; }
         if (o->use_fft) {
-            if ((s = dmalloc(&o->PQt, NN)) != MW_OK || (s = dmalloc(&o->dPQ_i0, (size_t)N)) != MW_OK ||
+            if ((s = dmalloc(&o->PQt, NN)) != MW_OK || (s = dmalloc(&o->Om, NN)) != MW_OK ||
+                (s = dmalloc(&o->dPQ_i0, (size_t)N)) != MW_OK ||
                 (s = dmalloc(&o->dPQ_j0, (size_t)N)) != MW_OK || (s = upload_twiddles(o)) != MW_OK) {
                 mw_ocean_destroy(o); return s;
             }

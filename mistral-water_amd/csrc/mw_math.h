@@ -52,6 +52,30 @@ MW_HD float sdiv(float a, float b) { return a / b; }
 MW_HD float ssqrt(float a) { return sqrtf(a); }
 #endif
 
+// ---- sin/cos of a float32 phase, |x| <~ 1e5 rad ---------------------------------------------------
+// The reference forms cos/sin of the FLOAT omega*t through double libm (Mathf.Cos, S/FFTMesh.cs:184-185).
+// Here: 3-term Cody-Waite reduction by pi/2 carried in FMAs (exact for |k| < 2^17) + the classic
+// degree-7/8 minimax polynomials on [-pi/4, pi/4]; absolute error <= ~1.5e-7 (about 1 ulp of a result
+// near 1), identical code on host (emulation) and device.  ~25 VALU ops, no branches, 6 live registers.
+MW_HD void sincos_f32(float x, float* sn, float* cs) {
+    const float k = rintf(x * 0.63661977236758134308f);  // 2/pi
+    float r = fmaf(-k, 1.5703125f, x);                    // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.5497899e-8
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.549789948768648e-8f, r);
+    const float z = r * r;
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(z, ps, -1.6666654611e-1f);
+    ps = fmaf(ps * z, r, r);  // sin(r)
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(z, pc, 4.166664568298827e-2f);
+    pc = fmaf(pc * z, z, fmaf(z, -0.5f, 1.0f));  // cos(r)
+    const int q = (int)k;
+    const float s0 = (q & 1) ? pc : ps;
+    const float c0 = (q & 1) ? ps : pc;
+    *sn = (q & 2) ? -s0 : s0;
+    *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 // S/FFTMesh.cs:141-147 Dispersion(n,m) * t  (:183) -- bit-for-bit the reference's float sequence.
 MW_HD float omega_f32(int N, float length, float gravity, int n, int m) {
     float w = sdiv(smul(2.0f, MW_PI_F), length);
@@ -224,26 +248,37 @@ MW_HD void load_slots(cf (&x)[16], int u, const cf* buf) {
 #pragma unroll
     for (int q = 0; q < 16; q++) x[q] = buf[lds_pad(u + FftGeom<N>::T * q)];
 }
-// W[k] = e^{SGN 2 pi i k/N}, k = 0..N-1
+// Twiddle tables (built on the host in double, rounded once to f32; SGN baked in):
+//   TB[k*16 + r] = e^{SGN 2 pi i r k/256}          k,r < 16     (second radix-16 pass, p = 16)
+//   TF[u*RL + r] = e^{SGN 2 pi i r u/N}            u < T, r < RL (final pass; the remaining factor
+//                  e^{SGN 2 pi i r m/16} of thread u's m-th butterfly is a compile-time rotation)
+// Both are read as one contiguous run per thread (vector loads, one address register).
+struct Twiddles {
+    const cf* TB;
+    const cf* TF;
+};
 template <int N, int SGN>
-MW_HD void stageB_store(cf (&x)[16], int u, cf* buf, const cf* __restrict__ W) {
+MW_HD void stageB_store(cf (&x)[16], int u, cf* buf, const cf* __restrict__ TB) {
     const int k = u & 15;
+    const cf* __restrict__ row = TB + k * 16;
 #pragma unroll
-    for (int r = 1; r < 16; r++) x[r] = cmul(x[r], W[(N / 256) * r * k]);
+    for (int r = 1; r < 16; r++) x[r] = cmul(x[r], row[r]);
     dft16<SGN>(x);
     const int j = ((u - k) << 4) + k;
 #pragma unroll
     for (int r = 0; r < 16; r++) buf[lds_pad(j + 16 * r)] = x[r];
 }
 template <int N, int SGN>
-MW_HD void final_stage(cf (&x)[16], int u, const cf* __restrict__ W) {
-    constexpr int RL = FftGeom<N>::RL, NB = FftGeom<N>::NB, T = FftGeom<N>::T;
+MW_HD void final_stage(cf (&x)[16], int u, const cf* __restrict__ TF) {
+    constexpr int RL = FftGeom<N>::RL, NB = FftGeom<N>::NB;
     if (RL == 1) return;
+    cf tw[RL];
+#pragma unroll
+    for (int r = 1; r < RL; r++) tw[r] = TF[u * RL + r];
 #pragma unroll
     for (int m = 0; m < NB; m++) {
-        const int v = u + T * m;
 #pragma unroll
-        for (int r = 1; r < RL; r++) x[m + r * NB] = cmul(x[m + r * NB], W[r * v]);
+        for (int r = 1; r < RL; r++) x[m + r * NB] = tw16<SGN>(cmul(x[m + r * NB], tw[r]), (r * m) & 15);
         if (RL == 2) {
             dft2<SGN>(x[m], x[m + NB]);
         } else if (RL == 4) {

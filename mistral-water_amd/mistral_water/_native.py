@@ -13,7 +13,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 AMD_DIR = os.path.dirname(PKG_DIR)                      # .../mistral-water_amd
 REPO_DIR = os.path.dirname(AMD_DIR)
 CSRC_DIR = os.path.join(AMD_DIR, "csrc")
-LIB_PATH = os.path.join(AMD_DIR, "libmistral_water.so")
+LIB_PATH = os.environ.get("MW_LIB") or os.path.join(AMD_DIR, "libmistral_water.so")  # MW_LIB: A/B kernel variants
 HEADER_PATH = os.path.join(REPO_DIR, "include", "mistral_water.h")
 
 MW_OK, MW_EINVAL, MW_ENOTPOW2, MW_ENOTCOMMENSURATE, MW_ENOMEM, MW_EDEVICE, MW_ESTATE = range(7)

@@ -21,39 +21,49 @@ using namespace mw;
 namespace {
 
 struct Tables {
-    std::vector<cf> W, Wpre;
-    explicit Tables(int N) : W(N), Wpre(2 * N) {
-        for (int k = 0; k < N; k++) {
-            double a = 2.0 * M_PI * (double)k / (double)N;
-            W[k] = mk((float)cos(a), (float)sin(a));
-        }
+    std::vector<cf> TB, TF, Wpre;
+    explicit Tables(int N) : TB(256), Wpre(2 * N) {
+        const int T = N / 16, PD = (N >= 256) ? 256 : 16, RL = N / PD;
+        TF.resize((size_t)T * RL);
+        for (int k = 0; k < 16; k++)
+            for (int r = 0; r < 16; r++) {
+                double a = 2.0 * M_PI * (double)(r * k) / 256.0;
+                TB[k * 16 + r] = mk((float)cos(a), (float)sin(a));
+            }
+        for (int u = 0; u < T; u++)
+            for (int r = 0; r < RL; r++) {
+                double a = 2.0 * M_PI * (double)(r * u) / (double)N;
+                TF[(size_t)u * RL + r] = mk((float)cos(a), (float)sin(a));
+            }
         for (int m = 0; m < 2 * N; m++) {
             double a = M_PI * (double)m / (double)N;
             double sg = (m & 1) ? -1.0 : 1.0;
             Wpre[m] = mk((float)(sg * cos(a)), (float)(sg * sin(a)));
         }
     }
+    Twiddles tw() const { Twiddles t; t.TB = TB.data(); t.TF = TF.data(); return t; }
 };
 
 template <int N>
 void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
     constexpr int T = FftGeom<N>::T, NT = P1Geom<N>::NTHREADS, BS = P1Geom<N>::BUFSTRIDE;
     std::vector<cf> lds(4 * BS);
-    struct St { cf hh[16]; cf x[16]; };
+    struct St { P1State<N> s; cf x[16]; };
     std::vector<St> st(NT);
     for (int step = 0; step < nsteps; step++)
-        for (int jb = 0; jb < N / 4; jb++) {
+        for (int jb = 0; jb < P1Geom<N>::GRID_X; jb++) {
             const float t = tm.t[step];
-            for (int tid = 0; tid < NT; tid++) p1_animate<N>(A, jb, tid, t, st[tid].hh);
+            for (int tid = 0; tid < NT; tid++) p1_animate<N>(A, jb, tid, t, st[tid].s);
             for (int f = 0; f < 3; f++) {
+                if (f == 0 && jb == N / 4) continue;
                 for (int tid = 0; tid < NT; tid++) {
-                    p1_build<N>(A, jb, tid, f, t, st[tid].hh, st[tid].x);
+                    p1_build<N>(A, jb, tid, f, st[tid].s, st[tid].x);
                     stageA_store<N, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
                 }
                 if (FftGeom<N>::HAS_B) {
                     for (int tid = 0; tid < NT; tid++) load_slots<N>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
                     for (int tid = 0; tid < NT; tid++)
-                        stageB_store<N, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, A.W);
+                        stageB_store<N, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, A.tw.TB);
                 }
                 for (int tid = 0; tid < NT; tid++) p1_finish<N>(A, jb, step, tid, f, st[tid].x, lds.data());
             }
@@ -94,17 +104,19 @@ int evaluate_n(const OceanConsts& C, const cf* h0, const cf* h0c, const float* t
     constexpr int R2 = (N >= 4096) ? 2 : 4;
     Tables tb(N);
     std::vector<f4> PQt((size_t)N * N), d_i0(N), d_j0(N);
+    std::vector<float> Om((size_t)N * N);
     for (int i = 0; i < N; i++)
-        for (int j = 0; j < N; j++) prep_element(N, i, j, h0, h0c, PQt.data(), d_i0.data(), d_j0.data());
-    std::vector<cf> E((size_t)nsteps * 3 * N * N);
+        for (int j = 0; j < N; j++)
+            prep_element(N, C.length, C.gravity, i, j, h0, h0c, tb.Wpre.data(), PQt.data(), d_i0.data(), d_j0.data(), Om.data());
+    std::vector<cf> E((size_t)nsteps * 3 * N * N), Cj0((size_t)nsteps * 3 * N);
     P1Args A1;
-    A1.PQt = PQt.data(); A1.dPQ_i0 = d_i0.data(); A1.dPQ_j0 = d_j0.data(); A1.W = tb.W.data(); A1.Wpre = tb.Wpre.data();
+    A1.PQt = PQt.data(); A1.dPQ_i0 = d_i0.data(); A1.dPQ_j0 = d_j0.data(); A1.Om = Om.data(); A1.tw = tb.tw(); A1.Cj0 = Cj0.data();
     A1.E = E.data(); A1.c = C;
     StepTimes tm;
     for (int k = 0; k < nsteps; k++) tm.t[k] = times[k];
     run_pass1<N>(A1, tm, nsteps);
     P2Args A2;
-    A2.E = E.data(); A2.W = tb.W.data(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
+    A2.E = E.data(); A2.Cj0 = Cj0.data(); A2.tw = tb.tw(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
     A2.white_stride = white_stride; A2.c = C;
     run_pass2<N, R2>(A2, nsteps);
     return 0;
@@ -150,9 +162,9 @@ int emul_fft1d(int N, int sgn, const float* in_xy, float* out_xy) {
         for (int u = 0; u < T; u++) stageA_store<NN, +1>(st[u].x, u, lds.data());                    \
         if (FftGeom<NN>::HAS_B) {                                                                    \
             for (int u = 0; u < T; u++) load_slots<NN>(st[u].x, u, lds.data());                      \
-            for (int u = 0; u < T; u++) stageB_store<NN, +1>(st[u].x, u, lds.data(), tb.W.data());   \
+            for (int u = 0; u < T; u++) stageB_store<NN, +1>(st[u].x, u, lds.data(), tb.TB.data());   \
         }                                                                                            \
-        for (int u = 0; u < T; u++) { load_slots<NN>(st[u].x, u, lds.data()); final_stage<NN, +1>(st[u].x, u, tb.W.data()); } \
+        for (int u = 0; u < T; u++) { load_slots<NN>(st[u].x, u, lds.data()); final_stage<NN, +1>(st[u].x, u, tb.TF.data()); } \
         for (int u = 0; u < T; u++)                                                                  \
             for (int q = 0; q < 16; q++) { out_xy[2 * (u + T * q)] = st[u].x[q].x; out_xy[2 * (u + T * q) + 1] = st[u].x[q].y; } \
         return 0;                                                                                    \
