@@ -18,10 +18,10 @@
 #include "gerstner_kernels.h"
 
 #ifndef MW_WAVES_P1
-#define MW_WAVES_P1 4
+#define MW_WAVES_P1 2
 #endif
 #ifndef MW_WAVES_P2
-#define MW_WAVES_P2 3
+#define MW_WAVES_P2 2
 #endif
 
 using namespace mw;
@@ -606,6 +606,28 @@ mw_status mw_debug_omega_t(mw_ocean* o, float t, float* out_host) {
     hipError_t e = hipStreamSynchronize(o->stream);
     hipFree(d);
     return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, "mw_debug_omega_t failed");
+}
+
+// test hooks: the stored omega table and the device sincos
+__global__ void k_dbg_sincos(const float* x, int n, float* sn, float* cs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sincos_f32(x[i], &sn[i], &cs[i]);
+}
+mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host) {
+    float *dx = nullptr, *ds = nullptr, *dc = nullptr;
+    if (hipMalloc((void**)&dx, 4 * n) != hipSuccess || hipMalloc((void**)&ds, 4 * n) != hipSuccess ||
+        hipMalloc((void**)&dc, 4 * n) != hipSuccess) return fail(MW_ENOMEM, "hipMalloc");
+    hipMemcpy(dx, x_host, 4 * n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_dbg_sincos, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, ds, dc);
+    hipMemcpy(s_host, ds, 4 * n, hipMemcpyDeviceToHost);
+    hipMemcpy(c_host, dc, 4 * n, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(ds); hipFree(dc);
+    return MW_OK;
+}
+mw_status mw_debug_get_omega(mw_ocean* o, float* out_host) {  // [j][i] layout
+    if (!o || !o->Om) return fail(MW_EINVAL, "no omega table");
+    HIP_TRY(hipMemcpy(out_host, o->Om, sizeof(float) * o->N * o->N, hipMemcpyDeviceToHost));
+    return MW_OK;
 }
 
 // ---- pond -------------------------------------------------------------------------------------

@@ -37,20 +37,35 @@ MW_HD cf mul_si(cf a) {  // a * (SGN * i)
 }
 
 // ---- strict IEEE float32 (no FMA contraction): the "index-like" scalars ------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-MW_HD float smul(float a, float b) { return __fmul_rn(a, b); }
-MW_HD float sadd(float a, float b) { return __fadd_rn(a, b); }
-MW_HD float ssub(float a, float b) { return __fsub_rn(a, b); }
-MW_HD float sdiv(float a, float b) { return __fdiv_rn(a, b); }
-MW_HD float ssqrt(float a) { return __fsqrt_rn(a); }
-#else
-// host build of this header must use -ffp-contract=off
-MW_HD float smul(float a, float b) { return a * b; }
-MW_HD float sadd(float a, float b) { return a + b; }
-MW_HD float ssub(float a, float b) { return a - b; }
-MW_HD float sdiv(float a, float b) { return a / b; }
-MW_HD float ssqrt(float a) { return sqrtf(a); }
+// Device: `#pragma clang fp contract(off)` strips the contract flag from these instructions so they can
+// never fuse after inlining (HIP's __fmul_rn/__fadd_rn are plain a*b / a+b and DO fuse; __fsqrt_rn is the
+// approximate v_sqrt_f32).  `/` and sqrtf are correctly rounded under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt.  Host: compiled with -ffp-contract=off.
+MW_HD float smul(float a, float b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
 #endif
+    return a * b;
+}
+MW_HD float sadd(float a, float b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    return a + b;
+}
+MW_HD float ssub(float a, float b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    return a - b;
+}
+MW_HD float sdiv(float a, float b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    return a / b;
+}
+MW_HD float ssqrt(float a) { return sqrtf(a); }
 
 // ---- sin/cos of a float32 phase, |x| <~ 1e5 rad ---------------------------------------------------
 // The reference forms cos/sin of the FLOAT omega*t through double libm (Mathf.Cos, S/FFTMesh.cs:184-185).

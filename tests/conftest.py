@@ -5,6 +5,12 @@ import sys
 
 import pytest
 
+try:  # PyTorch bundles its own HIP runtime: when it shares a process with libmistral_water.so it has to
+    import torch  # initialise first (INTEGRATION.md "PyTorch in the same process")
+    torch.cuda.is_available()
+except Exception:  # torch is optional for everything except the device-pointer tests
+    torch = None
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "mistral-water_amd"))
@@ -34,6 +40,11 @@ def emul():
 @pytest.fixture(scope="session")
 def mw():
     """The product: ctypes binding of libmistral_water.so (HIP only)."""
+    try:  # when PyTorch shares the process it must initialise ITS bundled HIP runtime first (INTEGRATION.md)
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
     import mistral_water
     mistral_water.lib()
     return mistral_water

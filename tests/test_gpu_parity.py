@@ -70,15 +70,18 @@ def test_fftmesh_large_grids(mw, oracle, N):
     workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"N={N}")
 
 
-def test_omega_t_bit_exact_on_device(mw, oracle):
-    # the quantised dispersion floor() and the omega*t product are "index work": bit for bit (S/FFTMesh.cs:146,183)
-    for N, t in [(64, 1.0), (256, 16.65), (1024, 7.3)]:
+def test_omega_t_bit_exact_on_device(mw, oracle, emul):
+    # the quantised dispersion floor() and the omega*t product are "index work": bit for bit over the WHOLE grid
+    # (S/FFTMesh.cs:146,183).  emul.omega_t is the same strict-f32 code on the host; spot rows pin it to the oracle.
+    for N, t in [(64, 1.0), (256, 16.65), (1024, 7.3), (4096, 2.5)]:
         p = workloads.fftmesh_params(N)
         with make(mw, p) as o:
             got = o.debug_omega_t(t)
-        w = np.array([[oracle.dispersion(p, i, j) for j in range(N)] for i in range(0, N, max(1, N // 64))], np.float32)
-        want = w * np.float32(t)
-        assert (got[::max(1, N // 64)] == want).all()
+        want = emul.omega_t(p, t)
+        assert (got == want).all(), f"N={N}: {(got != want).sum()} of {N * N} omega*t values differ"
+        for i in (0, 1, N // 2, N - 1):
+            row = np.array([oracle.dispersion(p, i, j) for j in range(N)], np.float32) * np.float32(t)
+            assert (want[i] == row).all()
 
 
 def test_rest_mesh_bit_exact_on_device(mw, oracle):
