@@ -143,35 +143,43 @@ MW_HD void prep_element(int N, float length, float gravity, int i, int j, const 
 }
 
 // =============================== pass 1: transform along i ===================================
-// grid (N/4 + 1, nsteps); block 4*T threads.  Block jb < N/4 owns spectrum columns j = 4 jb .. 4 jb + 3.
-// The extra block jb == N/4 is the *Nyquist-column job*: it transforms the correction column
-// cz(i,0) * D'(i,0) through the very same code path and writes it to Cj0, which
-// pass 2 adds to element j = 0 of every row.  The i = 0 correction is one element per column: thread
-// u == 0 carries it in `dl0` (zero for every other thread, so no branch).
+// grid (N/4 + 1, nsteps); block 4*T threads (T = N/P).  Block jb < N/4 owns spectrum columns
+// j = 4 jb .. 4 jb + 3.  The extra block jb == N/4 is the *Nyquist-column job*: it transforms the
+// correction column cz(i,0) * D'(i,0) through the very same code path and writes it
+// to Cj0, which pass 2 adds to element j = 0 of every row.  The i = 0 correction is one element per
+// column: thread u == 0 carries it in `dl0` (zero for every other thread, so no branch).
+#ifndef MW_DBUF
+#define MW_DBUF 0  // ping-pong exchange sets: measured no gain at 2x the LDS
+#endif
 struct P1Args {
     const f4* PQt;     // [j][i] (P,Q) * pre
     const f4* dPQ_i0;  // [j]    (dP,dQ) * pre on the row i = 0
     const f4* dPQ_j0;  // [i]    (dP,dQ) * pre on the column j = 0
     const float* Om;   // omega(i,j) at [j][i]
-    Twiddles tw;
+    const cf* TW;      // concatenated twiddle tables (TwGeom)
     cf* E;             // exchange buffer [step][3][N/4][N][4]
     cf* Cj0;           // [step][3][N]  transform of the j = 0 correction column
     OceanConsts c;
 };
 
-template <int N>
+template <int N, int P>
 struct P1Geom {
-    static constexpr int T = FftGeom<N>::T;
+    static constexpr int T = FftGeom<N, P>::T;
     static constexpr int NTHREADS = 4 * T;
-    static constexpr int BUFSTRIDE = FftGeom<N>::LBUF + 4;
-    static constexpr int LDS_BYTES = 4 * BUFSTRIDE * (int)sizeof(cf);
+    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4;
+    static constexpr int TW_LDS = TwGeom<N, P>::IN_LDS ? ((TwGeom<N, P>::TOTAL + 1) & ~1) : 0;  // cf units, 16-B aligned
+    static constexpr int SETSTRIDE = 4 * BUFSTRIDE;
+    // 2: ping-pong exchange buffers, one barrier per exchange (when both sets fit a 100 KiB budget)
+    static constexpr int NBUF = (MW_DBUF && (TW_LDS + 2 * SETSTRIDE) * 8 <= 100 * 1024) ? 2 : 1;
+    static constexpr int LDS_BYTES = (TW_LDS + NBUF * SETSTRIDE) * (int)sizeof(cf);
     static constexpr int GRID_X = N / 4 + 1;
+    static_assert(NTHREADS <= 1024, "workgroup too large: use P = 16 for this N");
 };
 
-template <int N>
+template <int P>
 struct P1State {
-    cf hh[16];  // Hh(k,t)*pre for a regular column; D'(i,0) for the Nyquist-column job
-    cf dl0;     // D'(0,j) in thread u == 0 of a regular column, else 0
+    cf hh[P];  // Hh(k,t)*pre for a regular column; D'(i,0) for the Nyquist-column job
+    cf dl0;    // D'(0,j) in thread u == 0 of a regular column, else 0
 };
 
 // multipliers of the packed fields: Z_f = (cx + cz) * Hh   (cx acts on the kx-odd part, cz on kz-odd)
@@ -195,10 +203,10 @@ MW_HD void field_coeffs(int f, float kx, float kz, cf* cx, cf* cz) {
     }
 }
 
-// animated packed spectrum, 16 points per thread (column job w, i = u + T q)
-template <int N>
-MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, P1State<N>& st) {
-    constexpr int T = FftGeom<N>::T;
+// animated packed spectrum, P points per thread (column job w, i = u + T q)
+template <int N, int P>
+MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, P1State<P>& st) {
+    constexpr int T = FftGeom<N, P>::T;
     const int w = tid / T, u = tid % T;
     const bool fix = (jb == N / 4);
     const int j = fix ? 0 : 4 * jb + w;
@@ -206,7 +214,7 @@ MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, P1State<N>& st)
     const float* __restrict__ omrow = A.Om + (size_t)j * N + u;
     const bool live = !fix || w == 0;
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
+    for (int q = 0; q < P; q++) {
         f4 pq = pqrow[T * q];
         float s, c;
         mw_sincos(smul(omrow[T * q], t), &s, &c);  // omega*t: one f32 multiply, S/FFTMesh.cs:183
@@ -222,22 +230,22 @@ MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, P1State<N>& st)
     }
 }
 
-template <int N>
-MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, const P1State<N>& st, cf (&x)[16]) {
-    constexpr int T = FftGeom<N>::T;
+template <int N, int P>
+MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, const P1State<P>& st, cf (&x)[P]) {
+    constexpr int T = FftGeom<N, P>::T;
     const int w = tid / T, u = tid % T;
     const bool fix = (jb == N / 4);
     const int j = fix ? 0 : 4 * jb + w;
     if (f == 0) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) x[q] = st.hh[q];
+        for (int q = 0; q < P; q++) x[q] = st.hh[q];
         return;
     }
     const float kscale = 2.0f * MW_PI_F / A.c.length;
     const float kz = wave_k_fast(N, kscale, j);
     const float fx = fix ? 0.f : 1.f;  // the Nyquist-column job keeps only the cz part
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
+    for (int q = 0; q < P; q++) {
         cf cx, cz;
         field_coeffs(f, wave_k_fast(N, kscale, u + T * q), kz, &cx, &cz);
         x[q] = cmul(cscale(cx, fx) + cz, st.hh[q]);
@@ -246,23 +254,23 @@ MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, const P1State<N>& s
 }
 
 // final pass in the column-interleaved mapping + coalesced store of the exchange buffer
-template <int N>
-MW_HD void p1_finish(const P1Args& A, int jb, int step, int tid, int f, cf (&x)[16], const cf* lds) {
-    constexpr int T = FftGeom<N>::T;
+template <int N, int P>
+MW_HD void p1_finish(const P1Args& A, const Twiddles& tw, int jb, int step, int tid, int f, cf (&x)[P], const cf* lds) {
+    constexpr int T = FftGeom<N, P>::T;
     const int w2 = tid & 3, u2 = tid >> 2;
-    load_slots<N>(x, u2, lds + w2 * P1Geom<N>::BUFSTRIDE);
-    final_stage<N, +1>(x, u2, A.tw.TF);
+    load_slots<N, P>(x, u2, lds + w2 * P1Geom<N, P>::BUFSTRIDE);
+    final_stage<N, P, +1>(x, u2, tw.TF);
     if (jb == N / 4) {
         if (w2 == 0) {
             cf* C = A.Cj0 + ((size_t)step * 3 + f) * N;
 #pragma unroll
-            for (int q = 0; q < 16; q++) C[u2 + T * q] = x[q];
+            for (int q = 0; q < P; q++) C[u2 + T * q] = x[q];
         }
         return;
     }
     cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)jb * N * 4;
 #pragma unroll
-    for (int q = 0; q < 16; q++) Ef[(size_t)(u2 + T * q) * 4 + w2] = x[q];
+    for (int q = 0; q < P; q++) Ef[(size_t)(u2 + T * q) * 4 + w2] = x[q];
 }
 
 // =============================== pass 2: transform along j + epilogue ========================
@@ -271,7 +279,7 @@ MW_HD void p1_finish(const P1Args& A, int jb, int step, int tid, int f, cf (&x)[
 struct P2Args {
     const cf* E;
     const cf* Cj0;    // [step][3][N]
-    Twiddles tw;
+    const cf* TW;     // concatenated twiddle tables (TwGeom)
     float* vertices;  // [step][N*N*3]
     float* normals;   // [step][N*N*3]
     float* white;     // [step][N*N*white_stride]
@@ -279,77 +287,86 @@ struct P2Args {
     OceanConsts c;
 };
 
-template <int N, int R2>
+template <int N, int P, int R2>
 struct P2Geom {
-    static constexpr int T = FftGeom<N>::T;
+    static constexpr int T = FftGeom<N, P>::T;
     static constexpr int NTHREADS = (R2 + 1) * T;
-    static constexpr int BUFSTRIDE = FftGeom<N>::LBUF + 4;
-    static constexpr int LDS_BYTES = (R2 + 1) * BUFSTRIDE * (int)sizeof(cf);
+    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4;
+    static constexpr int TW_LDS = TwGeom<N, P>::IN_LDS ? ((TwGeom<N, P>::TOTAL + 1) & ~1) : 0;
+    static constexpr int SETSTRIDE = (R2 + 1) * BUFSTRIDE;
+    static constexpr int NBUF = (MW_DBUF && (TW_LDS + 2 * SETSTRIDE) * 8 <= 100 * 1024) ? 2 : 1;
+    static constexpr int LDS_BYTES = (TW_LDS + NBUF * SETSTRIDE) * (int)sizeof(cf);
+    static_assert(NTHREADS <= 1024, "workgroup too large");
 };
 
-template <int N>
+template <int P>
 struct P2State {
-    float noise[16];  // |0.3 n.xz| per slot (S/FFTMesh.cs:269-270)
-    float h[16];      // height
-    cf d[16];         // hds = (d.x, d.z), un-scaled by choppiness (S/FFTMesh.cs:247)
+    float noise[P];  // |0.3 n.xz| per slot (S/FFTMesh.cs:269-270)
+    float h[P];      // height
+    cf d[P];         // hds = (d.x, d.z), un-scaled by choppiness (S/FFTMesh.cs:247)
 };
 
 // field processing order in pass 2: slopes, height, displacement (displacement last: its LDS buffers
 // are then recycled as the hds neighbour exchange)
 MW_HD int p2_field(int k) { return k == 0 ? 2 : (k == 1 ? 0 : 1); }
 
-template <int N, int R2>
+template <int N, int P, int R2>
 MW_HD bool p2_active(int ab, int tid, int f) {
-    constexpr int T = FftGeom<N>::T;
+    constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T;
     return g < R2 || (f == 1 && ab * R2 + R2 < N);
 }
 
-// stage-A load in the row-interleaved mapping: 16 consecutive lanes read one full 128-B line
-template <int N, int R2>
-MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[16], cf* lds) {
-    constexpr int T = FftGeom<N>::T;
+// (row slot, thread-in-row) of the load-side mapping: rows interleaved in consecutive lanes so that
+// 4*R2 consecutive lanes read one contiguous R2*32-byte piece of the exchange buffer
+template <int N, int P, int R2>
+MW_HD void p2_load_map(int tid, int* r1, int* u1) {
+    constexpr int T = FftGeom<N, P>::T;
+    if (tid < R2 * T) { *r1 = tid % R2; *u1 = tid / R2; }
+    else { *r1 = R2; *u1 = tid - R2 * T; }
+}
+
+template <int N, int P, int R2>
+MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P], cf* lds) {
+    constexpr int T = FftGeom<N, P>::T;
     int r1, u1;
-    if (tid < R2 * T) { r1 = tid % R2; u1 = tid / R2; }
-    else { r1 = R2; u1 = tid - R2 * T; }
+    p2_load_map<N, P, R2>(tid, &r1, &u1);
     const cf* Ef = A.E + ((size_t)step * 3 + f) * N * N;
     const int row = ab * R2 + r1;
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
+    for (int q = 0; q < P; q++) {
         const int j = u1 + T * q;
         x[q] = Ef[((size_t)(j >> 2) * N + row) * 4 + (j & 3)];
     }
     if (u1 == 0 && f != 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];  // Nyquist column j = 0
-    stageA_store<N, +1>(x, u1, lds + r1 * P2Geom<N, R2>::BUFSTRIDE);
+    stage0_store<N, P, +1>(x, u1, lds + r1 * P2Geom<N, P, R2>::BUFSTRIDE);
 }
-template <int N, int R2>
-MW_HD void p2_mid_load(int tid, cf (&x)[16], const cf* lds) {
-    constexpr int T = FftGeom<N>::T;
+// middle passes keep the load-side (row-interleaved) mapping: measured fewer LDS bank conflicts than row-major
+template <int N, int P, int R2>
+MW_HD void p2_mid_load(int tid, cf (&x)[P], const cf* lds) {
     int r1, u1;
-    if (tid < R2 * T) { r1 = tid % R2; u1 = tid / R2; }
-    else { r1 = R2; u1 = tid - R2 * T; }
-    load_slots<N>(x, u1, lds + r1 * P2Geom<N, R2>::BUFSTRIDE);
+    p2_load_map<N, P, R2>(tid, &r1, &u1);
+    load_slots<N, P>(x, u1, lds + r1 * P2Geom<N, P, R2>::BUFSTRIDE);
 }
-template <int N, int R2>
-MW_HD void p2_mid_store(const P2Args& A, int tid, cf (&x)[16], cf* lds) {
-    constexpr int T = FftGeom<N>::T;
+template <int N, int P, int R2>
+MW_HD void p2_mid_store(const Twiddles& tw, int tid, int s, cf (&x)[P], cf* lds) {
     int r1, u1;
-    if (tid < R2 * T) { r1 = tid % R2; u1 = tid / R2; }
-    else { r1 = R2; u1 = tid - R2 * T; }
-    stageB_store<N, +1>(x, u1, lds + r1 * P2Geom<N, R2>::BUFSTRIDE, A.tw.TB);
+    p2_load_map<N, P, R2>(tid, &r1, &u1);
+    stage_store<N, P, +1>(x, u1, lds + r1 * P2Geom<N, P, R2>::BUFSTRIDE, tw, s);
 }
 
 // final pass in the row-major mapping (thread (g,u) owns row a0+g, columns b = u + T q)
-template <int N, int R2>
-MW_HD void p2_finish(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[16], P2State<N>& st, const cf* lds) {
-    constexpr int T = FftGeom<N>::T;
+template <int N, int P, int R2>
+MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int tid, int f, cf (&x)[P], P2State<P>& st,
+                     const cf* lds) {
+    constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
-    load_slots<N>(x, u, lds + g * P2Geom<N, R2>::BUFSTRIDE);
-    final_stage<N, +1>(x, u, A.tw.TF);
+    load_slots<N, P>(x, u, lds + g * P2Geom<N, P, R2>::BUFSTRIDE);
+    final_stage<N, P, +1>(x, u, tw.TF);
     if (f == 2) {  // slopes -> unit normal (S/FFTMesh.cs:218), stored at once
         float* nout = A.normals + ((size_t)step * N * N + (size_t)a * N) * 3;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
+        for (int q = 0; q < P; q++) {
             const int b = u + T * q;
             const float sg = post_sign(a, b);
             const float sx = sg * x[q].x, sz = sg * x[q].y;
@@ -364,10 +381,10 @@ MW_HD void p2_finish(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[
         }
     } else if (f == 0) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) st.h[q] = post_sign(a, u + T * q) * x[q].x;
+        for (int q = 0; q < P; q++) st.h[q] = post_sign(a, u + T * q) * x[q].x;
     } else {
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
+        for (int q = 0; q < P; q++) {
             const float sg = post_sign(a, u + T * q);
             st.d[q] = mk(sg * x[q].x, sg * x[q].y);
         }
@@ -375,28 +392,28 @@ MW_HD void p2_finish(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[
 }
 
 // hds rows into LDS (plain index b) so that neighbours (a+1,b) and (a,b+1) can be read back
-template <int N, int R2>
-MW_HD void p2_publish_hds(int tid, const P2State<N>& st, cf* lds) {
-    constexpr int T = FftGeom<N>::T;
+template <int N, int P, int R2>
+MW_HD void p2_publish_hds(int tid, const P2State<P>& st, cf* lds) {
+    constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T;
-    cf* row = lds + g * P2Geom<N, R2>::BUFSTRIDE;
+    cf* row = lds + g * P2Geom<N, P, R2>::BUFSTRIDE;
 #pragma unroll
-    for (int q = 0; q < 16; q++) row[u + T * q] = st.d[q];
+    for (int q = 0; q < P; q++) row[u + T * q] = st.d[q];
 }
 
 // S/FFTMesh.cs:243-247 (vertex), :251-276 (Jacobian / whitecap)
-template <int N, int R2>
-MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State<N>& st, const cf* lds) {
-    constexpr int T = FftGeom<N>::T;
+template <int N, int P, int R2>
+MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State<P>& st, const cf* lds) {
+    constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
-    const cf* row = lds + g * P2Geom<N, R2>::BUFSTRIDE;
-    const cf* nxt = lds + (g + 1) * P2Geom<N, R2>::BUFSTRIDE;
+    const cf* row = lds + g * P2Geom<N, P, R2>::BUFSTRIDE;
+    const cf* nxt = lds + (g + 1) * P2Geom<N, P, R2>::BUFSTRIDE;
     float* vout = A.vertices + ((size_t)step * N * N + (size_t)a * N) * 3;
     float* wout = A.white + ((size_t)step * N * N + (size_t)a * N) * A.white_stride;
     const float rx = rest_coord(N, A.c.unit_width, a);
     const bool has_i = (a != N - 1);
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
+    for (int q = 0; q < P; q++) {
         const int b = u + T * q;
         const bool has_j = (b != N - 1);
         const cf d = st.d[q];
@@ -405,7 +422,6 @@ MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State
         vout[3 * b + 0] = ssub(rx, smul(d.x, A.c.choppiness));                             // :245
         vout[3 * b + 1] = st.h[q];                                                         // :243
         vout[3 * b + 2] = ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness));  // :244
-        // whitecap() wants |n.x|,|n.z| only through the noise magnitude, which p2_finish already formed
         float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
         if (has_i) { ax = smul(0.5f, ssub(d.x, dn_i.x)); ay = smul(0.5f, ssub(d.y, dn_i.y)); }  // :260-263
         if (has_j) { bx = smul(0.5f, ssub(d.x, dn_j.x)); by = smul(0.5f, ssub(d.y, dn_j.y)); }  // :264-267
@@ -419,5 +435,14 @@ MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State
         }
     }
 }
+
+// points per thread / rows per pass-2 block for a given N (MW_PT overrides P for experiments)
+#ifndef MW_PT
+#define MW_PT 8
+#endif
+template <int N> struct Plan {
+    static constexpr int P = (N >= 2048) ? 16 : MW_PT;  // 5 x N/8 threads would exceed 1024 at N = 2048
+    static constexpr int R2 = (N >= 4096) ? 2 : 4;
+};
 
 }  // namespace mw

@@ -18,10 +18,10 @@
 #include "gerstner_kernels.h"
 
 #ifndef MW_WAVES_P1
-#define MW_WAVES_P1 2
+#define MW_WAVES_P1 6  // min waves per SIMD the register allocator must leave room for (measured best)
 #endif
 #ifndef MW_WAVES_P2
-#define MW_WAVES_P2 2
+#define MW_WAVES_P2 6
 #endif
 
 using namespace mw;
@@ -71,63 +71,139 @@ __global__ void k_omega_t(int N, float length, float gravity, float t, float* ou
     out[idx] = omega_t_f32(N, length, gravity, idx / N, idx % N, t);
 }
 
-template <int N>
-__global__ __launch_bounds__(P1Geom<N>::NTHREADS) __attribute__((amdgpu_waves_per_eu(MW_WAVES_P1, MW_WAVES_P1))) void k_pass1(P1Args A, StepTimes times) {
+#ifdef MW_TIMING
+__device__ long long g_stamps[2][64][8][32];  // [kernel][block slot][wave][stamp]
+#define MW_STAMP(K, id)                                                                               \
+    do {                                                                                              \
+        if ((blockIdx.x % 37) == 5 && blockIdx.x / 37 < 64 && blockIdx.y == 3 && (threadIdx.x & 63) == 0) \
+            g_stamps[K][blockIdx.x / 37][threadIdx.x >> 6][id] = __builtin_readcyclecounter();        \
+    } while (0)
+#elif defined(MW_SCHED_FENCE)
+#define MW_STAMP(K, id) __builtin_amdgcn_sched_barrier(0)
+#else
+#define MW_STAMP(K, id) do { } while (0)
+#endif
+
+// LDS layout of both pass kernels: [twiddle tables, if small] [NBUF sets of exchange buffers].  With
+// NBUF == 2 the sets are used ping-pong (every store goes to the set the previous load did NOT read), so
+// one barrier per exchange suffices; with NBUF == 1 a second (WAR) barrier follows every load.
+template <int TOTAL, int NT>
+__device__ __forceinline__ void stage_tables(cf* dst, const cf* __restrict__ src, int tid) {
+    for (int i = tid; i < TOTAL; i += NT) dst[i] = src[i];
+}
+
+template <int N, int P>
+__global__ __launch_bounds__((P1Geom<N, P>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(P == 8 ? MW_WAVES_P1 : 4))) void k_pass1(
+    P1Args A, StepTimes times) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = P1Geom<N, P>;
     cf* lds = reinterpret_cast<cf*>(smem);
-    constexpr int T = FftGeom<N>::T;
-    constexpr int BS = P1Geom<N>::BUFSTRIDE;
+    constexpr int T = FftGeom<N, P>::T;
     const int tid = threadIdx.x, jb = blockIdx.x, step = blockIdx.y;
     const float t = times.t[step];
     const int w = tid / T, u = tid % T;
-    P1State<N> st;
-    cf x[16];
-    p1_animate<N>(A, jb, tid, t, st);
+    if (TwGeom<N, P>::IN_LDS) stage_tables<TwGeom<N, P>::TOTAL, G::NTHREADS>(lds, A.TW, tid);  // visible after the first barrier
+    const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
+    cf* set0 = lds + G::TW_LDS;
+    int cur = 0;  // set the next store goes to
+    P1State<P> st;
+    cf x[P];
+    MW_STAMP(0, 0);
+    p1_animate<N, P>(A, jb, tid, t, st);
+    MW_STAMP(0, 1);
 #pragma unroll
     for (int f = 0; f < 3; f++) {
         if (f == 0 && jb == N / 4) continue;  // the Nyquist-column job has no height term (block-uniform)
-        p1_build<N>(A, jb, tid, f, st, x);
-        if (f) __syncthreads();
-        stageA_store<N, +1>(x, u, lds + w * BS);
+        p1_build<N, P>(A, jb, tid, f, st, x);
+        if (G::NBUF == 1 && f) __syncthreads();
+        MW_STAMP(0, 2 + 8 * f);
+#ifdef MW_ABLATE_FFT
+        {
+            cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)(jb % (N / 4)) * N * 4;
+#pragma unroll
+            for (int q = 0; q < P; q++) Ef[(size_t)((tid >> 2) + T * q) * 4 + (tid & 3)] = x[q];
+            continue;
+        }
+#endif
+        stage0_store<N, P, +1>(x, u, set0 + cur * G::SETSTRIDE + w * G::BUFSTRIDE);
+        MW_STAMP(0, 3 + 8 * f);
         __syncthreads();
-        if (FftGeom<N>::HAS_B) {
-            load_slots<N>(x, u, lds + w * BS);
-            __syncthreads();
-            stageB_store<N, +1>(x, u, lds + w * BS, A.tw.TB);
+#pragma unroll
+        for (int s = 1; s < FftGeom<N, P>::S; s++) {
+            load_slots<N, P>(x, u, set0 + cur * G::SETSTRIDE + w * G::BUFSTRIDE);
+            if (G::NBUF == 1) __syncthreads(); else cur ^= 1;
+            stage_store<N, P, +1>(x, u, set0 + cur * G::SETSTRIDE + w * G::BUFSTRIDE, tw, s);
             __syncthreads();
         }
-        p1_finish<N>(A, jb, step, tid, f, x, lds);
+        MW_STAMP(0, 7 + 8 * f);
+        p1_finish<N, P>(A, tw, jb, step, tid, f, x, set0 + cur * G::SETSTRIDE);
+        if (G::NBUF == 2) cur ^= 1;
+        MW_STAMP(0, 8 + 8 * f);
     }
+    MW_STAMP(0, 26);
 }
 
-template <int N, int R2>
-__global__ __launch_bounds__((P2Geom<N, R2>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(MW_WAVES_P2, MW_WAVES_P2))) void k_pass2(P2Args A) {
+template <int N, int P, int R2>
+__global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(P == 8 ? MW_WAVES_P2 : 3))) void k_pass2(
+    P2Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = P2Geom<N, P, R2>;
     cf* lds = reinterpret_cast<cf*>(smem);
-    constexpr int T = FftGeom<N>::T;
+    constexpr int T = FftGeom<N, P>::T;
     const int tid = threadIdx.x, ab = blockIdx.x, step = blockIdx.y;
     const int g = tid / T;
-    P2State<N> st;
-    cf x[16];
+    if (TwGeom<N, P>::IN_LDS) stage_tables<TwGeom<N, P>::TOTAL, G::NTHREADS>(lds, A.TW, tid);
+    const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
+    cf* set0 = lds + G::TW_LDS;
+    int cur = 0;
+    P2State<P> st;
+    cf x[P];
+    MW_STAMP(1, 0);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int f = p2_field(k);
-        const bool active = p2_active<N, R2>(ab, tid, f);
-        if (k) __syncthreads();
-        if (active) p2_load<N, R2>(A, ab, step, tid, f, x, lds);
+        const bool active = p2_active<N, P, R2>(ab, tid, f);
+        if (G::NBUF == 1 && k) __syncthreads();
+        MW_STAMP(1, 1 + 8 * k);
+        if (active) p2_load<N, P, R2>(A, ab, step, tid, f, x, set0 + cur * G::SETSTRIDE);
+        MW_STAMP(1, 2 + 8 * k);
+#ifdef MW_ABLATE_FFT
+        if (active) {  // no exchanges: treat the loaded values as the transformed row (memory-pattern floor)
+            const int a = ab * R2 + g, u = tid % T;
+            if (f == 2) {
+                float* nout = A.normals + ((size_t)step * N * N + (size_t)a * N) * 3;
+#pragma unroll
+                for (int q = 0; q < P; q++) { const int b = u + T * q; nout[3 * b] = x[q].x; nout[3 * b + 1] = x[q].y; nout[3 * b + 2] = x[q].x; st.noise[q] = x[q].y; }
+            } else if (f == 0) {
+#pragma unroll
+                for (int q = 0; q < P; q++) st.h[q] = x[q].x;
+            } else {
+#pragma unroll
+                for (int q = 0; q < P; q++) st.d[q] = x[q];
+            }
+        }
+        continue;
+#endif
         __syncthreads();
-        if (FftGeom<N>::HAS_B) {
-            if (active) p2_mid_load<N, R2>(tid, x, lds);
-            __syncthreads();
-            if (active) p2_mid_store<N, R2>(A, tid, x, lds);
+#pragma unroll
+        for (int s = 1; s < FftGeom<N, P>::S; s++) {
+            if (active) p2_mid_load<N, P, R2>(tid, x, set0 + cur * G::SETSTRIDE);
+            if (G::NBUF == 1) __syncthreads(); else cur ^= 1;
+            if (active) p2_mid_store<N, P, R2>(tw, tid, s, x, set0 + cur * G::SETSTRIDE);
             __syncthreads();
         }
-        if (active) p2_finish<N, R2>(A, ab, step, tid, f, x, st, lds);
+        MW_STAMP(1, 6 + 8 * k);
+        if (active) p2_finish<N, P, R2>(A, tw, ab, step, tid, f, x, st, set0 + cur * G::SETSTRIDE);
+        if (G::NBUF == 2) cur ^= 1;
+        MW_STAMP(1, 7 + 8 * k);
     }
+    if (G::NBUF == 1) __syncthreads();
+    MW_STAMP(1, 25);
+    if (p2_active<N, P, R2>(ab, tid, 1)) p2_publish_hds<N, P, R2>(tid, st, set0 + cur * G::SETSTRIDE);
     __syncthreads();
-    if (p2_active<N, R2>(ab, tid, 1)) p2_publish_hds<N, R2>(tid, st, lds);
-    __syncthreads();
-    if (g < R2) p2_epilogue<N, R2>(A, ab, step, tid, st, lds);
+    MW_STAMP(1, 26);
+    if (g < R2) p2_epilogue<N, P, R2>(A, ab, step, tid, st, set0 + cur * G::SETSTRIDE);
+    MW_STAMP(1, 27);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -146,7 +222,7 @@ struct mw_ocean {
     cf *h0 = nullptr, *h0c = nullptr;
     f4 *PQt = nullptr, *dPQ_i0 = nullptr, *dPQ_j0 = nullptr;
     float* Om = nullptr;
-    cf *TB = nullptr, *TF = nullptr, *Wpre = nullptr;
+    cf *TW = nullptr, *Wpre = nullptr;
     cf *E = nullptr, *Cj0 = nullptr;
     int e_cap = 0;  // steps the exchange buffer holds
     float *s_vert = nullptr, *s_norm = nullptr, *s_white = nullptr;  // 1-step scratch for the host API
@@ -163,31 +239,48 @@ static mw_status dmalloc(T** p, size_t count) {
     return MW_OK;
 }
 
+// host-side geometry mirror of FftGeom<N,P> / Plan<N>
+static int plan_points(int N) { return N >= 2048 ? 16 : MW_PT; }
+
+// concatenated twiddle table [TS1 | TS2 | TS3 | TF] in the layout of TwGeom<N,P>
+static std::vector<cf> build_twiddle_table(int N, int P) {
+    const int T = N / P;
+    int S = 0;
+    long long PS = 1;
+    while (PS * P <= N) { PS *= P; S++; }
+    const int RL = (int)(N / PS);
+    std::vector<cf> tab;
+    for (int s = 1; s < S; s++) {
+        long long p = 1;
+        for (int i = 0; i < s; i++) p *= P;
+        for (long long k = 0; k < p; k++)
+            for (int r = 0; r < P; r++) {
+                double a = 2.0 * M_PI * (double)(r * k) / (double)(p * P);
+                tab.push_back(mk((float)cos(a), (float)sin(a)));
+            }
+    }
+    if (RL > 1)
+        for (int u = 0; u < T; u++)
+            for (int r = 0; r < RL; r++) {
+                double a = 2.0 * M_PI * (double)(r * u) / (double)N;
+                tab.push_back(mk((float)cos(a), (float)sin(a)));
+            }
+    if (tab.empty()) tab.push_back(mk(1.f, 0.f));
+    return tab;
+}
+
 static mw_status upload_twiddles(mw_ocean* o) {
-    const int N = o->N;
-    const int T = N / 16, PD = (N >= 256) ? 256 : 16, RL = N / PD;
-    std::vector<cf> TB(256), TF((size_t)T * RL), Wpre(2 * N);
-    for (int k = 0; k < 16; k++)
-        for (int r = 0; r < 16; r++) {
-            double a = 2.0 * M_PI * (double)(r * k) / 256.0;
-            TB[k * 16 + r] = mk((float)cos(a), (float)sin(a));
-        }
-    for (int u = 0; u < T; u++)
-        for (int r = 0; r < RL; r++) {
-            double a = 2.0 * M_PI * (double)(r * u) / (double)N;
-            TF[(size_t)u * RL + r] = mk((float)cos(a), (float)sin(a));
-        }
+    const int N = o->N, P = plan_points(N);
+    std::vector<cf> tab = build_twiddle_table(N, P), Wpre(2 * N);
     for (int m = 0; m < 2 * N; m++) {
         double a = M_PI * (double)m / (double)N;  // (-1)^m e^{i pi m/N}
         double sg = (m & 1) ? -1.0 : 1.0;
         Wpre[m] = mk((float)(sg * cos(a)), (float)(sg * sin(a)));
     }
-    mw_status s;
-    if ((s = dmalloc(&o->TB, 256)) != MW_OK) return s;
-    if ((s = dmalloc(&o->TF, (size_t)T * RL)) != MW_OK) return s;
-    if ((s = dmalloc(&o->Wpre, 2 * N)) != MW_OK) return s;
-    HIP_TRY(hipMemcpy(o->TB, TB.data(), sizeof(cf) * 256, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(o->TF, TF.data(), sizeof(cf) * T * RL, hipMemcpyHostToDevice));
+    mw_status st;
+    if ((st = dmalloc(&o->TW, tab.size())) != MW_OK) return st;
+    if ((st = dmalloc(&o->Wpre, 2 * N)) != MW_OK) return st;
+    HIP_TRY(hipMemcpy(o->TW, tab.data(), sizeof(cf) * tab.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(o->Wpre, Wpre.data(), sizeof(cf) * 2 * N, hipMemcpyHostToDevice));
     return MW_OK;
 }
@@ -204,32 +297,31 @@ static OceanConsts consts_of(const mw_ocean* o) {
 
 // ---- kernel dispatch over N ----------------------------------------------------------------------
 template <int N>
-static constexpr int rows_per_block() { return N >= 4096 ? 2 : 4; }
-
-template <int N>
 static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nsteps, hipStream_t st) {
+    constexpr int P = Plan<N>::P;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<N>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, P1Geom<N>::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<N, P>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, P1Geom<N, P>::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_pass1<N>, dim3(P1Geom<N>::GRID_X, nsteps), dim3(P1Geom<N>::NTHREADS), P1Geom<N>::LDS_BYTES, st, A, tm);
+    constexpr int NT = P1Geom<N, P>::NTHREADS, LB = P1Geom<N, P>::LDS_BYTES, GX = P1Geom<N, P>::GRID_X;
+    k_pass1<N, P><<<dim3(GX, nsteps), dim3(NT), LB, st>>>(A, tm);
     return hipGetLastError();
 }
 template <int N>
 static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
-    constexpr int R2 = rows_per_block<N>();
+    constexpr int P = Plan<N>::P, R2 = Plan<N>::R2;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<N, R2>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, P2Geom<N, R2>::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<N, P, R2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, P2Geom<N, P, R2>::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    constexpr int NT = P2Geom<N, R2>::NTHREADS, LB = P2Geom<N, R2>::LDS_BYTES;
-    k_pass2<N, R2><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
+    constexpr int NT = P2Geom<N, P, R2>::NTHREADS, LB = P2Geom<N, P, R2>::LDS_BYTES;
+    k_pass2<N, P, R2><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
     return hipGetLastError();
 }
 
@@ -247,8 +339,7 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
 
 static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps) {
     P1Args A;
-    A.PQt = o->PQt; A.dPQ_i0 = o->dPQ_i0; A.dPQ_j0 = o->dPQ_j0; A.Om = o->Om; A.tw.TB = o->TB; A.tw.TF = o->TF;
-    A.E = o->E; A.Cj0 = o->Cj0;
+    A.PQt = o->PQt; A.dPQ_i0 = o->dPQ_i0; A.dPQ_j0 = o->dPQ_j0; A.Om = o->Om; A.TW = o->TW; A.E = o->E; A.Cj0 = o->Cj0;
     A.c = consts_of(o);
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass1_n<NN>(A, tm, nsteps, o->stream));
@@ -257,7 +348,7 @@ static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps) {
 }
 static mw_status launch_pass2(mw_ocean* o, int nsteps, float* dv, float* dn, float* dw, int white_stride) {
     P2Args A;
-    A.E = o->E; A.Cj0 = o->Cj0; A.tw.TB = o->TB; A.tw.TF = o->TF; A.vertices = dv; A.normals = dn; A.white = dw; A.white_stride = white_stride;
+    A.E = o->E; A.Cj0 = o->Cj0; A.TW = o->TW; A.vertices = dv; A.normals = dn; A.white = dw; A.white_stride = white_stride;
     A.c = consts_of(o);
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass2_n<NN>(A, nsteps, o->stream));
@@ -325,7 +416,7 @@ void mw_ocean_destroy(mw_ocean* o) {
     hipSetDevice(o->device);
     if (o->stream) hipStreamSynchronize(o->stream);
     hipFree(o->h0); hipFree(o->h0c); hipFree(o->PQt); hipFree(o->Om); hipFree(o->dPQ_i0); hipFree(o->dPQ_j0);
-    hipFree(o->TB); hipFree(o->TF); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white);
+    hipFree(o->TW); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white);
     direct_free(o->direct);
     or_free(o->orr);
     if (o->own_stream) hipStreamDestroy(o->own_stream);
@@ -629,6 +720,13 @@ mw_status mw_debug_get_omega(mw_ocean* o, float* out_host) {  // [j][i] layout
     HIP_TRY(hipMemcpy(out_host, o->Om, sizeof(float) * o->N * o->N, hipMemcpyDeviceToHost));
     return MW_OK;
 }
+
+#ifdef MW_TIMING
+mw_status mw_debug_get_stamps(long long* out_host) {
+    HIP_TRY(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(long long) * 2 * 64 * 8 * 32));
+    return MW_OK;
+}
+#endif
 
 // ---- pond -------------------------------------------------------------------------------------
 mw_status mw_gerstner_displace_device(const void* d_pos_xyz, int64_t nverts, const float* waves, int32_t nwaves,

@@ -236,56 +236,115 @@ MW_HD void dft16(cf (&x)[16]) {
     for (int k = 0; k < 16; k++) x[k] = y[k];
 }
 
-// ---- Stockham autosort passes, 16 points per thread ------------------------------------------
-// An N-point transform is carried by T = N/16 threads; thread u keeps element u + T*q in slot q
-// before AND after the whole transform.  Passes: radix 16 (p=1) [, radix 16 (p=16)] [, radix RL].
-// Between passes the data goes through an LDS buffer of N + N/16 complex (one pad per 16).
-template <int N>
-struct FftGeom {
-    static constexpr int T = N / 16;
-    static constexpr bool HAS_B = (N >= 256);
-    static constexpr int P_DONE = HAS_B ? 256 : 16;
-    static constexpr int RL = N / P_DONE;  // radix of the final pass (1 = none)
-    static constexpr int NB = 16 / RL;     // butterflies per thread in the final pass
-    static constexpr int LBUF = N + N / 16;
-    static_assert(N >= 16 && (N & (N - 1)) == 0 && N <= 4096, "N must be a power of two in [16,4096]");
-};
-MW_HD int lds_pad(int idx) { return idx + (idx >> 4); }
+// ---- Stockham autosort passes, P points per thread (P = 8 or 16) -------------------------------
+// An N-point transform is carried by T = N/P threads; thread u keeps element u + T*q in slot q before
+// AND after the whole transform.  Passes: S radix-P passes (p = 1, P, P^2, ...) and, when P^S < N, a
+// final radix-RL pass (RL = N / P^S < P) done as P/RL butterflies per thread.  Between passes the data
+// goes through an LDS buffer of N + N/P complex (one pad per P elements: conflict-free b64 accesses).
+//   P = 8  : half the registers per thread, twice the threads (used for N <= 2048)
+//   P = 16 : one exchange fewer (used for N = 4096, where 4 columns x N/8 threads would exceed 1024)
+template <int P> struct LogP;
+template <> struct LogP<8> { static constexpr int v = 3; };
+template <> struct LogP<16> { static constexpr int v = 4; };
 
-template <int N, int SGN>
-MW_HD void stageA_store(cf (&x)[16], int u, cf* buf) {
-    dft16<SGN>(x);
-#pragma unroll
-    for (int r = 0; r < 16; r++) buf[lds_pad(16 * u + r)] = x[r];
-}
-template <int N>
-MW_HD void load_slots(cf (&x)[16], int u, const cf* buf) {
-#pragma unroll
-    for (int q = 0; q < 16; q++) x[q] = buf[lds_pad(u + FftGeom<N>::T * q)];
-}
+constexpr int mw_full_stages(int N, int P) { int s = 0; long long m = 1; while (m * P <= N) { m *= P; s++; } return s; }
+constexpr int mw_ipow(int P, int s) { int m = 1; for (int i = 0; i < s; i++) m *= P; return m; }
+
+template <int N, int P>
+struct FftGeom {
+    static constexpr int T = N / P;
+    static constexpr int LOGP = LogP<P>::v;
+    static constexpr int S = mw_full_stages(N, P);  // number of radix-P passes
+    static constexpr int PS = mw_ipow(P, S);
+    static constexpr int RL = N / PS;               // radix of the final pass (1 = none)
+    static constexpr int NB = P / RL;               // butterflies per thread in the final pass
+    static constexpr int LBUF = N + N / P;
+    static_assert(N >= 64 && (N & (N - 1)) == 0 && N <= 4096, "N must be a power of two in [64,4096]");
+    static_assert(S >= 1 && RL >= 1 && RL < P, "bad geometry");
+};
+template <int P>
+MW_HD int lds_pad(int idx) { return idx + (idx >> LogP<P>::v); }
+
+template <int P, int SGN> struct DftP;
+template <int SGN> struct DftP<8, SGN> {
+    static MW_HD void run(cf (&x)[8]) { dft8<SGN>(x); }
+    static MW_HD cf rot(cf a, int m) { return tw8<SGN>(a, m); }
+};
+template <int SGN> struct DftP<16, SGN> {
+    static MW_HD void run(cf (&x)[16]) { dft16<SGN>(x); }
+    static MW_HD cf rot(cf a, int m) { return tw16<SGN>(a, m); }
+};
+
 // Twiddle tables (built on the host in double, rounded once to f32; SGN baked in):
-//   TB[k*16 + r] = e^{SGN 2 pi i r k/256}          k,r < 16     (second radix-16 pass, p = 16)
-//   TF[u*RL + r] = e^{SGN 2 pi i r u/N}            u < T, r < RL (final pass; the remaining factor
-//                  e^{SGN 2 pi i r m/16} of thread u's m-th butterfly is a compile-time rotation)
-// Both are read as one contiguous run per thread (vector loads, one address register).
+//   TS[s][k*P + r] = e^{SGN 2 pi i r k / P^(s+1)}   k < P^s, r < P   (radix-P pass s >= 1, p = P^s)
+//   TF[u*RL + r]   = e^{SGN 2 pi i r u / N}         u < T,  r < RL   (final pass; the remaining factor
+//                    e^{SGN 2 pi i r m / P} of thread u's m-th butterfly is a compile-time rotation)
+// Each thread reads one contiguous run per pass (vector loads, one address register).
 struct Twiddles {
-    const cf* TB;
+    const cf* TS[4];
     const cf* TF;
 };
-template <int N, int SGN>
-MW_HD void stageB_store(cf (&x)[16], int u, cf* buf, const cf* __restrict__ TB) {
-    const int k = u & 15;
-    const cf* __restrict__ row = TB + k * 16;
+// one concatenated table [TS1 | TS2 | TS3 | TF] (device global memory; copied to LDS when it is small)
+template <int N, int P>
+struct TwGeom {
+    static constexpr int S = FftGeom<N, P>::S;
+    static constexpr int size_ts(int s) { return (s >= 1 && s < S) ? mw_ipow(P, s + 1) : 0; }
+    static constexpr int OFF1 = 0;
+    static constexpr int OFF2 = OFF1 + size_ts(1);
+    static constexpr int OFF3 = OFF2 + size_ts(2);
+    static constexpr int OFFF = OFF3 + size_ts(3);
+    static constexpr int SIZE_TF = (FftGeom<N, P>::RL > 1) ? FftGeom<N, P>::T * FftGeom<N, P>::RL : 0;
+    static constexpr int TOTAL = OFFF + SIZE_TF;
+    static constexpr bool IN_LDS = (TOTAL * 8 <= 8192);  // <= 8 KiB: staged in LDS, off the global-latency path
+    static MW_HD Twiddles view(const cf* base) {
+        Twiddles t;
+        t.TS[0] = nullptr;
+        t.TS[1] = base + OFF1;
+        t.TS[2] = base + OFF2;
+        t.TS[3] = base + OFF3;
+        t.TF = base + OFFF;
+        return t;
+    }
+};
+
+// LDS indices are written as (per-thread base) + (compile-time constant) so that every ds_read / ds_write
+// carries its offset in the instruction's immediate field and costs no address VALU.
+template <int N, int P, int SGN>
+MW_HD void stage0_store(cf (&x)[P], int u, cf* buf) {
+    DftP<P, SGN>::run(x);
+    cf* __restrict__ b = buf + (P + 1) * u;  // lds_pad(P*u + r) = (P+1)*u + r for r < P
 #pragma unroll
-    for (int r = 1; r < 16; r++) x[r] = cmul(x[r], row[r]);
-    dft16<SGN>(x);
-    const int j = ((u - k) << 4) + k;
-#pragma unroll
-    for (int r = 0; r < 16; r++) buf[lds_pad(j + 16 * r)] = x[r];
+    for (int r = 0; r < P; r++) b[r] = x[r];
 }
-template <int N, int SGN>
-MW_HD void final_stage(cf (&x)[16], int u, const cf* __restrict__ TF) {
-    constexpr int RL = FftGeom<N>::RL, NB = FftGeom<N>::NB;
+template <int N, int P>
+MW_HD void load_slots(cf (&x)[P], int u, const cf* buf) {
+    constexpr int T = FftGeom<N, P>::T;
+    if (T % P == 0) {  // lds_pad(u + T*q) = lds_pad(u) + T*q + T*q/P
+        const cf* __restrict__ b = buf + lds_pad<P>(u);
+#pragma unroll
+        for (int q = 0; q < P; q++) x[q] = b[T * q + (T * q) / P];
+    } else {
+#pragma unroll
+        for (int q = 0; q < P; q++) x[q] = buf[lds_pad<P>(u + T * q)];
+    }
+}
+// radix-P pass s (1 <= s < S): p = P^s
+template <int N, int P, int SGN>
+MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
+    const int p = 1 << (LogP<P>::v * s);
+    const int k = u & (p - 1);
+    const cf* __restrict__ row = tw.TS[s] + k * P;
+#pragma unroll
+    for (int r = 1; r < P; r++) x[r] = cmul(x[r], row[r]);
+    DftP<P, SGN>::run(x);
+    const int j = ((u - k) << LogP<P>::v) + k;
+    cf* __restrict__ b = buf + lds_pad<P>(j);  // p is a multiple of P: lds_pad(j + p*r) = lds_pad(j) + p*r + p*r/P
+#pragma unroll
+    for (int r = 0; r < P; r++) b[p * r + ((p * r) >> LogP<P>::v)] = x[r];
+}
+template <int N, int P, int SGN>
+MW_HD void final_stage(cf (&x)[P], int u, const cf* __restrict__ TF) {
+    constexpr int RL = FftGeom<N, P>::RL, NB = FftGeom<N, P>::NB;
     if (RL == 1) return;
     cf tw[RL];
 #pragma unroll
@@ -293,20 +352,18 @@ MW_HD void final_stage(cf (&x)[16], int u, const cf* __restrict__ TF) {
 #pragma unroll
     for (int m = 0; m < NB; m++) {
 #pragma unroll
-        for (int r = 1; r < RL; r++) x[m + r * NB] = tw16<SGN>(cmul(x[m + r * NB], tw[r]), (r * m) & 15);
+        for (int r = 1; r < RL; r++) x[m + r * NB] = DftP<P, SGN>::rot(cmul(x[m + r * NB], tw[r]), (r * m) & (P - 1));
         if (RL == 2) {
             dft2<SGN>(x[m], x[m + NB]);
         } else if (RL == 4) {
             dft4<SGN>(x[m], x[m + NB], x[m + 2 * NB], x[m + 3 * NB]);
-        } else if (RL == 8) {
+        } else {  // RL == 8 (only with P == 16)
             cf y[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) y[r] = x[(m + r * NB) & 15];
+            for (int r = 0; r < 8; r++) y[r] = x[(m + r * NB) & (P - 1)];
             dft8<SGN>(y);
 #pragma unroll
-            for (int r = 0; r < 8; r++) x[(m + r * NB) & 15] = y[r];
-        } else {  // 16
-            dft16<SGN>(x);
+            for (int r = 0; r < 8; r++) x[(m + r * NB) & (P - 1)] = y[r];
         }
     }
 }

@@ -20,89 +20,101 @@ using namespace mw;
 
 namespace {
 
+// concatenated twiddle table in the layout of TwGeom<N,P> (mirrors build_twiddle_table in mistral_water.hip)
 struct Tables {
-    std::vector<cf> TB, TF, Wpre;
-    explicit Tables(int N) : TB(256), Wpre(2 * N) {
-        const int T = N / 16, PD = (N >= 256) ? 256 : 16, RL = N / PD;
-        TF.resize((size_t)T * RL);
-        for (int k = 0; k < 16; k++)
-            for (int r = 0; r < 16; r++) {
-                double a = 2.0 * M_PI * (double)(r * k) / 256.0;
-                TB[k * 16 + r] = mk((float)cos(a), (float)sin(a));
-            }
-        for (int u = 0; u < T; u++)
-            for (int r = 0; r < RL; r++) {
-                double a = 2.0 * M_PI * (double)(r * u) / (double)N;
-                TF[(size_t)u * RL + r] = mk((float)cos(a), (float)sin(a));
-            }
+    std::vector<cf> TW, Wpre;
+    Tables(int N, int P) : Wpre(2 * N) {
+        const int T = N / P;
+        int S = 0;
+        long long PS = 1;
+        while (PS * P <= N) { PS *= P; S++; }
+        const int RL = (int)(N / PS);
+        for (int s = 1; s < S; s++) {
+            long long p = 1;
+            for (int i = 0; i < s; i++) p *= P;
+            for (long long k = 0; k < p; k++)
+                for (int r = 0; r < P; r++) {
+                    double a = 2.0 * M_PI * (double)(r * k) / (double)(p * P);
+                    TW.push_back(mk((float)cos(a), (float)sin(a)));
+                }
+        }
+        if (RL > 1)
+            for (int u = 0; u < T; u++)
+                for (int r = 0; r < RL; r++) {
+                    double a = 2.0 * M_PI * (double)(r * u) / (double)N;
+                    TW.push_back(mk((float)cos(a), (float)sin(a)));
+                }
+        if (TW.empty()) TW.push_back(mk(1.f, 0.f));
         for (int m = 0; m < 2 * N; m++) {
             double a = M_PI * (double)m / (double)N;
             double sg = (m & 1) ? -1.0 : 1.0;
             Wpre[m] = mk((float)(sg * cos(a)), (float)(sg * sin(a)));
         }
     }
-    Twiddles tw() const { Twiddles t; t.TB = TB.data(); t.TF = TF.data(); return t; }
 };
 
-template <int N>
+template <int N, int P>
 void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
-    constexpr int T = FftGeom<N>::T, NT = P1Geom<N>::NTHREADS, BS = P1Geom<N>::BUFSTRIDE;
+    constexpr int T = FftGeom<N, P>::T, NT = P1Geom<N, P>::NTHREADS, BS = P1Geom<N, P>::BUFSTRIDE;
     std::vector<cf> lds(4 * BS);
-    struct St { P1State<N> s; cf x[16]; };
+    const Twiddles tw = TwGeom<N, P>::view(A.TW);
+    struct St { P1State<P> s; cf x[P]; };
     std::vector<St> st(NT);
     for (int step = 0; step < nsteps; step++)
-        for (int jb = 0; jb < P1Geom<N>::GRID_X; jb++) {
+        for (int jb = 0; jb < P1Geom<N, P>::GRID_X; jb++) {
             const float t = tm.t[step];
-            for (int tid = 0; tid < NT; tid++) p1_animate<N>(A, jb, tid, t, st[tid].s);
+            for (int tid = 0; tid < NT; tid++) p1_animate<N, P>(A, jb, tid, t, st[tid].s);
             for (int f = 0; f < 3; f++) {
                 if (f == 0 && jb == N / 4) continue;
                 for (int tid = 0; tid < NT; tid++) {
-                    p1_build<N>(A, jb, tid, f, st[tid].s, st[tid].x);
-                    stageA_store<N, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
+                    p1_build<N, P>(A, jb, tid, f, st[tid].s, st[tid].x);
+                    stage0_store<N, P, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
                 }
-                if (FftGeom<N>::HAS_B) {
-                    for (int tid = 0; tid < NT; tid++) load_slots<N>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
+                for (int s = 1; s < FftGeom<N, P>::S; s++) {
+                    for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
                     for (int tid = 0; tid < NT; tid++)
-                        stageB_store<N, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, A.tw.TB);
+                        stage_store<N, P, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, tw, s);
                 }
-                for (int tid = 0; tid < NT; tid++) p1_finish<N>(A, jb, step, tid, f, st[tid].x, lds.data());
+                for (int tid = 0; tid < NT; tid++) p1_finish<N, P>(A, tw, jb, step, tid, f, st[tid].x, lds.data());
             }
         }
 }
 
-template <int N, int R2>
+template <int N, int P, int R2>
 void run_pass2(const P2Args& A, int nsteps) {
-    constexpr int T = FftGeom<N>::T, NT = P2Geom<N, R2>::NTHREADS, BS = P2Geom<N, R2>::BUFSTRIDE;
+    constexpr int T = FftGeom<N, P>::T, NT = P2Geom<N, P, R2>::NTHREADS, BS = P2Geom<N, P, R2>::BUFSTRIDE;
     std::vector<cf> lds((R2 + 1) * BS);
-    struct St { P2State<N> s; cf x[16]; };
+    const Twiddles tw = TwGeom<N, P>::view(A.TW);
+    struct St { P2State<P> s; cf x[P]; };
     std::vector<St> st(NT);
     for (int step = 0; step < nsteps; step++)
         for (int ab = 0; ab < N / R2; ab++) {
             for (int k = 0; k < 3; k++) {
                 const int f = p2_field(k);
                 for (int tid = 0; tid < NT; tid++)
-                    if (p2_active<N, R2>(ab, tid, f)) p2_load<N, R2>(A, ab, step, tid, f, st[tid].x, lds.data());
-                if (FftGeom<N>::HAS_B) {
+                    if (p2_active<N, P, R2>(ab, tid, f)) p2_load<N, P, R2>(A, ab, step, tid, f, st[tid].x, lds.data());
+                for (int s = 1; s < FftGeom<N, P>::S; s++) {
                     for (int tid = 0; tid < NT; tid++)
-                        if (p2_active<N, R2>(ab, tid, f)) p2_mid_load<N, R2>(tid, st[tid].x, lds.data());
+                        if (p2_active<N, P, R2>(ab, tid, f)) p2_mid_load<N, P, R2>(tid, st[tid].x, lds.data());
                     for (int tid = 0; tid < NT; tid++)
-                        if (p2_active<N, R2>(ab, tid, f)) p2_mid_store<N, R2>(A, tid, st[tid].x, lds.data());
+                        if (p2_active<N, P, R2>(ab, tid, f)) p2_mid_store<N, P, R2>(tw, tid, s, st[tid].x, lds.data());
                 }
                 for (int tid = 0; tid < NT; tid++)
-                    if (p2_active<N, R2>(ab, tid, f)) p2_finish<N, R2>(A, ab, step, tid, f, st[tid].x, st[tid].s, lds.data());
+                    if (p2_active<N, P, R2>(ab, tid, f))
+                        p2_finish<N, P, R2>(A, tw, ab, step, tid, f, st[tid].x, st[tid].s, lds.data());
             }
             for (int tid = 0; tid < NT; tid++)
-                if (p2_active<N, R2>(ab, tid, 1)) p2_publish_hds<N, R2>(tid, st[tid].s, lds.data());
+                if (p2_active<N, P, R2>(ab, tid, 1)) p2_publish_hds<N, P, R2>(tid, st[tid].s, lds.data());
             for (int tid = 0; tid < NT; tid++)
-                if (tid / T < R2) p2_epilogue<N, R2>(A, ab, step, tid, st[tid].s, lds.data());
+                if (tid / T < R2) p2_epilogue<N, P, R2>(A, ab, step, tid, st[tid].s, lds.data());
         }
 }
 
-template <int N>
-int evaluate_n(const OceanConsts& C, const cf* h0, const cf* h0c, const float* times, int nsteps, float* vertices,
-               float* normals, float* white, int white_stride) {
-    constexpr int R2 = (N >= 4096) ? 2 : 4;
-    Tables tb(N);
+template <int N, int P>
+int evaluate_np(const OceanConsts& C, const cf* h0, const cf* h0c, const float* times, int nsteps, float* vertices,
+                float* normals, float* white, int white_stride) {
+    constexpr int R2 = Plan<N>::R2;
+    Tables tb(N, P);
     std::vector<f4> PQt((size_t)N * N), d_i0(N), d_j0(N);
     std::vector<float> Om((size_t)N * N);
     for (int i = 0; i < N; i++)
@@ -110,15 +122,48 @@ int evaluate_n(const OceanConsts& C, const cf* h0, const cf* h0c, const float* t
             prep_element(N, C.length, C.gravity, i, j, h0, h0c, tb.Wpre.data(), PQt.data(), d_i0.data(), d_j0.data(), Om.data());
     std::vector<cf> E((size_t)nsteps * 3 * N * N), Cj0((size_t)nsteps * 3 * N);
     P1Args A1;
-    A1.PQt = PQt.data(); A1.dPQ_i0 = d_i0.data(); A1.dPQ_j0 = d_j0.data(); A1.Om = Om.data(); A1.tw = tb.tw(); A1.Cj0 = Cj0.data();
-    A1.E = E.data(); A1.c = C;
+    A1.PQt = PQt.data(); A1.dPQ_i0 = d_i0.data(); A1.dPQ_j0 = d_j0.data(); A1.Om = Om.data(); A1.TW = tb.TW.data();
+    A1.Cj0 = Cj0.data(); A1.E = E.data(); A1.c = C;
     StepTimes tm;
     for (int k = 0; k < nsteps; k++) tm.t[k] = times[k];
-    run_pass1<N>(A1, tm, nsteps);
+    run_pass1<N, P>(A1, tm, nsteps);
     P2Args A2;
-    A2.E = E.data(); A2.Cj0 = Cj0.data(); A2.tw = tb.tw(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
+    A2.E = E.data(); A2.Cj0 = Cj0.data(); A2.TW = tb.TW.data(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
     A2.white_stride = white_stride; A2.c = C;
-    run_pass2<N, R2>(A2, nsteps);
+    run_pass2<N, P, R2>(A2, nsteps);
+    return 0;
+}
+
+// pts = 0: the product's plan (Plan<N>::P); 8 / 16: force that variant where the geometry allows it
+template <int N>
+int evaluate_n(int pts, const OceanConsts& C, const cf* h0, const cf* h0c, const float* times, int nsteps, float* vertices,
+               float* normals, float* white, int white_stride) {
+    if (pts == 0) pts = Plan<N>::P;
+    if (pts == 16) return evaluate_np<N, 16>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
+    if constexpr (N <= 1024) {
+        if (pts == 8) return evaluate_np<N, 8>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
+    }
+    return 3;
+}
+
+template <int N, int P>
+int fft1d_np(const float* in_xy, float* out_xy) {
+    constexpr int T = FftGeom<N, P>::T;
+    Tables tb(N, P);
+    Twiddles tw = TwGeom<N, P>::view(tb.TW.data());
+    std::vector<cf> lds(FftGeom<N, P>::LBUF + 8);
+    struct S { cf x[P]; };
+    std::vector<S> st(T);
+    for (int u = 0; u < T; u++)
+        for (int q = 0; q < P; q++) st[u].x[q] = mk(in_xy[2 * (u + T * q)], in_xy[2 * (u + T * q) + 1]);
+    for (int u = 0; u < T; u++) stage0_store<N, P, +1>(st[u].x, u, lds.data());
+    for (int s = 1; s < FftGeom<N, P>::S; s++) {
+        for (int u = 0; u < T; u++) load_slots<N, P>(st[u].x, u, lds.data());
+        for (int u = 0; u < T; u++) stage_store<N, P, +1>(st[u].x, u, lds.data(), tw, s);
+    }
+    for (int u = 0; u < T; u++) { load_slots<N, P>(st[u].x, u, lds.data()); final_stage<N, P, +1>(st[u].x, u, tw.TF); }
+    for (int u = 0; u < T; u++)
+        for (int q = 0; q < P; q++) { out_xy[2 * (u + T * q)] = st[u].x[q].x; out_xy[2 * (u + T * q) + 1] = st[u].x[q].y; }
     return 0;
 }
 
@@ -126,8 +171,8 @@ int evaluate_n(const OceanConsts& C, const cf* h0, const cf* h0c, const float* t
 
 extern "C" {
 
-// returns 0 on success, 1 for an unsupported N
-int emul_fftmesh_evaluate(int N, float unit_width, float length, float gravity, float choppiness, const float* h0,
+// returns 0 on success, 1 for an unsupported N, 3 for an unsupported (N, pts) pair
+int emul_fftmesh_evaluate(int N, int pts, float unit_width, float length, float gravity, float choppiness, const float* h0,
                           const float* h0c, const float* times, int nsteps, float* vertices, float* normals, float* white,
                           int white_stride) {
     OceanConsts C;
@@ -136,49 +181,25 @@ int emul_fftmesh_evaluate(int N, float unit_width, float length, float gravity, 
     const cf* b = reinterpret_cast<const cf*>(h0c);
     if (nsteps < 1 || nsteps > MW_MAX_BATCH) return 2;
     switch (N) {
-        case 64: return evaluate_n<64>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
-        case 128: return evaluate_n<128>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
-        case 256: return evaluate_n<256>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
-        case 512: return evaluate_n<512>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
-        case 1024: return evaluate_n<1024>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
-        case 2048: return evaluate_n<2048>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
-        case 4096: return evaluate_n<4096>(C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 64: return evaluate_n<64>(pts, C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 128: return evaluate_n<128>(pts, C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 256: return evaluate_n<256>(pts, C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 512: return evaluate_n<512>(pts, C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 1024: return evaluate_n<1024>(pts, C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 2048: return evaluate_n<2048>(pts, C, a, b, times, nsteps, vertices, normals, white, white_stride);
+        case 4096: return evaluate_n<4096>(pts, C, a, b, times, nsteps, vertices, normals, white, white_stride);
         default: return 1;
     }
 }
 
 // 1-D transform through the Stockham passes exactly as one FFT group of the kernels runs them
-int emul_fft1d(int N, int sgn, const float* in_xy, float* out_xy) {
-    if (sgn != 1) return 2;
-    Tables tb(N);
-#define RUN(NN)                                                                                      \
-    {                                                                                                \
-        constexpr int T = FftGeom<NN>::T;                                                            \
-        std::vector<cf> lds(FftGeom<NN>::LBUF + 8);                                                  \
-        struct S { cf x[16]; };                                                                      \
-        std::vector<S> st(T);                                                                        \
-        for (int u = 0; u < T; u++)                                                                  \
-            for (int q = 0; q < 16; q++) st[u].x[q] = mk(in_xy[2 * (u + T * q)], in_xy[2 * (u + T * q) + 1]); \
-        for (int u = 0; u < T; u++) stageA_store<NN, +1>(st[u].x, u, lds.data());                    \
-        if (FftGeom<NN>::HAS_B) {                                                                    \
-            for (int u = 0; u < T; u++) load_slots<NN>(st[u].x, u, lds.data());                      \
-            for (int u = 0; u < T; u++) stageB_store<NN, +1>(st[u].x, u, lds.data(), tb.TB.data());   \
-        }                                                                                            \
-        for (int u = 0; u < T; u++) { load_slots<NN>(st[u].x, u, lds.data()); final_stage<NN, +1>(st[u].x, u, tb.TF.data()); } \
-        for (int u = 0; u < T; u++)                                                                  \
-            for (int q = 0; q < 16; q++) { out_xy[2 * (u + T * q)] = st[u].x[q].x; out_xy[2 * (u + T * q) + 1] = st[u].x[q].y; } \
-        return 0;                                                                                    \
-    }
+int emul_fft1d(int N, int pts, const float* in_xy, float* out_xy) {
+#define RUN(NN)                                              \
+    case NN:                                                 \
+        if (pts == 8) return fft1d_np<NN, 8>(in_xy, out_xy); \
+        return fft1d_np<NN, 16>(in_xy, out_xy);
     switch (N) {
-        case 16: RUN(16)
-        case 32: RUN(32)
-        case 64: RUN(64)
-        case 128: RUN(128)
-        case 256: RUN(256)
-        case 512: RUN(512)
-        case 1024: RUN(1024)
-        case 2048: RUN(2048)
-        case 4096: RUN(4096)
+        RUN(64) RUN(128) RUN(256) RUN(512) RUN(1024) RUN(2048) RUN(4096)
         default: return 1;
     }
 #undef RUN

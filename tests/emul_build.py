@@ -27,24 +27,24 @@ class Emul:
     def __init__(self):
         self.L = C.CDLL(build())
 
-    def evaluate(self, p, h0, h0c, times, white_stride=4):
+    def evaluate(self, p, h0, h0c, times, white_stride=4, pts=0):
         """p: oracle.Params.  Returns (vertices, normals, white) with a leading step axis."""
         N, ns = p.N, len(times)
         v = np.empty((ns, N * N, 3), np.float32)
         n = np.empty((ns, N * N, 3), np.float32)
         w = np.empty((ns, N * N, white_stride), np.float32)
         tt = np.asarray(times, np.float32)
-        r = self.L.emul_fftmesh_evaluate(N, C.c_float(p.unit_width), C.c_float(p.length), C.c_float(p.gravity),
+        r = self.L.emul_fftmesh_evaluate(N, pts, C.c_float(p.unit_width), C.c_float(p.length), C.c_float(p.gravity),
                                          C.c_float(p.choppiness), _p(np.ascontiguousarray(h0, np.float32)),
                                          _p(np.ascontiguousarray(h0c, np.float32)), _p(tt), ns, _p(v), _p(n), _p(w),
                                          white_stride)
         assert r == 0, f"emul_fftmesh_evaluate -> {r}"
         return v, n, w
 
-    def fft1d(self, x):
+    def fft1d(self, x, pts=16):
         x = np.ascontiguousarray(x, np.float32)
         y = np.empty_like(x)
-        assert self.L.emul_fft1d(x.shape[0], 1, _p(x), _p(y)) == 0
+        assert self.L.emul_fft1d(x.shape[0], pts, _p(x), _p(y)) == 0
         return y
 
     def rest_mesh(self, N, unit_width):
