@@ -14,7 +14,7 @@
 #include "../../include/mistral_water.h"
 #include "fftmesh_kernels.h"
 #include "direct_kernels.h"
-#include "ocean_renderer_kernels.h"
+#include "ocean_renderer_device.h"
 #include "gerstner_kernels.h"
 
 #ifndef MW_WAVES_P1
@@ -243,7 +243,9 @@ static mw_status dmalloc(T** p, size_t count) {
 static int plan_points(int N) { return N >= 2048 ? 16 : MW_PT; }
 
 // concatenated twiddle table [TS1 | TS2 | TS3 | TF] in the layout of TwGeom<N,P>
-static std::vector<cf> build_twiddle_table(int N, int P) {
+namespace mw {
+int plan_points_host(int N) { return N >= 2048 ? 16 : MW_PT; }
+std::vector<cf> build_twiddle_table(int N, int P, int sgn) {
     const int T = N / P;
     int S = 0;
     long long PS = 1;
@@ -255,23 +257,24 @@ static std::vector<cf> build_twiddle_table(int N, int P) {
         for (int i = 0; i < s; i++) p *= P;
         for (long long k = 0; k < p; k++)
             for (int r = 0; r < P; r++) {
-                double a = 2.0 * M_PI * (double)(r * k) / (double)(p * P);
+                double a = sgn * 2.0 * M_PI * (double)(r * k) / (double)(p * P);
                 tab.push_back(mk((float)cos(a), (float)sin(a)));
             }
     }
     if (RL > 1)
         for (int u = 0; u < T; u++)
             for (int r = 0; r < RL; r++) {
-                double a = 2.0 * M_PI * (double)(r * u) / (double)N;
+                double a = sgn * 2.0 * M_PI * (double)(r * u) / (double)N;
                 tab.push_back(mk((float)cos(a), (float)sin(a)));
             }
     if (tab.empty()) tab.push_back(mk(1.f, 0.f));
     return tab;
 }
+}  // namespace mw
 
 static mw_status upload_twiddles(mw_ocean* o) {
     const int N = o->N, P = plan_points(N);
-    std::vector<cf> tab = build_twiddle_table(N, P), Wpre(2 * N);
+    std::vector<cf> tab = build_twiddle_table(N, P, +1), Wpre(2 * N);
     for (int m = 0; m < 2 * N; m++) {
         double a = M_PI * (double)m / (double)N;  // (-1)^m e^{i pi m/N}
         double sg = (m & 1) ? -1.0 : 1.0;

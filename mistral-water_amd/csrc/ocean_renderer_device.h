@@ -1,0 +1,188 @@
+// ocean_renderer_device.h -- __global__ wrappers and host-side state of MW_SEM_OCEANRENDERER (device build only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mistral_water.h"
+#include "ocean_renderer_kernels.h"
+
+namespace mw {
+
+struct OrState {
+    int M = 0;
+    OrConsts c{};
+    float mult = 1.f, choppiness = 0.f;
+    f4* initT = nullptr;
+    float* phaseT = nullptr;
+    cf *TW = nullptr, *E = nullptr;
+    float *out_height = nullptr, *out_disp_g = nullptr, *out_normal = nullptr, *out_white = nullptr;
+    cf* out_disp_cf = nullptr;
+    float* out_disp = nullptr;  // alias of out_disp_cf as floats (r, b)
+};
+static thread_local std::string g_or_err;
+static inline const char* or_last_error() { return g_or_err.c_str(); }
+
+__global__ void k_or_init(int M, float length, float wind_x, float wind_y, float amp, float gravity, uint64_t seed, f4* initT,
+                          float* phaseT) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * M) return;
+    // idx enumerates the transposed array (px major) so the writes coalesce
+    or_init_element(M, length, wind_x, wind_y, amp, gravity, seed, idx / M, idx % M, initT, phaseT);
+}
+
+template <int N, int P>
+__global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = OrP1Geom<N, P>;
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = FftGeom<N, P>::T;
+    const int tid = threadIdx.x, jb = blockIdx.x;
+    const int w = tid / T, u = tid % T;
+    if (TwGeom<N, P>::IN_LDS)
+        for (int i = tid; i < TwGeom<N, P>::TOTAL; i += G::NTHREADS) lds[i] = A.TW[i];
+    const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
+    cf* set0 = lds + G::TW_LDS;
+    cf h[P], x[P];
+    or_p1_animate<N, P>(A, jb, tid, h);
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+        or_p1_build<N, P>(A, jb, tid, f, h, x);
+        if (f) __syncthreads();
+        stage0_store<N, P, -1>(x, u, set0 + w * G::BUFSTRIDE);
+        __syncthreads();
+#pragma unroll
+        for (int s = 1; s < FftGeom<N, P>::S; s++) {
+            load_slots<N, P>(x, u, set0 + w * G::BUFSTRIDE);
+            __syncthreads();
+            stage_store<N, P, -1>(x, u, set0 + w * G::BUFSTRIDE, tw, s);
+            __syncthreads();
+        }
+        or_p1_finish<N, P>(A, tw, jb, tid, f, x, set0);
+    }
+}
+
+template <int N, int P>
+__global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = OrP2Geom<N, P>;
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = FftGeom<N, P>::T;
+    const int tid = threadIdx.x, ab = blockIdx.x;
+    if (TwGeom<N, P>::IN_LDS)
+        for (int i = tid; i < TwGeom<N, P>::TOTAL; i += G::NTHREADS) lds[i] = A.TW[i];
+    const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
+    cf* set0 = lds + G::TW_LDS;
+    cf x[P];
+    float dx[P];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int f = or_p2_field(k);
+        if (k) __syncthreads();
+        or_p2_load<N, P>(A, ab, tid, f, x, set0);
+        __syncthreads();
+#pragma unroll
+        for (int s = 1; s < FftGeom<N, P>::S; s++) {
+            load_slots<N, P>(x, tid >> 2, set0 + (tid & 3) * G::BUFSTRIDE);
+            __syncthreads();
+            stage_store<N, P, -1>(x, tid >> 2, set0 + (tid & 3) * G::BUFSTRIDE, tw, s);
+            __syncthreads();
+        }
+        or_p2_finish<N, P>(A, tw, ab, tid, f, x, dx, set0);
+    }
+}
+
+__global__ void k_or_normal(OrConsts c, const float* height, const cf* disp, const float* disp_g, float* normal) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= c.M * c.M) return;
+    or_normal_element(c, idx % c.M, idx / c.M, height, disp, disp_g, normal);
+}
+__global__ void k_or_white(OrConsts c, const cf* disp, const float* normal, float* white) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= c.M * c.M) return;
+    or_white_element(c, idx % c.M, idx / c.M, disp, normal, white);
+}
+
+std::vector<cf> build_twiddle_table(int N, int P, int sgn);  // mistral_water.hip
+int plan_points_host(int N);
+
+static inline void or_free(OrState& s) {
+    hipFree(s.initT); hipFree(s.phaseT); hipFree(s.TW); hipFree(s.E); hipFree(s.out_height); hipFree(s.out_disp_cf);
+    hipFree(s.out_disp_g); hipFree(s.out_normal); hipFree(s.out_white);
+    s = OrState();
+}
+
+static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStream_t st) {
+    s.M = M;
+    s.c.M = M; s.c.length = p.length; s.c.gravity = p.gravity; s.c.choppiness = p.choppiness;
+    s.mult = p.mult; s.choppiness = p.choppiness;
+    const size_t MM = (size_t)M * M;
+    std::vector<cf> tab = build_twiddle_table(M, plan_points_host(M), -1);
+#define OR_ALLOC(ptr, bytes) if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { g_or_err = "OceanRenderer: hipMalloc failed"; return MW_ENOMEM; }
+    OR_ALLOC(s.initT, sizeof(f4) * MM) OR_ALLOC(s.phaseT, sizeof(float) * MM) OR_ALLOC(s.TW, sizeof(cf) * tab.size())
+    OR_ALLOC(s.E, sizeof(cf) * 3 * MM) OR_ALLOC(s.out_height, sizeof(float) * MM) OR_ALLOC(s.out_disp_cf, sizeof(cf) * MM)
+    OR_ALLOC(s.out_disp_g, sizeof(float) * MM) OR_ALLOC(s.out_normal, sizeof(float) * 3 * MM) OR_ALLOC(s.out_white, sizeof(float) * MM)
+#undef OR_ALLOC
+    s.out_disp = reinterpret_cast<float*>(s.out_disp_cf);
+    if (hipMemcpy(s.TW, tab.data(), sizeof(cf) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { g_or_err = "twiddle upload failed"; return MW_EDEVICE; }
+    k_or_init<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(M, p.length, p.wind_x, p.wind_y, p.amplitude / 10000.f,
+                                                                       p.gravity, p.seed, s.initT, s.phaseT);
+    if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_init launch failed"; return MW_EDEVICE; }
+    return MW_OK;
+}
+
+template <int N>
+static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
+    constexpr int P = Plan<N>::P;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_or_pass1<N, P>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, OrP1Geom<N, P>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_or_pass2<N, P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                OrP2Geom<N, P>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    OrP1Args A1;
+    A1.initT = s.initT; A1.phaseT = s.phaseT; A1.TW = s.TW; A1.E = s.E; A1.c = s.c; A1.dt = dt;
+    constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
+    k_or_pass1<N, P><<<dim3(N / 4), dim3(NT1), LB1, st>>>(A1);
+    OrP2Args A2;
+    A2.E = s.E; A2.TW = s.TW; A2.height = s.out_height; A2.disp = s.out_disp_cf; A2.disp_g = s.out_disp_g; A2.c = s.c;
+    constexpr int NT2 = OrP2Geom<N, P>::NTHREADS, LB2 = OrP2Geom<N, P>::LDS_BYTES;
+    k_or_pass2<N, P><<<dim3(N / 4), dim3(NT2), LB2, st>>>(A2);
+    return hipGetLastError();
+}
+
+// one GenerateTexture(): results land in s.out_*; optional device destinations receive copies
+static inline mw_status or_generate(OrState& s, float delta_time, float* d_height, float* d_disp, float* d_normal, float* d_white,
+                                    hipStream_t st) {
+    s.c.choppiness = s.choppiness;
+    const float dt = delta_time * s.mult;  // S/OceanRenderer.cs:223
+    hipError_t e = hipSuccess;
+    switch (s.M) {
+        case 64: e = or_launch_passes<64>(s, dt, st); break;
+        case 128: e = or_launch_passes<128>(s, dt, st); break;
+        case 256: e = or_launch_passes<256>(s, dt, st); break;
+        case 512: e = or_launch_passes<512>(s, dt, st); break;
+        case 1024: e = or_launch_passes<1024>(s, dt, st); break;
+        case 2048: e = or_launch_passes<2048>(s, dt, st); break;
+        case 4096: e = or_launch_passes<4096>(s, dt, st); break;
+        default: g_or_err = "OceanRenderer: unsupported texture size"; return MW_EINVAL;
+    }
+    if (e != hipSuccess) { g_or_err = std::string("OceanRenderer pass launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
+    const size_t MM = (size_t)s.M * s.M;
+    const unsigned nb = (unsigned)((MM + 255) / 256);
+    k_or_normal<<<dim3(nb), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal);
+    k_or_white<<<dim3(nb), dim3(256), 0, st>>>(s.c, s.out_disp_cf, s.out_normal, s.out_white);
+    if (hipGetLastError() != hipSuccess) { g_or_err = "OceanRenderer normal/white launch failed"; return MW_EDEVICE; }
+    if (d_height) hipMemcpyAsync(d_height, s.out_height, MM * 4, hipMemcpyDeviceToDevice, st);
+    if (d_disp) hipMemcpyAsync(d_disp, s.out_disp_cf, MM * 8, hipMemcpyDeviceToDevice, st);
+    if (d_normal) hipMemcpyAsync(d_normal, s.out_normal, MM * 12, hipMemcpyDeviceToDevice, st);
+    if (d_white) hipMemcpyAsync(d_white, s.out_white, MM * 4, hipMemcpyDeviceToDevice, st);
+    return MW_OK;
+}
+
+}  // namespace mw

@@ -186,3 +186,64 @@ def whitecap_f32(N: int, hds, normals):
     lib().orc_whitecap_f32(C.c_int32(N), _fp(np.ascontiguousarray(hds, np.float32)),
                            _fp(np.ascontiguousarray(normals, np.float32)), _fp(c))
     return c
+
+
+# ======================================= OceanRenderer semantics ========================================
+class _RP(C.Structure):
+    _fields_ = [("resolution", C.c_int32), ("length", C.c_float), ("wind_x", C.c_float), ("wind_y", C.c_float),
+                ("amplitude", C.c_float), ("choppiness", C.c_float), ("gravity", C.c_float), ("mult", C.c_float)]
+
+
+@dataclass
+class RendererParams:
+    """Inspector fields of S/OceanRenderer.cs:10-19; textures are (8*resolution)^2."""
+    resolution: int
+    length: float = 256.0
+    wind_x: float = 0.0
+    wind_y: float = 0.0
+    amplitude: float = 1.0
+    choppiness: float = 1.5
+    gravity: float = 9.81
+    mult: float = 2.0
+
+    @property
+    def M(self):
+        return 8 * self.resolution
+
+    def c(self):
+        return _RP(self.resolution, self.length, self.wind_x, self.wind_y, self.amplitude, self.choppiness, self.gravity,
+                   self.mult)
+
+
+def renderer_initial_spectrum(p: RendererParams, seed: int):
+    """F/InitialSpectrum.shader -> [M, M, 4] = (h0.xy, conj(h0').xy), texel (px,py) at [py, px]."""
+    init4 = np.empty((p.M, p.M, 4), np.float32)
+    lib().orr_initial_spectrum(C.byref(p.c()), C.c_uint64(seed), _fp(init4))
+    return init4
+
+
+def renderer_step_f64(p: RendererParams, init4, phase, delta_time: float, literal_passes: bool = True):
+    """One OceanRenderer.GenerateTexture().  `phase` ([M,M] float32) is advanced in place.
+    literal_passes=True runs the 2*log2(M) Stockham gather passes exactly as S/OceanRenderer.cs schedules them;
+    False swaps in numpy's fft2 (validated equal in tests) for large M."""
+    M = p.M
+    init4 = np.ascontiguousarray(init4, np.float32)
+    assert phase.dtype == np.float32 and phase.flags.c_contiguous
+    h = np.empty((M, M), np.float64)
+    d = np.empty((M, M, 2), np.float64)
+    n = np.empty((M, M, 3), np.float64)
+    w = np.empty((M, M), np.float64)
+    g = np.empty((M, M), np.float64)
+    if literal_passes:
+        lib().orr_step_f64(C.byref(p.c()), _fp(init4), _fp(phase), C.c_float(delta_time), _fp(h), _fp(d), _fp(n), _fp(w), _fp(g))
+        return h, d, n, w, g
+    sd = np.empty((M, M, 4), np.float64)
+    sh = np.empty((M, M, 2), np.float64)
+    lib().orr_spectra_f64(C.byref(p.c()), _fp(init4), _fp(phase), C.c_float(delta_time), _fp(sd), _fp(sh))
+    hx = np.fft.fft2(sd[..., 0] + 1j * sd[..., 1])
+    hz = np.fft.fft2(sd[..., 2] + 1j * sd[..., 3])
+    hh = np.fft.fft2(sh[..., 0] + 1j * sh[..., 1])
+    dtex = np.ascontiguousarray(np.stack([hx.real, hx.imag, hz.real, hz.imag], -1))
+    hre = np.ascontiguousarray(hh.real)
+    lib().orr_normal_white_f64(C.byref(p.c()), _fp(dtex), _fp(hre), _fp(n), _fp(w))
+    return hre, np.ascontiguousarray(dtex[..., [0, 2]]), n, w, np.ascontiguousarray(dtex[..., 1])

@@ -15,6 +15,7 @@
 
 #include "../../mistral-water_amd/csrc/fftmesh_kernels.h"
 #include "../../mistral-water_amd/csrc/gerstner_kernels.h"
+#include "../../mistral-water_amd/csrc/ocean_renderer_kernels.h"
 
 using namespace mw;
 
@@ -23,7 +24,7 @@ namespace {
 // concatenated twiddle table in the layout of TwGeom<N,P> (mirrors build_twiddle_table in mistral_water.hip)
 struct Tables {
     std::vector<cf> TW, Wpre;
-    Tables(int N, int P) : Wpre(2 * N) {
+    Tables(int N, int P, int sgn = +1) : Wpre(2 * N) {
         const int T = N / P;
         int S = 0;
         long long PS = 1;
@@ -34,14 +35,14 @@ struct Tables {
             for (int i = 0; i < s; i++) p *= P;
             for (long long k = 0; k < p; k++)
                 for (int r = 0; r < P; r++) {
-                    double a = 2.0 * M_PI * (double)(r * k) / (double)(p * P);
+                    double a = sgn * 2.0 * M_PI * (double)(r * k) / (double)(p * P);
                     TW.push_back(mk((float)cos(a), (float)sin(a)));
                 }
         }
         if (RL > 1)
             for (int u = 0; u < T; u++)
                 for (int r = 0; r < RL; r++) {
-                    double a = 2.0 * M_PI * (double)(r * u) / (double)N;
+                    double a = sgn * 2.0 * M_PI * (double)(r * u) / (double)N;
                     TW.push_back(mk((float)cos(a), (float)sin(a)));
                 }
         if (TW.empty()) TW.push_back(mk(1.f, 0.f));
@@ -167,6 +168,61 @@ int fft1d_np(const float* in_xy, float* out_xy) {
     return 0;
 }
 
+// ---- OceanRenderer semantics: one GenerateTexture() stepped through the kernels' phase functions ----------
+template <int N, int P>
+int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, float* height, cf* disp, float* disp_g,
+               float* normal, float* white) {
+    constexpr int T = FftGeom<N, P>::T;
+    Tables tb(N, P, -1);
+    const Twiddles tw = TwGeom<N, P>::view(tb.TW.data());
+    std::vector<cf> E((size_t)3 * N * N);
+    {
+        OrP1Args A;
+        A.initT = initT; A.phaseT = phaseT; A.TW = tb.TW.data(); A.E = E.data(); A.c = C; A.dt = dt;
+        constexpr int NT = OrP1Geom<N, P>::NTHREADS, BS = OrP1Geom<N, P>::BUFSTRIDE;
+        std::vector<cf> lds(4 * BS);
+        struct St { cf h[P]; cf x[P]; };
+        std::vector<St> st(NT);
+        for (int jb = 0; jb < N / 4; jb++) {
+            for (int tid = 0; tid < NT; tid++) or_p1_animate<N, P>(A, jb, tid, st[tid].h);
+            for (int f = 0; f < 3; f++) {
+                for (int tid = 0; tid < NT; tid++) {
+                    or_p1_build<N, P>(A, jb, tid, f, st[tid].h, st[tid].x);
+                    stage0_store<N, P, -1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
+                }
+                for (int s = 1; s < FftGeom<N, P>::S; s++) {
+                    for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
+                    for (int tid = 0; tid < NT; tid++) stage_store<N, P, -1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, tw, s);
+                }
+                for (int tid = 0; tid < NT; tid++) or_p1_finish<N, P>(A, tw, jb, tid, f, st[tid].x, lds.data());
+            }
+        }
+    }
+    {
+        OrP2Args A;
+        A.E = E.data(); A.TW = tb.TW.data(); A.height = height; A.disp = disp; A.disp_g = disp_g; A.c = C;
+        constexpr int NT = OrP2Geom<N, P>::NTHREADS, BS = OrP2Geom<N, P>::BUFSTRIDE;
+        std::vector<cf> lds(4 * BS);
+        struct St { cf x[P]; float dx[P]; };
+        std::vector<St> st(NT);
+        for (int ab = 0; ab < N / 4; ab++)
+            for (int k = 0; k < 3; k++) {
+                const int f = or_p2_field(k);
+                for (int tid = 0; tid < NT; tid++) or_p2_load<N, P>(A, ab, tid, f, st[tid].x, lds.data());
+                for (int s = 1; s < FftGeom<N, P>::S; s++) {
+                    for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid >> 2, lds.data() + (tid & 3) * BS);
+                    for (int tid = 0; tid < NT; tid++) stage_store<N, P, -1>(st[tid].x, tid >> 2, lds.data() + (tid & 3) * BS, tw, s);
+                }
+                for (int tid = 0; tid < NT; tid++) or_p2_finish<N, P>(A, tw, ab, tid, f, st[tid].x, st[tid].dx, lds.data());
+            }
+    }
+    for (int py = 0; py < N; py++)
+        for (int px = 0; px < N; px++) or_normal_element(C, px, py, height, disp, disp_g, normal);
+    for (int py = 0; py < N; py++)
+        for (int px = 0; px < N; px++) or_white_element(C, px, py, disp, normal, white);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -203,6 +259,29 @@ int emul_fft1d(int N, int pts, const float* in_xy, float* out_xy) {
         default: return 1;
     }
 #undef RUN
+}
+
+// OceanRenderer: init (transposed initial spectrum + zero phase) and one GenerateTexture step
+void emul_or_init(int M, float length, float wind_x, float wind_y, float amplitude, float gravity, uint64_t seed, float* initT,
+                  float* phaseT) {
+    for (int px = 0; px < M; px++)
+        for (int py = 0; py < M; py++)
+            or_init_element(M, length, wind_x, wind_y, amplitude / 10000.f, gravity, seed, px, py, reinterpret_cast<f4*>(initT), phaseT);
+}
+int emul_or_step(int M, float length, float gravity, float choppiness, float dt, const float* initT, float* phaseT,
+                 float* height, float* disp, float* disp_g, float* normal, float* white) {
+    OrConsts C;
+    C.M = M; C.length = length; C.gravity = gravity; C.choppiness = choppiness;
+    const f4* it = reinterpret_cast<const f4*>(initT);
+    cf* d = reinterpret_cast<cf*>(disp);
+    switch (M) {
+        case 64: return or_step_np<64, Plan<64>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white);
+        case 128: return or_step_np<128, Plan<128>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white);
+        case 256: return or_step_np<256, Plan<256>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white);
+        case 512: return or_step_np<512, Plan<512>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white);
+        case 1024: return or_step_np<1024, Plan<1024>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white);
+        default: return 1;
+    }
 }
 
 void emul_rest_mesh(int N, float unit_width, float* vertices, float* normals, float* uvs, int32_t* indices) {

@@ -67,6 +67,27 @@ class Emul:
         self.L.emul_omega_t(p.N, C.c_float(p.length), C.c_float(p.gravity), C.c_float(t), _p(out))
         return out
 
+    def or_init(self, rp, seed):
+        M = rp.M
+        initT = np.empty((M, M, 4), np.float32)   # [px][py]
+        phaseT = np.empty((M, M), np.float32)
+        self.L.emul_or_init(M, C.c_float(rp.length), C.c_float(rp.wind_x), C.c_float(rp.wind_y), C.c_float(rp.amplitude),
+                            C.c_float(rp.gravity), C.c_uint64(seed), _p(initT), _p(phaseT))
+        return initT, phaseT
+
+    def or_step(self, rp, initT, phaseT, delta_time):
+        M = rp.M
+        h = np.empty((M, M), np.float32)
+        d = np.empty((M, M, 2), np.float32)
+        g = np.empty((M, M), np.float32)
+        n = np.empty((M, M, 3), np.float32)
+        w = np.empty((M, M), np.float32)
+        dt = np.float32(delta_time) * np.float32(rp.mult)
+        r = self.L.emul_or_step(M, C.c_float(rp.length), C.c_float(rp.gravity), C.c_float(rp.choppiness), C.c_float(dt),
+                                _p(initT), _p(phaseT), _p(h), _p(d), _p(g), _p(n), _p(w))
+        assert r == 0
+        return h, d, n, w, g
+
     def gerstner(self, pos, waves, amplitude, frequency, steepness, t):
         pos = np.ascontiguousarray(pos, np.float32)
         wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)

@@ -1,0 +1,132 @@
+"""OceanRenderer semantics.  CPU tier: oracle self-consistency + the kernels' phase functions
+under host emulation; GPU tier (-m gpu): the C ABI (mw_ocean_generate_texture) against the oracle."""
+import numpy as np
+import pytest
+
+from oracle.oracle import RendererParams
+
+
+def shipped(resolution=8):
+    # D/Ocean Demo.unity:296-302 (resolution 128 -> 1024^2 textures there; smaller here), length scaled with M
+    M = 8 * resolution
+    return RendererParams(resolution=resolution, length=434.48 * M / 1024.0, wind_x=14.45, wind_y=12.0, amplitude=0.41,
+                          choppiness=0.46, gravity=9.81, mult=1.5)
+
+
+def tol_check(got, want, rel, name):
+    sc = max(float(np.abs(want).max()), 1e-6)
+    err = float(np.abs(got - want).max())
+    assert err <= rel * sc, f"{name}: {err:.3e} vs scale {sc:.3e}"
+
+
+def test_anchor_table_b_phillips(oracle):
+    # SURVEY.md 8a anchors: B Phillips phi1, N=1024, L=434.48, wind=(14.45,12), A=0.41e-4 at texel px
+    rp = RendererParams(resolution=128, length=434.48, wind_x=14.45, wind_y=12.0, amplitude=0.41)
+    L = oracle.lib()
+    L.orr_phillips.restype = __import__("ctypes").c_float
+    import ctypes as C
+    for (px, py), want in {(1, 0): 13.75721, (0, 1): 9.487616, (3, 2): 4.126636, (1023, 1023): 36.58870, (1000, 5): 9.844989e-4}.items():
+        got = L.orr_phillips(C.byref(rp.c()), C.c_float(px + 0.5), C.c_float(py + 0.5), 1024)
+        assert got == pytest.approx(want, rel=3e-6)
+
+
+def test_anchor_table_b_dispersion(oracle):
+    # B omega (dt = 1, phase from 0): px=(1,0) / (3,2) / (512,512) / (1000,5)
+    import ctypes as C
+    rp = RendererParams(resolution=128, length=434.48)
+    L = oracle.lib()
+    L.orr_phase_advance.restype = C.c_float
+    for (px, py), want in {(1, 0): 0.3766514, (3, 2): 0.7151965, (1000, 5): 1.8649121}.items():
+        got = L.orr_phase_advance(C.byref(rp.c()), 1024, px, py, C.c_float(0.0), C.c_float(1.0))
+        assert got == pytest.approx(want, rel=2e-6)
+    got = L.orr_phase_advance(C.byref(rp.c()), 1024, 512, 512, C.c_float(0.0), C.c_float(1.0))
+    assert got == pytest.approx(10.1392509 % (2 * np.float32(3.1415926536)), rel=2e-6)   # wrapped by fmod
+
+
+def test_literal_stockham_schedule_is_forward_dft(oracle):
+    """The 2*log2(M) gather passes of S/OceanRenderer.cs:229-262 == numpy fft2 (forward, unnormalised, natural order)."""
+    rp = shipped(8)
+    init4 = oracle.renderer_initial_spectrum(rp, 3)
+    pa = np.zeros((rp.M, rp.M), np.float32)
+    pb = np.zeros((rp.M, rp.M), np.float32)
+    a = oracle.renderer_step_f64(rp, init4, pa, 0.02, literal_passes=True)
+    b = oracle.renderer_step_f64(rp, init4, pb, 0.02, literal_passes=False)
+    assert (pa == pb).all()
+    for x, y, nm in zip(a, b, ("height", "disp", "normal", "white", "disp_g")):
+        tol_check(x, y, 1e-10, nm)
+
+
+def test_initial_spectrum_off_by_one_mirror(oracle):
+    # b5: at texel (0,0) phi1 = 0 (k = 0) but phi2 = Phillips at texel (M-1, M-1) != 0
+    rp = shipped(8)
+    init4 = oracle.renderer_initial_spectrum(rp, 1)
+    assert (init4[0, 0, :2] == 0).all() and np.abs(init4[0, 0, 2:]).max() > 0
+
+
+def test_phase_is_stateful_and_wrapped(oracle):
+    rp = shipped(8)
+    init4 = oracle.renderer_initial_spectrum(rp, 1)
+    ph = np.zeros((rp.M, rp.M), np.float32)
+    for _ in range(40):
+        oracle.renderer_step_f64(rp, init4, ph, 0.3, literal_passes=False)
+    assert ph.min() >= 0 and ph.max() < 2 * np.float32(3.1415926536) and ph[0, 0] == 0  # k = 0 never advances
+
+
+@pytest.mark.parametrize("resolution", [8, 16, 32])
+def test_emulated_kernels_vs_oracle(emul, oracle, resolution):
+    rp = shipped(resolution)
+    M = rp.M
+    init4 = oracle.renderer_initial_spectrum(rp, 5)
+    initT, phaseT = emul.or_init(rp, 5)
+    sc = np.abs(init4).max()
+    assert np.abs(initT.transpose(1, 0, 2) - init4).max() < 3e-6 * sc   # generation: libm differences only
+    initT = np.ascontiguousarray(init4.transpose(1, 0, 2))              # then inject identical spectra
+    ph = np.zeros((M, M), np.float32)
+    for frame, dt in enumerate((0.016, 0.033, 0.3)):
+        h, d, n, w, g = emul.or_step(rp, initT, phaseT, dt)
+        H, D, Nn, W, G = oracle.renderer_step_f64(rp, init4, ph, dt, literal_passes=(M <= 128))
+        assert (phaseT.T == ph).all(), "stateful f32 phase must match bit for bit"
+        tol_check(h, H, 3e-6, "height"); tol_check(d, D, 3e-6, "disp"); tol_check(g, G, 3e-6, "disp.g")
+        assert np.abs(n - Nn).max() < 2e-5
+        assert np.abs(w - W).max() < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resolution", [8, 32, 128])
+def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
+    rp = shipped(resolution)
+    M = rp.M
+    o = mw.Ocean(resolution=resolution, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude,
+                 choppiness=rp.choppiness, gravity=rp.gravity, mult=rp.mult, seed=5, semantics=mw.MW_SEM_OCEANRENDERER)
+    assert o.N == M
+    init4 = oracle.renderer_initial_spectrum(rp, 5)
+    ph = np.zeros((M, M), np.float32)
+    # the device generates its own initial spectrum (same RNG, device libm): the first frames agree to ~1e-5,
+    # dominated by exp/log/sqrt differences in the spectrum itself
+    for dt in (0.016, 0.033, 0.3):
+        h, d, n, w = o.generate_texture(dt)
+        H, D, Nn, W, G = oracle.renderer_step_f64(rp, init4, ph, dt, literal_passes=False)
+        tol_check(h, H, 2e-5, "height"); tol_check(d, D, 2e-5, "disp")
+        assert np.abs(n - Nn).max() < 1e-4 and np.abs(w - W).max() < 3e-4
+    o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_oceanrenderer_lifecycle(mw):
+    r = mw.OceanRenderer()
+    r.resolution, r.length, r.amplitude, r.choppiness, r.mult = 16, 60.0, 0.41, 0.46, 1.5
+    r.wind = mw.Vector2(14.45, 12.0)
+    r.Awake()
+    assert r.mesh.vertices.shape == (256, 3) and r.mesh.indices.size == 15 * 15 * 6
+    r.Update(0.016)
+    h1 = r.heightTexture.copy()
+    r.Update(0.016)
+    assert r.heightTexture.shape == (128, 128) and not np.array_equal(h1, r.heightTexture)
+    assert np.isfinite(r.normalTexture).all() and (r.whiteTexture >= 0).all() and (r.whiteTexture <= 1).all()
+    r.wind = mw.Vector2(3.0, 1.0)          # param change -> RenderInitial again (S/OceanRenderer.cs:98-109)
+    r.Update(0.016)
+    r.Update(0.016)
+    assert np.isfinite(r.heightTexture).all()
+    with pytest.raises(mw.MistralWaterError) as e:
+        mw.Ocean(resolution=12, length=10.0, semantics=mw.MW_SEM_OCEANRENDERER)   # 96 is not a power of two
+    assert e.value.status == mw.MW_ENOTPOW2

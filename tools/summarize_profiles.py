@@ -1,0 +1,31 @@
+"""Condenses a tools/profile_r1.sh output directory into the small files committed under profiles/.
+usage: python tools/summarize_profiles.py gpurun_out/prof_<tag> profiles/<name>"""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), dst + "_kernel_stats.csv")
+bench_line = [l for l in open(os.path.join(src, "bench_stdout.txt")) if l.startswith("{")]
+pmc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0]
+        if "k_pass" in k or "gerstner" in k:
+            pmc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            pmc[k]["_dur_ns_" + row["Counter_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+out = {"source": src, "bench_line": json.loads(bench_line[-1]) if bench_line else None, "pmc_mean_per_launch": {}}
+for k, d in pmc.items():
+    # drop the short warm-up launches: keep launches within 15 % of the median duration of that counter pass
+    o = {}
+    for c, vals in d.items():
+        if c.startswith("_dur_ns_"):
+            continue
+        durs = d["_dur_ns_" + c]
+        med = sorted(durs)[len(durs) // 2]
+        keep = [v for v, t in zip(vals, durs) if abs(t - med) <= 0.15 * med]
+        o[c] = sum(keep) / len(keep)
+        o.setdefault("_launch_us", {})[c] = med / 1e3
+    out["pmc_mean_per_launch"][k] = o
+json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
+print(json.dumps(out["pmc_mean_per_launch"], indent=1)[:3000])
