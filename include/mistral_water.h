@@ -91,6 +91,8 @@ mw_status mw_ocean_set_choppiness(mw_ocean* o, float choppiness);
 /* Inject / read back verttilde and vertConj (S/FFTMesh.cs:35-36,114-116), N*N*2 floats each,
  * idx = i*N + j.  Injection is how a caller reproduces a Unity-generated spectrum exactly, and
  * how the parity tests feed identical inputs to the oracle and to the GPU.                         */
+/* OceanRenderer semantics: the same pair is initialTexture.rg / .ba (F/InitialSpectrum.shader:53), M*M*2 floats
+ * each with texel (px,py) at index py*M + px; setting it restarts the phase at 0.                              */
 mw_status mw_ocean_set_spectrum(mw_ocean* o, const float* h0_xy, const float* h0conj_xy);
 mw_status mw_ocean_get_spectrum(mw_ocean* o, float* h0_xy, float* h0conj_xy);
 

@@ -531,9 +531,20 @@ mw_status mw_ocean_reset_timer(mw_ocean* o) {
 
 mw_status mw_ocean_set_spectrum(mw_ocean* o, const float* h0_xy, const float* h0conj_xy) {
     if (!o || !h0_xy || !h0conj_xy) return fail(MW_EINVAL, "mw_ocean_set_spectrum: NULL argument");
-    if (o->sem != MW_SEM_FFTMESH) return fail(MW_ESTATE, "mw_ocean_set_spectrum: FFTMesh semantics only");
     HIP_TRY(hipSetDevice(o->device));
     const size_t bytes = sizeof(cf) * (size_t)o->N * o->N;
+    if (o->sem == MW_SEM_OCEANRENDERER) {  // initialTexture.rg / .ba, texel (px,py) at py*M + px
+        cf *a = nullptr, *b = nullptr;
+        HIP_TRY(hipMalloc((void**)&a, bytes));
+        if (hipMalloc((void**)&b, bytes) != hipSuccess) { hipFree(a); return fail(MW_ENOMEM, "hipMalloc failed"); }
+        hipMemcpyAsync(a, h0_xy, bytes, hipMemcpyHostToDevice, o->stream);
+        hipMemcpyAsync(b, h0conj_xy, bytes, hipMemcpyHostToDevice, o->stream);
+        k_or_set_init<<<dim3((unsigned)(((size_t)o->N * o->N + 255) / 256)), dim3(256), 0, o->stream>>>(o->N, a, b, o->orr.initT,
+                                                                                                   o->orr.phaseT);
+        hipError_t e = hipStreamSynchronize(o->stream);
+        hipFree(a); hipFree(b);
+        return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, "set_spectrum (OceanRenderer) failed");
+    }
     HIP_TRY(hipMemcpyAsync(o->h0, h0_xy, bytes, hipMemcpyHostToDevice, o->stream));
     HIP_TRY(hipMemcpyAsync(o->h0c, h0conj_xy, bytes, hipMemcpyHostToDevice, o->stream));
     mw_status s = run_prep(o);
@@ -543,9 +554,19 @@ mw_status mw_ocean_set_spectrum(mw_ocean* o, const float* h0_xy, const float* h0
 }
 mw_status mw_ocean_get_spectrum(mw_ocean* o, float* h0_xy, float* h0conj_xy) {
     if (!o || !h0_xy || !h0conj_xy) return fail(MW_EINVAL, "mw_ocean_get_spectrum: NULL argument");
-    if (o->sem != MW_SEM_FFTMESH) return fail(MW_ESTATE, "mw_ocean_get_spectrum: FFTMesh semantics only");
     HIP_TRY(hipSetDevice(o->device));
     const size_t bytes = sizeof(cf) * (size_t)o->N * o->N;
+    if (o->sem == MW_SEM_OCEANRENDERER) {
+        cf *a = nullptr, *b = nullptr;
+        HIP_TRY(hipMalloc((void**)&a, bytes));
+        if (hipMalloc((void**)&b, bytes) != hipSuccess) { hipFree(a); return fail(MW_ENOMEM, "hipMalloc failed"); }
+        k_or_get_init<<<dim3((unsigned)(((size_t)o->N * o->N + 255) / 256)), dim3(256), 0, o->stream>>>(o->N, o->orr.initT, a, b);
+        hipMemcpyAsync(h0_xy, a, bytes, hipMemcpyDeviceToHost, o->stream);
+        hipMemcpyAsync(h0conj_xy, b, bytes, hipMemcpyDeviceToHost, o->stream);
+        hipError_t e = hipStreamSynchronize(o->stream);
+        hipFree(a); hipFree(b);
+        return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, "get_spectrum (OceanRenderer) failed");
+    }
     HIP_TRY(hipMemcpyAsync(h0_xy, o->h0, bytes, hipMemcpyDeviceToHost, o->stream));
     HIP_TRY(hipMemcpyAsync(h0conj_xy, o->h0c, bytes, hipMemcpyDeviceToHost, o->stream));
     HIP_TRY(hipStreamSynchronize(o->stream));

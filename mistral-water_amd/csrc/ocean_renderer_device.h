@@ -32,6 +32,25 @@ __global__ void k_or_init(int M, float length, float wind_x, float wind_y, float
     or_init_element(M, length, wind_x, wind_y, amp, gravity, seed, idx / M, idx % M, initT, phaseT);
 }
 
+// initialTexture <-> (h0, h0conj) arrays in the reference's texel order idx = py*M + px
+__global__ void k_or_set_init(int M, const cf* h0, const cf* h0c, f4* initT, float* phaseT) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * M) return;
+    const int px = idx / M, py = idx % M;  // transposed enumeration: coalesced writes
+    const cf a = h0[(size_t)py * M + px], b = h0c[(size_t)py * M + px];
+    f4 v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
+    initT[idx] = v;
+    phaseT[idx] = 0.f;  // RenderInitial does not touch the phase in the reference; a fresh spectrum restarts it here
+}
+__global__ void k_or_get_init(int M, const f4* initT, cf* h0, cf* h0c) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * M) return;
+    const int py = idx / M, px = idx % M;
+    const f4 v = initT[(size_t)px * M + py];
+    h0[idx] = mk(v.x, v.y);
+    h0c[idx] = mk(v.z, v.w);
+}
+
 template <int N, int P>
 __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

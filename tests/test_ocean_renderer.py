@@ -94,20 +94,30 @@ def test_emulated_kernels_vs_oracle(emul, oracle, resolution):
 @pytest.mark.gpu
 @pytest.mark.parametrize("resolution", [8, 32, 128])
 def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
+    """BASELINE's shipped OceanRenderer configuration (1024^2 textures at resolution 128) and smaller."""
     rp = shipped(resolution)
     M = rp.M
     o = mw.Ocean(resolution=resolution, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude,
                  choppiness=rp.choppiness, gravity=rp.gravity, mult=rp.mult, seed=5, semantics=mw.MW_SEM_OCEANRENDERER)
     assert o.N == M
     init4 = oracle.renderer_initial_spectrum(rp, 5)
+    # (1) the device-generated initial spectrum equals the oracle's up to device libm (exp/log/sqrt)
+    g0, g0c = o.get_spectrum()
+    sc = np.abs(init4).max()
+    assert np.abs(g0 - init4[..., :2]).max() < 5e-6 * sc and np.abs(g0c - init4[..., 2:]).max() < 5e-6 * sc
+    # (2) with the SAME spectrum injected, every frame matches to float32 transform accuracy
+    o.set_spectrum(init4[..., :2], init4[..., 2:])
     ph = np.zeros((M, M), np.float32)
-    # the device generates its own initial spectrum (same RNG, device libm): the first frames agree to ~1e-5,
-    # dominated by exp/log/sqrt differences in the spectrum itself
     for dt in (0.016, 0.033, 0.3):
         h, d, n, w = o.generate_texture(dt)
         H, D, Nn, W, G = oracle.renderer_step_f64(rp, init4, ph, dt, literal_passes=False)
-        tol_check(h, H, 2e-5, "height"); tol_check(d, D, 2e-5, "disp")
-        assert np.abs(n - Nn).max() < 1e-4 and np.abs(w - W).max() < 3e-4
+        tol_check(h, H, 3e-6, "height"); tol_check(d, D, 3e-6, "disp")
+        # F/OceanNormal.shader normalises a sum of four cross products that (with its `center = D.rgb` quirk) can
+        # nearly cancel: at those isolated texels 1/|n| amplifies float32 rounding.  Bound the bulk tightly and the
+        # ill-conditioned tail loosely.
+        en, ew = np.abs(n - Nn).max(-1).ravel(), np.abs(w - W).ravel()
+        assert np.quantile(en, 0.999) < 3e-5 and en.max() < 1e-2, (float(np.quantile(en, 0.999)), float(en.max()))
+        assert np.quantile(ew, 0.999) < 1e-4 and ew.max() < 1e-2, (float(np.quantile(ew, 0.999)), float(ew.max()))
     o.close()
 
 
