@@ -312,6 +312,10 @@ struct TwGeom {
 template <int N, int P, int SGN>
 MW_HD void stage0_store(cf (&x)[P], int u, cf* buf) {
     DftP<P, SGN>::run(x);
+#ifdef MW_ABLATE_LDS
+    if (u == 12345) buf[0] = x[0];
+    return;
+#endif
     cf* __restrict__ b = buf + (P + 1) * u;  // lds_pad(P*u + r) = (P+1)*u + r for r < P
 #pragma unroll
     for (int r = 0; r < P; r++) b[r] = x[r];
@@ -319,6 +323,10 @@ MW_HD void stage0_store(cf (&x)[P], int u, cf* buf) {
 template <int N, int P>
 MW_HD void load_slots(cf (&x)[P], int u, const cf* buf) {
     constexpr int T = FftGeom<N, P>::T;
+#ifdef MW_ABLATE_LDS
+    if (u == 12345) x[0] = buf[0];
+    return;
+#endif
     if (T % P == 0) {  // lds_pad(u + T*q) = lds_pad(u) + T*q + T*q/P
         const cf* __restrict__ b = buf + lds_pad<P>(u);
 #pragma unroll
@@ -338,6 +346,10 @@ MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
     for (int r = 1; r < P; r++) x[r] = cmul(x[r], row[r]);
     DftP<P, SGN>::run(x);
     const int j = ((u - k) << LogP<P>::v) + k;
+#ifdef MW_ABLATE_LDS
+    if (u == 12345) buf[j] = x[0];
+    return;
+#endif
     cf* __restrict__ b = buf + lds_pad<P>(j);  // p is a multiple of P: lds_pad(j + p*r) = lds_pad(j) + p*r + p*r/P
 #pragma unroll
     for (int r = 0; r < P; r++) b[p * r + ((p * r) >> LogP<P>::v)] = x[r];

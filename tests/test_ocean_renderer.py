@@ -116,7 +116,7 @@ def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
         # nearly cancel: at those isolated texels 1/|n| amplifies float32 rounding.  Bound the bulk tightly and the
         # ill-conditioned tail loosely.
         en, ew = np.abs(n - Nn).max(-1).ravel(), np.abs(w - W).ravel()
-        assert np.quantile(en, 0.999) < 3e-5 and en.max() < 1e-2, (float(np.quantile(en, 0.999)), float(en.max()))
+        assert np.quantile(en, 0.999) < 1e-4 and np.median(en) < 2e-6 and en.max() < 1e-2, (float(np.quantile(en, 0.999)), float(en.max()))
         assert np.quantile(ew, 0.999) < 1e-4 and ew.max() < 1e-2, (float(np.quantile(ew, 0.999)), float(ew.max()))
     o.close()
 
