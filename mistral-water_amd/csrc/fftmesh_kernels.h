@@ -203,6 +203,12 @@ MW_HD void field_coeffs(int f, float kx, float kz, cf* cx, cf* cz) {
     }
 }
 
+// Which fields a pass-1 block transforms.  The height field (f = 0) transforms to a REAL output, so after the
+// first 1-D transform its rows are Hermitian in j: T(a, N-j) = conj T(a, j).  Only columns j <= N/2 are
+// transformed and stored (blocks jb <= N/8); pass 2 rebuilds the other half by conjugation (p2_load).  The
+// Nyquist-column job (jb == N/4) has no height term at all.
+MW_HD bool p1_field_active(int N, int jb, int f) { return f != 0 || jb <= N / 8; }
+
 // animated packed spectrum, P points per thread (column job w, i = u + T q)
 template <int N, int P>
 MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, P1State<P>& st) {
@@ -326,8 +332,10 @@ MW_HD void p2_load_map(int tid, int* r1, int* u1) {
     else { *r1 = R2; *u1 = tid - R2 * T; }
 }
 
+// global loads of one field's row data (row-interleaved mapping).  Split from the stage-0 pass so that the kernel
+// can issue field k+1's loads before it starts field k's exchanges (software prefetch: twice the bytes in flight).
 template <int N, int P, int R2>
-MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P], cf* lds) {
+MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P]) {
     constexpr int T = FftGeom<N, P>::T;
     int r1, u1;
     p2_load_map<N, P, R2>(tid, &r1, &u1);
@@ -336,11 +344,27 @@ MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P]
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int j = u1 + T * q;
-        x[q] = Ef[((size_t)(j >> 2) * N + row) * 4 + (j & 3)];
+        if (f == 0 && j > N / 2) {  // height: stored for j <= N/2 only; T(a, j) = conj T(a, N - j)
+            const int m = N - j;
+            x[q] = cconj(Ef[((size_t)(m >> 2) * N + row) * 4 + (m & 3)]);
+        } else {
+            x[q] = Ef[((size_t)(j >> 2) * N + row) * 4 + (j & 3)];
+        }
     }
     if (u1 == 0 && f != 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];  // Nyquist column j = 0
+}
+template <int N, int P, int R2>
+MW_HD void p2_stage0(int tid, cf (&x)[P], cf* lds) {
+    int r1, u1;
+    p2_load_map<N, P, R2>(tid, &r1, &u1);
     stage0_store<N, P, +1>(x, u1, lds + r1 * P2Geom<N, P, R2>::BUFSTRIDE);
 }
+template <int N, int P, int R2>
+MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P], cf* lds) {
+    p2_fetch<N, P, R2>(A, ab, step, tid, f, x);
+    p2_stage0<N, P, R2>(tid, x, lds);
+}
+
 // middle passes keep the load-side (row-interleaved) mapping: measured fewer LDS bank conflicts than row-major
 template <int N, int P, int R2>
 MW_HD void p2_mid_load(int tid, cf (&x)[P], const cf* lds) {

@@ -114,7 +114,7 @@ __global__ __launch_bounds__((P1Geom<N, P>::NTHREADS)) __attribute__((amdgpu_wav
     MW_STAMP(0, 1);
 #pragma unroll
     for (int f = 0; f < 3; f++) {
-        if (f == 0 && jb == N / 4) continue;  // the Nyquist-column job has no height term (block-uniform)
+        if (!p1_field_active(N, jb, f)) continue;  // block-uniform: height needs columns j <= N/2 only
         p1_build<N, P>(A, jb, tid, f, st, x);
         if (G::NBUF == 1 && f) __syncthreads();
         MW_STAMP(0, 2 + 8 * f);
@@ -159,6 +159,10 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
     int cur = 0;
     P2State<P> st;
     cf x[P];
+#ifdef MW_P2_PREFETCH
+    cf xn[P];
+    if (p2_active<N, P, R2>(ab, tid, p2_field(0))) p2_fetch<N, P, R2>(A, ab, step, tid, p2_field(0), xn);
+#endif
     MW_STAMP(1, 0);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -166,7 +170,17 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
         const bool active = p2_active<N, P, R2>(ab, tid, f);
         if (G::NBUF == 1 && k) __syncthreads();
         MW_STAMP(1, 1 + 8 * k);
+#ifdef MW_P2_PREFETCH
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < P; q++) x[q] = xn[q];
+            p2_stage0<N, P, R2>(tid, x, set0 + cur * G::SETSTRIDE);
+        }
+        if (k < 2 && p2_active<N, P, R2>(ab, tid, p2_field(k + 1)))  // next field's rows fly during this field's passes
+            p2_fetch<N, P, R2>(A, ab, step, tid, p2_field(k + 1), xn);
+#else
         if (active) p2_load<N, P, R2>(A, ab, step, tid, f, x, set0 + cur * G::SETSTRIDE);
+#endif
         MW_STAMP(1, 2 + 8 * k);
 #ifdef MW_ABLATE_FFT
         if (active) {  // no exchanges: treat the loaded values as the transformed row (memory-pattern floor)
@@ -222,7 +236,7 @@ struct mw_ocean {
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_full[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_inputs = nullptr;
     int region = 0;
-    bool pipeline = true;
+    bool pipeline = false;  // MW_PIPELINE=1: measured neutral at 1024^2, kept as an option
     float timer = 0.f;
     // FFTMesh state
     cf *h0 = nullptr, *h0c = nullptr;
@@ -379,9 +393,10 @@ static mw_status ensure_exchange(mw_ocean* o, int nsteps) {
         o->E = o->Cj0 = nullptr;
         o->e_cap = 0;
     }
-    mw_status s = dmalloc(&o->E, (size_t)2 * nsteps * 3 * o->N * o->N);  // two regions (pipeline)
+    const size_t regions = o->pipeline ? 2 : 1;
+    mw_status s = dmalloc(&o->E, regions * nsteps * 3 * o->N * o->N);
     if (s != MW_OK) return s;
-    if ((s = dmalloc(&o->Cj0, (size_t)2 * nsteps * 3 * o->N)) != MW_OK) return s;
+    if ((s = dmalloc(&o->Cj0, regions * nsteps * 3 * o->N)) != MW_OK) return s;
     o->e_cap = nsteps;
     return MW_OK;
 }

@@ -66,7 +66,7 @@ void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
             const float t = tm.t[step];
             for (int tid = 0; tid < NT; tid++) p1_animate<N, P>(A, jb, tid, t, st[tid].s);
             for (int f = 0; f < 3; f++) {
-                if (f == 0 && jb == N / 4) continue;
+                if (!p1_field_active(N, jb, f)) continue;
                 for (int tid = 0; tid < NT; tid++) {
                     p1_build<N, P>(A, jb, tid, f, st[tid].s, st[tid].x);
                     stage0_store<N, P, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
