@@ -46,6 +46,20 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(N, B):
+    """HBM-side bytes per k_pass2 launch from the committed rocprofv3 PMC passes (tools/profile_r1.sh ->
+    profiles/r01_ocean{N}_b{B}_pmc.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, i.e. with the gfx950 correction the
+    micro-architecture guide prescribes (FETCH_SIZE counts 128-B requests at 64 B).  Counters cannot be read from
+    inside this process, so this is the value measured by the same command under the profiler; None if absent."""
+    path = os.path.join(REPO, "profiles", f"r01_ocean{N}_b{B}_pmc.json")
+    try:
+        d = json.load(open(path))["pmc_mean_per_launch"]
+        k = [v for name, v in d.items() if "k_pass2" in name][0]
+        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, f"rocprofv3 --pmc, {os.path.relpath(path, REPO)}"
+    except Exception:
+        return None, "no committed PMC pass for this workload/batch"
+
+
 def cpu_baseline(p, h0, h0c, budget_s=12.0):
     """Literal O(N^4) port (oracle) on a vertex sample sized for ~10-20 s of one host core."""
     from oracle import oracle as O
@@ -147,11 +161,12 @@ def main():
         el = float(tt.item())
 
     # ---- kernel-level timing with HIP events on the launch stream (rank 0) ----------------------------
-    kern = ocean.profile_kernels(nsteps=B, iters=50)
+    kern = ocean.profile_kernels(nsteps=B, iters=50)   # in situ: pass1/pass2 alternate as in the timed loop
     k2_ms = kern[1][1]
     roof_ach = BYTES_PASS2 * NN * B / (k2_ms * 1e-3)
+    traffic, traffic_note = pmc_traffic(N, B)
     roofline = {"bound": "hbm", "kernel": "k_pass2", "achieved": roof_ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": roof_ach / HBM_PEAK, "traffic": None,
+                "frac": roof_ach / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
                 "bytes_per_launch": BYTES_PASS2 * NN * B, "launch_us": k2_ms * 1e3,
                 "kernels": [{"name": nm, "us_per_launch": ms * 1e3,
                              "algorithmic_GBps": (BYTES_PASS1 if i == 0 else BYTES_PASS2) * NN * B / (ms * 1e-3) / 1e9}

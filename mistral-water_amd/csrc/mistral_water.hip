@@ -738,26 +738,36 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
     }
     StepTimes tm;
     for (int k = 0; k < nsteps; k++) tm.t[k] = 1.0f + (float)k / 60.f;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
+    // In-situ timing: the two kernels alternate exactly as in mw_ocean_evaluate_device (pass 2 of a batch follows
+    // its pass 1), with a HIP event between every launch on the launch stream.
     static const char* names[2] = {"k_pass1 (h~ + transform along i)", "k_pass2 (transform along j + epilogue)"};
-    for (int k = 0; k < 2 && s == MW_OK; k++) {
-        // warm-up
-        s = (k == 0) ? launch_pass1(o, tm, nsteps, o->stream, 0) : launch_pass2(o, nsteps, dv, dn, dw, 1, 0);
-        if (s != MW_OK) break;
-        hipEventRecord(e0, o->stream);
-        for (int it = 0; it < iters && s == MW_OK; it++)
-            s = (k == 0) ? launch_pass1(o, tm, nsteps, o->stream, 0) : launch_pass2(o, nsteps, dv, dn, dw, 1, 0);
-        hipEventRecord(e1, o->stream);
-        hipEventSynchronize(e1);
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
-        ms_out[k] = ms / (float)iters;
+    std::vector<hipEvent_t> ev(2 * iters + 1);
+    for (auto& e : ev) hipEventCreate(&e);
+    for (int w = 0; w < 2 && s == MW_OK; w++) {  // warm-up
+        s = launch_pass1(o, tm, nsteps, o->stream, 0);
+        if (s == MW_OK) s = launch_pass2(o, nsteps, dv, dn, dw, 1, 0);
+    }
+    hipEventRecord(ev[0], o->stream);
+    for (int it = 0; it < iters && s == MW_OK; it++) {
+        s = launch_pass1(o, tm, nsteps, o->stream, 0);
+        hipEventRecord(ev[2 * it + 1], o->stream);
+        if (s == MW_OK) s = launch_pass2(o, nsteps, dv, dn, dw, 1, 0);
+        hipEventRecord(ev[2 * it + 2], o->stream);
+    }
+    hipEventSynchronize(ev[2 * iters]);
+    double acc[2] = {0.0, 0.0};
+    for (int it = 0; it < iters && s == MW_OK; it++) {
+        float m1 = 0.f, m2 = 0.f;
+        hipEventElapsedTime(&m1, ev[2 * it], ev[2 * it + 1]);
+        hipEventElapsedTime(&m2, ev[2 * it + 1], ev[2 * it + 2]);
+        acc[0] += m1;
+        acc[1] += m2;
+    }
+    for (int k = 0; k < 2; k++) {
+        ms_out[k] = (float)(acc[k] / iters);
         if (names_out) names_out[k] = names[k];
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    for (auto& e : ev) hipEventDestroy(e);
     if (nsteps != 1) { hipFree(dv); hipFree(dn); hipFree(dw); }
     *nkernels = 2;
     return s;

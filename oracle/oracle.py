@@ -247,3 +247,13 @@ def renderer_step_f64(p: RendererParams, init4, phase, delta_time: float, litera
     hre = np.ascontiguousarray(hh.real)
     lib().orr_normal_white_f64(C.byref(p.c()), _fp(dtex), _fp(hre), _fp(n), _fp(w))
     return hre, np.ascontiguousarray(dtex[..., [0, 2]]), n, w, np.ascontiguousarray(dtex[..., 1])
+
+
+def gerstner_f64(pos_xyz, waves, amplitude, frequency, steepness, t):
+    """W/MistralWaterLib.cginc:71-99,154-180 in f64 (oracle/gerstner_oracle.c)."""
+    pos = np.ascontiguousarray(pos_xyz, np.float32)
+    wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)
+    out = np.empty(pos.shape, np.float64)
+    lib().orc_gerstner_f64(_fp(pos), C.c_int64(pos.size // 3), _fp(wv), C.c_int(wv.shape[0]), C.c_float(amplitude),
+                           C.c_float(frequency), C.c_float(steepness), C.c_float(t), _fp(out))
+    return out

@@ -112,17 +112,19 @@ def test_white_scalar_layout(emul, oracle):
     assert (w4[..., 0] == w1[..., 0]).all() and (w4[..., 3] == w1[..., 0]).all()
 
 
-def test_gerstner_vs_numpy(emul):
+def test_gerstner_vs_oracle(emul, oracle):
     rng = np.random.default_rng(0)
     pos = rng.uniform(-50, 50, (1000, 3)).astype(np.float32)
-    W = workloads.pond_waves8()
-    P = workloads.POND
+    W, P = workloads.pond_waves8(), workloads.POND
     out = emul.gerstner(pos, W, P["amplitude"], P["frequency"], P["steepness"], 3.25)
+    want = oracle.gerstner_f64(pos, W, P["amplitude"], P["frequency"], P["steepness"], 3.25)
+    assert np.abs(out - want).max() < 3e-5
+    # numpy cross-check of the oracle itself (W/MistralWaterLib.cginc:77-88)
     x, y, z = pos.astype(np.float64).T
     ox, oy, oz = x.copy(), y.copy(), z.copy()
-    for dx, dy, sp in W:   # W/MistralWaterLib.cginc:77-88
-        th = P["frequency"] * (np.float32(dx) * x + np.float32(dy) * z) + 3.25 * np.float32(sp)
-        ox += np.cos(th) * P["steepness"] * P["amplitude"] * np.float32(dx)
-        oz += np.cos(th) * P["steepness"] * P["amplitude"] * np.float32(dy)
-        oy += P["amplitude"] * np.sin(th)
-    assert np.abs(out - np.stack([ox, oy, oz], 1)).max() < 2e-4
+    for dx, dy, sp in W:
+        th = np.float32(P["frequency"]) * (np.float32(dx) * x + np.float32(dy) * z) + np.float32(3.25) * np.float32(sp)
+        ox += np.cos(th) * np.float32(P["steepness"]) * np.float32(P["amplitude"]) * np.float32(dx)
+        oz += np.cos(th) * np.float32(P["steepness"]) * np.float32(P["amplitude"]) * np.float32(dy)
+        oy += np.float32(P["amplitude"]) * np.sin(th)
+    assert np.abs(want - np.stack([ox, oy, oz], 1)).max() < 1e-6
