@@ -255,6 +255,31 @@ def test_gerstner_pond(mw, oracle):
     assert np.abs(out - oracle.gerstner_f64(pos, P["waves"], P["amplitude"], P["frequency"], P["steepness"], 0.7)).max() < 3e-6
 
 
+def test_batch_limits_and_empty_inputs(mw, oracle):
+    """Maximum batch (32 steps per enqueue) equals single steps; one more is MW_EINVAL; empty pond input is a no-op."""
+    import torch
+    p = workloads.fftmesh_params(64)
+    NN = 64 * 64
+    with make(mw, p) as o:
+        assert o.max_batch == 32
+        times = [0.1 * k for k in range(32)]
+        dv = torch.empty((32, NN, 3), dtype=torch.float32, device="cuda")
+        dn = torch.empty((32, NN, 3), dtype=torch.float32, device="cuda")
+        dw = torch.empty((32, NN, 4), dtype=torch.float32, device="cuda")
+        o.evaluate_device(times, dv.data_ptr(), dn.data_ptr(), dw.data_ptr(), rgba=True)
+        o.synchronize()
+        for k in (0, 17, 31):
+            v, n, c = o.evaluate(times[k])
+            assert (dv[k].cpu().numpy() == v).all() and (dw[k].cpu().numpy() == c).all()
+        with pytest.raises(mw.MistralWaterError) as e:
+            o.evaluate_device([0.0] * 33, dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+        assert e.value.status == mw.MW_EINVAL
+    out = mw.gerstner_displace(np.zeros((0, 3), np.float32), workloads.POND["waves"], 0.1, 2.58, 0.99, 1.0)
+    assert out.shape == (0, 3)
+    with pytest.raises(mw.MistralWaterError):
+        mw.gerstner_displace(np.zeros((4, 3), np.float32), [(1, 0, 1)] * 17, 0.1, 1.0, 0.5, 0.0)   # > 16 waves
+
+
 def test_errors_on_gpu(mw):
     with pytest.raises(mw.MistralWaterError) as e:
         mw.Ocean(resolution=8192, length=8192.0)
