@@ -135,6 +135,14 @@ mw_status mw_ocean_generate_texture_device(mw_ocean* o, float delta_time, void* 
 mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, const char** names_out,
                                    int32_t* nkernels);
 
+/* ---- test hooks (used by tests/ only; not needed by a host integration) ---------------------------------
+ * mw_debug_omega_t: omega(i,j)*t [N*N, idx = i*N + j] exactly as the kernels form it -- the quantised dispersion
+ * (S/FFTMesh.cs:146,183) is compared bit for bit with the oracle.  mw_debug_get_omega: the stored table in its
+ * transposed [j][i] layout.  mw_debug_sincos: the library's range-reduced sin/cos on n host floats.            */
+mw_status mw_debug_omega_t(mw_ocean* o, float t, float* out_host);
+mw_status mw_debug_get_omega(mw_ocean* o, float* out_host);
+mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host);
+
 /* ---- pond: Gerstner vertex displacement  (W/MistralWaterLib.cginc:71-99,154-180) ---------------
  * pos_xyz/out_xyz [nverts*3] world positions; waves [nwaves*3] = {dir.x, dir.y, speed}; amplitude is
  * the already x0.01-scaled _Amplitude (:172).  out = pos + offsets (:176).  Host pointers, synchronous. */

@@ -148,6 +148,9 @@ MW_HD void prep_element(int N, float length, float gravity, int i, int j, const 
 // correction column cz(i,0) * D'(i,0) through the very same code path and writes it
 // to Cj0, which pass 2 adds to element j = 0 of every row.  The i = 0 correction is one element per
 // column: thread u == 0 carries it in `dl0` (zero for every other thread, so no branch).
+#ifndef MW_NOISE_LDS
+#define MW_NOISE_LDS 1
+#endif
 #ifndef MW_DBUF
 #define MW_DBUF 0  // ping-pong exchange sets: measured no gain at 2x the LDS
 #endif
@@ -301,13 +304,16 @@ struct P2Geom {
     static constexpr int TW_LDS = TwGeom<N, P>::IN_LDS ? ((TwGeom<N, P>::TOTAL + 1) & ~1) : 0;
     static constexpr int SETSTRIDE = (R2 + 1) * BUFSTRIDE;
     static constexpr int NBUF = (MW_DBUF && (TW_LDS + 2 * SETSTRIDE) * 8 <= 100 * 1024) ? 2 : 1;
-    static constexpr int LDS_BYTES = (TW_LDS + NBUF * SETSTRIDE) * (int)sizeof(cf);
+    // the whitecap noise term |0.3 n.xz| waits in LDS (R2*N floats) from the slope field to the epilogue instead of
+    // in P registers per thread: that is what lets pass 2 fit 80 VGPRs without scratch spills
+    static constexpr int NOISE_OFF = TW_LDS + NBUF * SETSTRIDE;  // cf units
+    static constexpr int LDS_BYTES = NOISE_OFF * (int)sizeof(cf) + (MW_NOISE_LDS ? R2 * N * (int)sizeof(float) : 0);
     static_assert(NTHREADS <= 1024, "workgroup too large");
 };
 
 template <int P>
 struct P2State {
-    float noise[P];  // |0.3 n.xz| per slot (S/FFTMesh.cs:269-270)
+    float noise[MW_NOISE_LDS ? 1 : P];  // |0.3 n.xz| per slot (S/FFTMesh.cs:269-270) when it is not parked in LDS
     float h[P];      // height
     cf d[P];         // hds = (d.x, d.z), un-scaled by choppiness (S/FFTMesh.cs:247)
 };
@@ -382,7 +388,7 @@ MW_HD void p2_mid_store(const Twiddles& tw, int tid, int s, cf (&x)[P], cf* lds)
 // final pass in the row-major mapping (thread (g,u) owns row a0+g, columns b = u + T q)
 template <int N, int P, int R2>
 MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int tid, int f, cf (&x)[P], P2State<P>& st,
-                     const cf* lds) {
+                     const cf* lds, float* noise_lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
     load_slots<N, P>(x, u, lds + g * P2Geom<N, P, R2>::BUFSTRIDE);
@@ -401,7 +407,8 @@ MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int 
             nout[3 * b + 1] = ny;
             nout[3 * b + 2] = nz;
             const float n0 = smul(fabsf(nx), 0.3f), n1 = smul(fabsf(nz), 0.3f);
-            st.noise[q] = ssqrt(sadd(smul(n0, n0), smul(n1, n1)));
+            const float nz_ = ssqrt(sadd(smul(n0, n0), smul(n1, n1)));
+            if (MW_NOISE_LDS) noise_lds[g * N + b] = nz_; else st.noise[MW_NOISE_LDS ? 0 : q] = nz_;
         }
     } else if (f == 0) {
 #pragma unroll
@@ -427,7 +434,8 @@ MW_HD void p2_publish_hds(int tid, const P2State<P>& st, cf* lds) {
 
 // S/FFTMesh.cs:243-247 (vertex), :251-276 (Jacobian / whitecap)
 template <int N, int P, int R2>
-MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State<P>& st, const cf* lds) {
+MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State<P>& st, const cf* lds,
+                       const float* noise_lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
     const cf* row = lds + g * P2Geom<N, P, R2>::BUFSTRIDE;
@@ -450,7 +458,8 @@ MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State
         if (has_i) { ax = smul(0.5f, ssub(d.x, dn_i.x)); ay = smul(0.5f, ssub(d.y, dn_i.y)); }  // :260-263
         if (has_j) { bx = smul(0.5f, ssub(d.x, dn_j.x)); by = smul(0.5f, ssub(d.y, dn_j.y)); }  // :264-267
         const float jac = ssub(smul(sadd(1.f, ax), sadd(1.f, by)), smul(ay, bx));          // :268
-        const float turb = fmaxf(sadd(ssub(1.f, jac), st.noise[q]), 0.f);                  // :270
+        const float nz_ = MW_NOISE_LDS ? noise_lds[g * N + b] : st.noise[MW_NOISE_LDS ? 0 : q];
+        const float turb = fmaxf(sadd(ssub(1.f, jac), nz_), 0.f);                          // :270
         const float xx = smoothstep01(turb);                                               // :273
         if (A.white_stride == 1) {
             wout[b] = xx;

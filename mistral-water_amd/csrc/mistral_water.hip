@@ -156,6 +156,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
     if (TwGeom<N, P>::IN_LDS) stage_tables<TwGeom<N, P>::TOTAL, G::NTHREADS>(lds, A.TW, tid);
     const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
     cf* set0 = lds + G::TW_LDS;
+    float* noise_lds = reinterpret_cast<float*>(lds + G::NOISE_OFF);
     int cur = 0;
     P2State<P> st;
     cf x[P];
@@ -188,7 +189,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
             if (f == 2) {
                 float* nout = A.normals + ((size_t)step * N * N + (size_t)a * N) * 3;
 #pragma unroll
-                for (int q = 0; q < P; q++) { const int b = u + T * q; nout[3 * b] = x[q].x; nout[3 * b + 1] = x[q].y; nout[3 * b + 2] = x[q].x; st.noise[q] = x[q].y; }
+                for (int q = 0; q < P; q++) { const int b = u + T * q; nout[3 * b] = x[q].x; nout[3 * b + 1] = x[q].y; nout[3 * b + 2] = x[q].x; noise_lds[g * N + b] = x[q].y; }
             } else if (f == 0) {
 #pragma unroll
                 for (int q = 0; q < P; q++) st.h[q] = x[q].x;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
             __syncthreads();
         }
         MW_STAMP(1, 6 + 8 * k);
-        if (active) p2_finish<N, P, R2>(A, tw, ab, step, tid, f, x, st, set0 + cur * G::SETSTRIDE);
+        if (active) p2_finish<N, P, R2>(A, tw, ab, step, tid, f, x, st, set0 + cur * G::SETSTRIDE, noise_lds);
         if (G::NBUF == 2) cur ^= 1;
         MW_STAMP(1, 7 + 8 * k);
     }
@@ -217,7 +218,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
     if (p2_active<N, P, R2>(ab, tid, 1)) p2_publish_hds<N, P, R2>(tid, st, set0 + cur * G::SETSTRIDE);
     __syncthreads();
     MW_STAMP(1, 26);
-    if (g < R2) p2_epilogue<N, P, R2>(A, ab, step, tid, st, set0 + cur * G::SETSTRIDE);
+    if (g < R2) p2_epilogue<N, P, R2>(A, ab, step, tid, st, set0 + cur * G::SETSTRIDE, noise_lds);
     MW_STAMP(1, 27);
 }
 

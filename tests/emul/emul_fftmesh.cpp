@@ -85,6 +85,7 @@ template <int N, int P, int R2>
 void run_pass2(const P2Args& A, int nsteps) {
     constexpr int T = FftGeom<N, P>::T, NT = P2Geom<N, P, R2>::NTHREADS, BS = P2Geom<N, P, R2>::BUFSTRIDE;
     std::vector<cf> lds((R2 + 1) * BS);
+    std::vector<float> noise((size_t)R2 * N);
     const Twiddles tw = TwGeom<N, P>::view(A.TW);
     struct St { P2State<P> s; cf x[P]; };
     std::vector<St> st(NT);
@@ -102,12 +103,12 @@ void run_pass2(const P2Args& A, int nsteps) {
                 }
                 for (int tid = 0; tid < NT; tid++)
                     if (p2_active<N, P, R2>(ab, tid, f))
-                        p2_finish<N, P, R2>(A, tw, ab, step, tid, f, st[tid].x, st[tid].s, lds.data());
+                        p2_finish<N, P, R2>(A, tw, ab, step, tid, f, st[tid].x, st[tid].s, lds.data(), noise.data());
             }
             for (int tid = 0; tid < NT; tid++)
                 if (p2_active<N, P, R2>(ab, tid, 1)) p2_publish_hds<N, P, R2>(tid, st[tid].s, lds.data());
             for (int tid = 0; tid < NT; tid++)
-                if (tid / T < R2) p2_epilogue<N, P, R2>(A, ab, step, tid, st[tid].s, lds.data());
+                if (tid / T < R2) p2_epilogue<N, P, R2>(A, ab, step, tid, st[tid].s, lds.data(), noise.data());
         }
 }
 
