@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", default="ocean1024", choices=["ocean1024", "ocean4096", "ocean256", "pond"])
+    ap.add_argument("--workload", default="ocean1024", choices=["ocean1024", "ocean4096", "ocean256", "pond", "renderer1024"])
     ap.add_argument("--batch", type=int, default=16, help="time-steps per enqueue (FFTMesh steps are independent in t)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -117,6 +117,8 @@ def main():
 
     if a.workload == "pond":
         return pond(a, mw, torch, dev, stream, barrier, dist, rank, world)
+    if a.workload == "renderer1024":
+        return renderer(a, mw, torch, dev, stream, barrier, dist, rank, world)
 
     N = {"ocean1024": 1024, "ocean4096": 4096, "ocean256": 256}[a.workload]
     NN = N * N
@@ -209,6 +211,42 @@ def main():
     ocean.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):
+    """OceanRenderer semantics at the reference's shipped configuration (D/Ocean Demo.unity:296-302): 1024^2 textures,
+    one GenerateTexture() per step.  The phase is stateful, so steps cannot be batched (F/FFTCommon.cginc:101-104).
+    Algorithmic bytes per texel: 20 (spectrum + phase in) + 4 (phase out) + 24 + 24 (exchange) + 16 (height, disp.rgb out)
+    + 16 (re-read by the normal/whitecap passes) + 16 (normal, white out) = 120."""
+    import ctypes as C
+    from mistral_water import _native as nat
+    o = mw.Ocean(resolution=128, length=434.48, wind=(14.45, 12.0), amplitude=0.41, choppiness=0.46, mult=1.5,
+                 seed=1 + rank, semantics=mw.MW_SEM_OCEANRENDERER, device=dev.index)
+    o.set_stream(stream.cuda_stream)
+    M = o.N
+
+    def step():
+        nat.check(nat.lib().mw_ocean_generate_texture_device(o.handle, C.c_float(1.0 / 60.0), None, None, None, None))
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    barrier()
+    if rank == 0:
+        v = world * a.steps * M * M / el
+        print(json.dumps({
+            "metric": "OceanRenderer-semantics texels/sec (dispersion+spectrum -> 2-D Stockham -> normal -> whitecap), 1024^2",
+            "value": v, "unit": "texels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": {"workload": "OceanRenderer GenerateTexture(), 1024x1024 textures, shipped demo parameters",
+                                            "semantics": "MW_SEM_OCEANRENDERER"},
+            "roofline": {"bound": "hbm", "kernel": "whole frame (4 kernels)", "achieved": v * 120 / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": v * 120 / HBM_PEAK, "traffic": None}, "cpu_baseline": None}))
+    o.close()
 
 
 def pond(a, mw, torch, dev, stream, barrier, dist, rank, world):

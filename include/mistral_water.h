@@ -142,6 +142,8 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
 mw_status mw_debug_omega_t(mw_ocean* o, float t, float* out_host);
 mw_status mw_debug_get_omega(mw_ocean* o, float* out_host);
 mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host);
+/* streams `bytes` of device memory through `width`-byte per-lane loads (4, 8 or 16): FETCH_SIZE calibration */
+mw_status mw_debug_stream_read(int64_t bytes, int32_t width, int32_t iters);
 
 /* ---- pond: Gerstner vertex displacement  (W/MistralWaterLib.cginc:71-99,154-180) ---------------
  * pos_xyz/out_xyz [nverts*3] world positions; waves [nwaves*3] = {dir.x, dir.y, speed}; amplitude is

@@ -151,7 +151,17 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
     using G = P2Geom<N, P, R2>;
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = FftGeom<N, P>::T;
-    const int tid = threadIdx.x, ab = blockIdx.x, step = blockIdx.y;
+    const int tid = threadIdx.x, step = blockIdx.y;
+    // XCD-aware row-block mapping: the dispatcher places block b on XCD b % 8 (speed only, never correctness); giving
+    // each XCD a contiguous range of row blocks makes a block's halo row (the first row of the NEXT block) a hit in
+    // the same XCD's L2 instead of a second 128-B line fill across the fabric.
+    constexpr int NBLK = N / R2;
+#ifndef MW_XCD_GROUP
+#define MW_XCD_GROUP 1  // adjacent row blocks kept on one XCD (1 = plain round-robin)
+#endif
+    constexpr int XG = MW_XCD_GROUP;
+    const int xcd = blockIdx.x % 8, cidx = blockIdx.x / 8;
+    const int ab = (XG > 1 && NBLK % (8 * XG) == 0) ? (cidx / XG) * (8 * XG) + xcd * XG + (cidx % XG) : (int)blockIdx.x;
     const int g = tid / T;
     if (TwGeom<N, P>::IN_LDS) stage_tables<TwGeom<N, P>::TOTAL, G::NTHREADS>(lds, A.TW, tid);
     const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
@@ -412,6 +422,18 @@ static mw_status run_prep(mw_ocean* o) {
     }
     if (o->ev_inputs) HIP_TRY(hipEventRecord(o->ev_inputs, o->stream));
     return MW_OK;
+}
+
+// FETCH_SIZE calibration streams (MI355X_MICROARCH.md "HBM": calibrate the counter on a known byte count in your own
+// access width): every lane reads `width` bytes, lanes contiguous, `bytes` in total; one float per block is written.
+template <typename V>
+__global__ void k_dbg_stream(const V* __restrict__ src, size_t n, float* sink) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        V v = src[i];
+        acc += reinterpret_cast<const float*>(&v)[0];
+    }
+    if (acc == 123.456f) sink[blockIdx.x] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -805,6 +827,23 @@ mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* 
     hipFree(dx); hipFree(ds); hipFree(dc);
     return MW_OK;
 }
+mw_status mw_debug_stream_read(int64_t bytes, int32_t width, int32_t iters) {
+    void* buf = nullptr;
+    float* sink = nullptr;
+    HIP_TRY(hipMalloc(&buf, (size_t)bytes));
+    HIP_TRY(hipMalloc((void**)&sink, 4 * 4096));
+    HIP_TRY(hipMemset(buf, 0, (size_t)bytes));
+    for (int it = 0; it < iters; it++) {
+        if (width == 4) k_dbg_stream<float><<<2048, 256>>>((const float*)buf, (size_t)bytes / 4, sink);
+        else if (width == 8) k_dbg_stream<cf><<<2048, 256>>>((const cf*)buf, (size_t)bytes / 8, sink);
+        else k_dbg_stream<f4><<<2048, 256>>>((const f4*)buf, (size_t)bytes / 16, sink);
+    }
+    hipError_t e = hipDeviceSynchronize();
+    hipFree(buf);
+    hipFree(sink);
+    return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, "stream_read failed");
+}
+
 mw_status mw_debug_get_omega(mw_ocean* o, float* out_host) {  // [j][i] layout
     if (!o || !o->Om) return fail(MW_EINVAL, "no omega table");
     HIP_TRY(hipMemcpy(out_host, o->Om, sizeof(float) * o->N * o->N, hipMemcpyDeviceToHost));

@@ -99,6 +99,7 @@ def lib():
         "mw_debug_omega_t": (C.c_int, [vp, C.c_float, f32p]),
         "mw_debug_get_omega": (C.c_int, [vp, f32p]),
         "mw_debug_sincos": (C.c_int, [f32p, C.c_int32, f32p, f32p]),
+        "mw_debug_stream_read": (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = ABI symbol missing: fail loudly
@@ -116,7 +117,7 @@ ABI_SYMBOLS = [
     "mw_ocean_grid_size", "mw_ocean_evaluate", "mw_ocean_update", "mw_ocean_timer", "mw_ocean_reset_timer",
     "mw_ocean_evaluate_device", "mw_ocean_max_batch", "mw_ocean_generate_texture",
     "mw_ocean_generate_texture_device", "mw_ocean_profile_kernels", "mw_gerstner_displace",
-    "mw_gerstner_displace_device", "mw_debug_omega_t", "mw_debug_get_omega", "mw_debug_sincos",
+    "mw_gerstner_displace_device", "mw_debug_omega_t", "mw_debug_get_omega", "mw_debug_sincos", "mw_debug_stream_read",
 ]
 
 
