@@ -28,6 +28,17 @@ struct StepTimes {
 };
 
 MW_HD void mw_sincos(float x, float* s, float* c) { sincos_f32(x, s, c); }
+// A value that is the same in every lane of a wave (e.g. tid / T when T is a multiple of 64): telling the compiler
+// lets it keep the value -- and every pointer derived from it -- in SGPRs, so global accesses use the
+// `saddr + 32-bit voffset` form instead of one 64-bit VGPR address pair per access.
+template <bool WAVE_UNIFORM>
+MW_HD int wave_uniform(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return WAVE_UNIFORM ? __builtin_amdgcn_readfirstlane(v) : v;
+#else
+    return v;
+#endif
+}
 MW_HD float mw_rsqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __frsqrt_rn(x);
@@ -216,17 +227,17 @@ MW_HD bool p1_field_active(int N, int jb, int f) { return f != 0 || jb <= N / 8;
 template <int N, int P>
 MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, P1State<P>& st) {
     constexpr int T = FftGeom<N, P>::T;
-    const int w = tid / T, u = tid % T;
+    const int w = wave_uniform<(T % 64) == 0>(tid / T), u = tid % T;
     const bool fix = (jb == N / 4);
     const int j = fix ? 0 : 4 * jb + w;
-    const f4* __restrict__ pqrow = fix ? A.dPQ_j0 + u : A.PQt + (size_t)j * N + u;
-    const float* __restrict__ omrow = A.Om + (size_t)j * N + u;
+    const f4* __restrict__ pqrow = fix ? A.dPQ_j0 : A.PQt + (size_t)j * N;  // wave-uniform row base
+    const float* __restrict__ omrow = A.Om + (size_t)j * N;
     const bool live = !fix || w == 0;
 #pragma unroll
     for (int q = 0; q < P; q++) {
-        f4 pq = pqrow[T * q];
+        f4 pq = (pqrow + T * q)[(unsigned)u];
         float s, c;
-        mw_sincos(smul(omrow[T * q], t), &s, &c);  // omega*t: one f32 multiply, S/FFTMesh.cs:183
+        mw_sincos(smul((omrow + T * q)[(unsigned)u], t), &s, &c);  // omega*t: one f32 multiply, S/FFTMesh.cs:183
         cf h = animate(pq.x, pq.y, pq.z, pq.w, c, s);
         st.hh[q] = live ? h : mk(0.f, 0.f);
     }
@@ -277,9 +288,10 @@ MW_HD void p1_finish(const P1Args& A, const Twiddles& tw, int jb, int step, int 
         }
         return;
     }
-    cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)jb * N * 4;
+    cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)jb * N * 4;  // block-uniform
+    const unsigned voff = (unsigned)(u2 * 4 + w2);
 #pragma unroll
-    for (int q = 0; q < P; q++) Ef[(size_t)(u2 + T * q) * 4 + w2] = x[q];
+    for (int q = 0; q < P; q++) (Ef + (size_t)T * q * 4)[voff] = x[q];
 }
 
 // =============================== pass 2: transform along j + epilogue ========================
@@ -345,16 +357,20 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
     constexpr int T = FftGeom<N, P>::T;
     int r1, u1;
     p2_load_map<N, P, R2>(tid, &r1, &u1);
-    const cf* Ef = A.E + ((size_t)step * 3 + f) * N * N;
     const int row = ab * R2 + r1;
+    const cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * 4;  // block-uniform base (first row of the block)
+    // per-lane 32-bit offset of element j = u1 (slot q adds the uniform T*q/4 chunks of N*4)
+    const unsigned voff = (unsigned)(((u1 >> 2) * N + r1) * 4 + (u1 & 3));
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int j = u1 + T * q;
         if (f == 0 && j > N / 2) {  // height: stored for j <= N/2 only; T(a, j) = conj T(a, N - j)
             const int m = N - j;
-            x[q] = cconj(Ef[((size_t)(m >> 2) * N + row) * 4 + (m & 3)]);
+            x[q] = cconj(Ef[(unsigned)(((m >> 2) * N + r1) * 4 + (m & 3))]);
+        } else if (T % 4 == 0) {
+            x[q] = (Ef + (size_t)(T / 4) * q * N * 4)[voff];
         } else {
-            x[q] = Ef[((size_t)(j >> 2) * N + row) * 4 + (j & 3)];
+            x[q] = Ef[(unsigned)(((j >> 2) * N + r1) * 4 + (j & 3))];
         }
     }
     if (u1 == 0 && f != 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];  // Nyquist column j = 0
@@ -394,18 +410,20 @@ MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int 
     load_slots<N, P>(x, u, lds + g * P2Geom<N, P, R2>::BUFSTRIDE);
     final_stage<N, P, +1>(x, u, tw.TF);
     if (f == 2) {  // slopes -> unit normal (S/FFTMesh.cs:218), stored at once
-        float* nout = A.normals + ((size_t)step * N * N + (size_t)a * N) * 3;
+        float* nblk = A.normals + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;  // block-uniform
+        const unsigned noff = (unsigned)((g * N + u) * 3);
 #pragma unroll
         for (int q = 0; q < P; q++) {
             const int b = u + T * q;
+            float* nq = nblk + (size_t)T * q * 3;  // uniform; element (g, b, c) = nq[noff + c]
             const float sg = post_sign(a, b);
             const float sx = sg * x[q].x, sz = sg * x[q].y;
             // Vector3.Normalize(up - n): |(sx,1,sz)| >= 1, so Unity's 1e-5 zero-guard never fires
             const float inv = mw_rsqrt(sx * sx + 1.0f + sz * sz);
             const float nx = sx * inv, ny = inv, nz = sz * inv;
-            nout[3 * b + 0] = nx;
-            nout[3 * b + 1] = ny;
-            nout[3 * b + 2] = nz;
+            nq[noff + 0] = nx;
+            nq[noff + 1] = ny;
+            nq[noff + 2] = nz;
             const float n0 = smul(fabsf(nx), 0.3f), n1 = smul(fabsf(nz), 0.3f);
             const float nz_ = ssqrt(sadd(smul(n0, n0), smul(n1, n1)));
             if (MW_NOISE_LDS) noise_lds[g * N + b] = nz_; else st.noise[MW_NOISE_LDS ? 0 : q] = nz_;
@@ -440,8 +458,9 @@ MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
     const cf* row = lds + g * P2Geom<N, P, R2>::BUFSTRIDE;
     const cf* nxt = lds + (g + 1) * P2Geom<N, P, R2>::BUFSTRIDE;
-    float* vout = A.vertices + ((size_t)step * N * N + (size_t)a * N) * 3;
-    float* wout = A.white + ((size_t)step * N * N + (size_t)a * N) * A.white_stride;
+    float* vblk = A.vertices + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;          // block-uniform
+    float* wblk = A.white + ((size_t)step * N * N + (size_t)ab * R2 * N) * A.white_stride;
+    const unsigned voff = (unsigned)((g * N + u) * 3), woff = (unsigned)((g * N + u) * A.white_stride);
     const float rx = rest_coord(N, A.c.unit_width, a);
     const bool has_i = (a != N - 1);
 #pragma unroll
@@ -451,9 +470,11 @@ MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State
         const cf d = st.d[q];
         const cf dn_i = has_i ? nxt[b] : mk(0.f, 0.f);
         const cf dn_j = has_j ? row[b + 1] : mk(0.f, 0.f);
-        vout[3 * b + 0] = ssub(rx, smul(d.x, A.c.choppiness));                             // :245
-        vout[3 * b + 1] = st.h[q];                                                         // :243
-        vout[3 * b + 2] = ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness));  // :244
+        float* vq = vblk + (size_t)T * q * 3;                                              // uniform
+        float* wq = wblk + (size_t)T * q * A.white_stride;
+        vq[voff + 0] = ssub(rx, smul(d.x, A.c.choppiness));                                // :245
+        vq[voff + 1] = st.h[q];                                                            // :243
+        vq[voff + 2] = ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness));  // :244
         float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
         if (has_i) { ax = smul(0.5f, ssub(d.x, dn_i.x)); ay = smul(0.5f, ssub(d.y, dn_i.y)); }  // :260-263
         if (has_j) { bx = smul(0.5f, ssub(d.x, dn_j.x)); by = smul(0.5f, ssub(d.y, dn_j.y)); }  // :264-267
@@ -462,10 +483,13 @@ MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State
         const float turb = fmaxf(sadd(ssub(1.f, jac), nz_), 0.f);                          // :270
         const float xx = smoothstep01(turb);                                               // :273
         if (A.white_stride == 1) {
-            wout[b] = xx;
+            wq[woff] = xx;
         } else {
-            wout[4 * b + 0] = xx; wout[4 * b + 1] = xx; wout[4 * b + 2] = xx; wout[4 * b + 3] = xx;  // :274
+            wq[woff + 0] = xx; wq[woff + 1] = xx; wq[woff + 2] = xx; wq[woff + 3] = xx;  // :274
         }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MW_EPILOGUE_FENCE)
+        __builtin_amdgcn_sched_barrier(0);  // keep the q iterations apart: fewer live temporaries
+#endif
     }
 }
 
@@ -473,8 +497,16 @@ MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State
 #ifndef MW_PT
 #define MW_PT 8
 #endif
+#ifndef MW_PT1
+#define MW_PT1 16  // pass 1: 16 points/thread (one exchange fewer; 125 VGPRs, 4 workgroups of 4 waves per CU) measured 1 % ahead of 8
+#endif
+#ifndef MW_PT2
+#define MW_PT2 MW_PT  // pass 2 (the exchange-buffer layout does not depend on P, so the passes may differ)
+#endif
 template <int N> struct Plan {
-    static constexpr int P = (N >= 2048) ? 16 : MW_PT;  // 5 x N/8 threads would exceed 1024 at N = 2048
+    static constexpr int P = (N >= 2048) ? 16 : MW_PT;    // OceanRenderer passes
+    static constexpr int P1 = (N >= 2048) ? 16 : MW_PT1;  // 5 x N/8 threads would exceed 1024 at N = 2048
+    static constexpr int P2 = (N >= 2048) ? 16 : MW_PT2;
     static constexpr int R2 = (N >= 4096) ? 2 : 4;
 };
 

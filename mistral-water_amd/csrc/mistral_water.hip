@@ -253,7 +253,7 @@ struct mw_ocean {
     cf *h0 = nullptr, *h0c = nullptr;
     f4 *PQt = nullptr, *dPQ_i0 = nullptr, *dPQ_j0 = nullptr;
     float* Om = nullptr;
-    cf *TW = nullptr, *Wpre = nullptr;
+    cf *TW = nullptr, *TW2 = nullptr, *Wpre = nullptr;  // twiddle tables of pass 1 / pass 2
     cf *E = nullptr, *Cj0 = nullptr;
     int e_cap = 0;  // steps the exchange buffer holds
     float *s_vert = nullptr, *s_norm = nullptr, *s_white = nullptr;  // 1-step scratch for the host API
@@ -271,7 +271,7 @@ static mw_status dmalloc(T** p, size_t count) {
 }
 
 // host-side geometry mirror of FftGeom<N,P> / Plan<N>
-static int plan_points(int N) { return N >= 2048 ? 16 : MW_PT; }
+static int plan_points(int N, int pass) { return N >= 2048 ? 16 : (pass == 1 ? MW_PT1 : MW_PT2); }
 
 // concatenated twiddle table [TS1 | TS2 | TS3 | TF] in the layout of TwGeom<N,P>
 namespace mw {
@@ -304,8 +304,9 @@ std::vector<cf> build_twiddle_table(int N, int P, int sgn) {
 }  // namespace mw
 
 static mw_status upload_twiddles(mw_ocean* o) {
-    const int N = o->N, P = plan_points(N);
-    std::vector<cf> tab = build_twiddle_table(N, P, +1), Wpre(2 * N);
+    const int N = o->N;
+    std::vector<cf> tab = build_twiddle_table(N, plan_points(N, 1), +1), tab2 = build_twiddle_table(N, plan_points(N, 2), +1);
+    std::vector<cf> Wpre(2 * N);
     for (int m = 0; m < 2 * N; m++) {
         double a = M_PI * (double)m / (double)N;  // (-1)^m e^{i pi m/N}
         double sg = (m & 1) ? -1.0 : 1.0;
@@ -313,8 +314,10 @@ static mw_status upload_twiddles(mw_ocean* o) {
     }
     mw_status st;
     if ((st = dmalloc(&o->TW, tab.size())) != MW_OK) return st;
+    if ((st = dmalloc(&o->TW2, tab2.size())) != MW_OK) return st;
     if ((st = dmalloc(&o->Wpre, 2 * N)) != MW_OK) return st;
     HIP_TRY(hipMemcpy(o->TW, tab.data(), sizeof(cf) * tab.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(o->TW2, tab2.data(), sizeof(cf) * tab2.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(o->Wpre, Wpre.data(), sizeof(cf) * 2 * N, hipMemcpyHostToDevice));
     return MW_OK;
 }
@@ -332,7 +335,7 @@ static OceanConsts consts_of(const mw_ocean* o) {
 // ---- kernel dispatch over N ----------------------------------------------------------------------
 template <int N>
 static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nsteps, hipStream_t st) {
-    constexpr int P = Plan<N>::P;
+    constexpr int P = Plan<N>::P1;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<N, P>),
@@ -346,7 +349,7 @@ static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nstep
 }
 template <int N>
 static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
-    constexpr int P = Plan<N>::P, R2 = Plan<N>::R2;
+    constexpr int P = Plan<N>::P2, R2 = Plan<N>::R2;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<N, P, R2>),
@@ -386,7 +389,7 @@ static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipS
 }
 static mw_status launch_pass2(mw_ocean* o, int nsteps, float* dv, float* dn, float* dw, int white_stride, int r) {
     P2Args A;
-    A.E = region_E(o, r); A.Cj0 = region_C(o, r); A.TW = o->TW; A.vertices = dv; A.normals = dn; A.white = dw; A.white_stride = white_stride;
+    A.E = region_E(o, r); A.Cj0 = region_C(o, r); A.TW = o->TW2; A.vertices = dv; A.normals = dn; A.white = dw; A.white_stride = white_stride;
     A.c = consts_of(o);
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass2_n<NN>(A, nsteps, o->stream));
@@ -470,7 +473,7 @@ void mw_ocean_destroy(mw_ocean* o) {
     hipSetDevice(o->device);
     if (o->stream) hipStreamSynchronize(o->stream);
     hipFree(o->h0); hipFree(o->h0c); hipFree(o->PQt); hipFree(o->Om); hipFree(o->dPQ_i0); hipFree(o->dPQ_j0);
-    hipFree(o->TW); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white);
+    hipFree(o->TW); hipFree(o->TW2); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white);
     direct_free(o->direct);
     or_free(o->orr);
     if (o->aux_stream) { hipStreamSynchronize(o->aux_stream); hipStreamDestroy(o->aux_stream); }
