@@ -287,14 +287,14 @@ std::vector<cf> build_twiddle_table(int N, int P, int sgn) {
         long long p = 1;
         for (int i = 0; i < s; i++) p *= P;
         for (long long k = 0; k < p; k++)
-            for (int r = 0; r < P; r++) {
-                double a = sgn * 2.0 * M_PI * (double)(r * k) / (double)(p * P);
+            for (int r = 0; r < P + 1; r++) {  // row stride P+1 (one pad entry): see Twiddles in mw_math.h
+                double a = sgn * 2.0 * M_PI * (double)((r % P) * k) / (double)(p * P);
                 tab.push_back(mk((float)cos(a), (float)sin(a)));
             }
     }
     if (RL > 1)
-        for (int u = 0; u < T; u++)
-            for (int r = 0; r < RL; r++) {
+        for (int r = 0; r < RL; r++)
+            for (int u = 0; u < T; u++) {
                 double a = sgn * 2.0 * M_PI * (double)(r * u) / (double)N;
                 tab.push_back(mk((float)cos(a), (float)sin(a)));
             }

@@ -276,10 +276,12 @@ template <int SGN> struct DftP<16, SGN> {
 };
 
 // Twiddle tables (built on the host in double, rounded once to f32; SGN baked in):
-//   TS[s][k*P + r] = e^{SGN 2 pi i r k / P^(s+1)}   k < P^s, r < P   (radix-P pass s >= 1, p = P^s)
-//   TF[u*RL + r]   = e^{SGN 2 pi i r u / N}         u < T,  r < RL   (final pass; the remaining factor
-//                    e^{SGN 2 pi i r m / P} of thread u's m-th butterfly is a compile-time rotation)
-// Each thread reads one contiguous run per pass (vector loads, one address register).
+//   TS[s][k*(P+1) + r] = e^{SGN 2 pi i r k / P^(s+1)}   k < P^s, r < P   (radix-P pass s >= 1, p = P^s)
+//   TF[r*T + u]        = e^{SGN 2 pi i r u / N}         u < T,  r < RL   (final pass; the remaining factor
+//                        e^{SGN 2 pi i r m / P} of thread u's m-th butterfly is a compile-time rotation)
+// Each thread reads one contiguous run of TS per pass.  Rows are P+1 apart (odd stride) and TF is r-major so that,
+// when the tables sit in LDS, the lanes of a wave (16 distinct k, consecutive u) fall on distinct banks: with the
+// natural P-stride all 16 rows of a radix-16 pass land on two bank groups (an 8-way conflict on every read).
 struct Twiddles {
     const cf* TS[4];
     const cf* TF;
@@ -288,7 +290,7 @@ struct Twiddles {
 template <int N, int P>
 struct TwGeom {
     static constexpr int S = FftGeom<N, P>::S;
-    static constexpr int size_ts(int s) { return (s >= 1 && s < S) ? mw_ipow(P, s + 1) : 0; }
+    static constexpr int size_ts(int s) { return (s >= 1 && s < S) ? mw_ipow(P, s) * (P + 1) : 0; }
     static constexpr int OFF1 = 0;
     static constexpr int OFF2 = OFF1 + size_ts(1);
     static constexpr int OFF3 = OFF2 + size_ts(2);
@@ -341,7 +343,7 @@ template <int N, int P, int SGN>
 MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
     const int p = 1 << (LogP<P>::v * s);
     const int k = u & (p - 1);
-    const cf* __restrict__ row = tw.TS[s] + k * P;
+    const cf* __restrict__ row = tw.TS[s] + k * (P + 1);
 #pragma unroll
     for (int r = 1; r < P; r++) x[r] = cmul(x[r], row[r]);
     DftP<P, SGN>::run(x);
@@ -360,7 +362,7 @@ MW_HD void final_stage(cf (&x)[P], int u, const cf* __restrict__ TF) {
     if (RL == 1) return;
     cf tw[RL];
 #pragma unroll
-    for (int r = 1; r < RL; r++) tw[r] = TF[u * RL + r];
+    for (int r = 1; r < RL; r++) tw[r] = TF[r * FftGeom<N, P>::T + u];
 #pragma unroll
     for (int m = 0; m < NB; m++) {
 #pragma unroll
