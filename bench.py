@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="ocean1024", choices=["ocean1024", "ocean4096", "ocean256", "pond", "renderer1024"])
-    ap.add_argument("--batch", type=int, default=16, help="time-steps per enqueue (FFTMesh steps are independent in t)")
+    ap.add_argument("--batch", type=int, default=32, help="time-steps per enqueue (FFTMesh steps are independent in t)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the last step's tiles (configs[2])")

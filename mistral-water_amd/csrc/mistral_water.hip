@@ -247,7 +247,8 @@ struct mw_ocean {
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_full[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_inputs = nullptr;
     int region = 0;
-    bool pipeline = false;  // MW_PIPELINE=1: measured neutral at 1024^2, kept as an option
+    bool pipeline = false;  // MW_PIPELINE=1: +1.5-2 % at 1024^2 (hides the inter-kernel tail/ramp); off by default so
+                            // that per-kernel durations in a profile are not stretched by the overlap
     float timer = 0.f;
     // FFTMesh state
     cf *h0 = nullptr, *h0c = nullptr;
