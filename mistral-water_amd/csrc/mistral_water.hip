@@ -337,12 +337,14 @@ static OceanConsts consts_of(const mw_ocean* o) {
 template <int N>
 static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nsteps, hipStream_t st) {
     constexpr int P = Plan<N>::P1;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {false};  // per device: the attribute belongs to the function on the current device
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (!attr_done[dev & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<N, P>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, P1Geom<N, P>::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[dev & 63] = true;
     }
     constexpr int NT = P1Geom<N, P>::NTHREADS, LB = P1Geom<N, P>::LDS_BYTES, GX = P1Geom<N, P>::GRID_X;
     k_pass1<N, P><<<dim3(GX, nsteps), dim3(NT), LB, st>>>(A, tm);
@@ -351,12 +353,14 @@ static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nstep
 template <int N>
 static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     constexpr int P = Plan<N>::P2, R2 = Plan<N>::R2;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {false};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (!attr_done[dev & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<N, P, R2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, P2Geom<N, P, R2>::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[dev & 63] = true;
     }
     constexpr int NT = P2Geom<N, P, R2>::NTHREADS, LB = P2Geom<N, P, R2>::LDS_BYTES;
     k_pass2<N, P, R2><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);

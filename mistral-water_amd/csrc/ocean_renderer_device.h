@@ -154,7 +154,10 @@ static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStre
 template <int N>
 static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
     constexpr int P = Plan<N>::P;
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {false};
+    int dev = 0;
+    hipGetDevice(&dev);
+    bool& attr_done = attr_done_dev[dev & 63];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_or_pass1<N, P>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, OrP1Geom<N, P>::LDS_BYTES);
