@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", default="ocean1024", choices=["ocean1024", "ocean4096", "ocean256", "pond", "renderer1024"])
+    ap.add_argument("--workload", default="ocean1024", choices=["ocean1024", "ocean4096", "ocean2048", "ocean512", "ocean256", "pond", "renderer1024"])
     ap.add_argument("--batch", type=int, default=32, help="time-steps per enqueue (FFTMesh steps are independent in t)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -120,7 +120,7 @@ def main():
     if a.workload == "renderer1024":
         return renderer(a, mw, torch, dev, stream, barrier, dist, rank, world)
 
-    N = {"ocean1024": 1024, "ocean4096": 4096, "ocean256": 256}[a.workload]
+    N = {"ocean1024": 1024, "ocean4096": 4096, "ocean2048": 2048, "ocean512": 512, "ocean256": 256}[a.workload]
     NN = N * N
     p = workloads.fftmesh_params(N)
     seed = 1 + rank
