@@ -174,7 +174,26 @@ struct P1Args {
     cf* E;             // exchange buffer [step][3][N/4][N][4]
     cf* Cj0;           // [step][3][N]  transform of the j = 0 correction column
     OceanConsts c;
+    int tgroup;        // > 0: 1-D grid, `tgroup` time-steps of one column job kept on one XCD (p1_block_map)
+    int nsteps;
 };
+
+// Pass-1 block -> (column job, time-step).  All time-steps of a batch read the same PQt/Om rows, so the tgroup
+// steps of one column job are issued back to back on ONE XCD (the dispatcher places block b on XCD b % 8): the
+// first of them pulls the rows into that XCD's L2 and the others hit there instead of crossing the fabric again.
+// Speed only -- any bijection is correct.  Returns false for the padding blocks of the rounded-up grid.
+MW_HD bool p1_block_map(int bid, int gx, int nsteps, int tgroup, int* jb, int* step) {
+    const int xcd = bid % 8, slot = bid / 8;
+    const int gg = (slot / tgroup) * 8 + xcd, m = slot % tgroup;
+    if (gg >= gx * (nsteps / tgroup)) return false;
+    *jb = gg % gx;
+    *step = (gg / gx) * tgroup + m;
+    return true;
+}
+MW_HD int p1_grid_blocks(int gx, int nsteps, int tgroup) {
+    const int groups = gx * (nsteps / tgroup);
+    return ((groups + 7) / 8) * 8 * tgroup;
+}
 
 template <int N, int P>
 struct P1Geom {

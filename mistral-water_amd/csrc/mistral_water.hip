@@ -100,7 +100,9 @@ __global__ __launch_bounds__((P1Geom<N, P>::NTHREADS)) __attribute__((amdgpu_wav
     using G = P1Geom<N, P>;
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = FftGeom<N, P>::T;
-    const int tid = threadIdx.x, jb = blockIdx.x, step = blockIdx.y;
+    const int tid = threadIdx.x;
+    int jb = blockIdx.x, step = blockIdx.y;
+    if (A.tgroup > 0 && !p1_block_map((int)blockIdx.x, G::GRID_X, A.nsteps, A.tgroup, &jb, &step)) return;
     const float t = times.t[step];
     const int w = tid / T, u = tid % T;
     if (TwGeom<N, P>::IN_LDS) stage_tables<TwGeom<N, P>::TOTAL, G::NTHREADS>(lds, A.TW, tid);  // visible after the first barrier
@@ -247,6 +249,8 @@ struct mw_ocean {
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_full[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_inputs = nullptr;
     int region = 0;
+    int p1_tgroup = 8;  // time-steps of one pass-1 column job grouped on one XCD (p1_block_map): -25 % pass-1 time;
+                        // env MW_P1_TGROUP overrides (0 = plain 2-D grid)
     bool pipeline = false;  // MW_PIPELINE=1: +1.5-2 % at 1024^2 (hides the inter-kernel tail/ramp); off by default so
                             // that per-kernel durations in a profile are not stretched by the overlap
     float timer = 0.f;
@@ -347,7 +351,10 @@ static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nstep
         attr_done[dev & 63] = true;
     }
     constexpr int NT = P1Geom<N, P>::NTHREADS, LB = P1Geom<N, P>::LDS_BYTES, GX = P1Geom<N, P>::GRID_X;
-    k_pass1<N, P><<<dim3(GX, nsteps), dim3(NT), LB, st>>>(A, tm);
+    if (A.tgroup > 0)
+        k_pass1<N, P><<<dim3(p1_grid_blocks(GX, nsteps, A.tgroup)), dim3(NT), LB, st>>>(A, tm);
+    else
+        k_pass1<N, P><<<dim3(GX, nsteps), dim3(NT), LB, st>>>(A, tm);
     return hipGetLastError();
 }
 template <int N>
@@ -387,6 +394,10 @@ static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipS
     A.PQt = o->PQt; A.dPQ_i0 = o->dPQ_i0; A.dPQ_j0 = o->dPQ_j0; A.Om = o->Om; A.TW = o->TW;
     A.E = region_E(o, r); A.Cj0 = region_C(o, r);
     A.c = consts_of(o);
+    A.nsteps = nsteps;
+    A.tgroup = 0;
+    for (int g = o->p1_tgroup; g > 1; g >>= 1)
+        if (nsteps % g == 0) { A.tgroup = g; break; }
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass1_n<NN>(A, tm, nsteps, st));
     if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pass1 launch: ") + hipGetErrorString(e));
@@ -523,6 +534,7 @@ mw_status mw_ocean_create(const mw_params* params, mw_ocean** out) {
     }
     hipEventCreateWithFlags(&o->ev_inputs, hipEventDisableTiming);
     if (const char* e = std::getenv("MW_PIPELINE")) o->pipeline = (e[0] != '0');
+    if (const char* e = std::getenv("MW_P1_TGROUP")) o->p1_tgroup = std::atoi(e);
 
     if (o->sem == MW_SEM_FFTMESH) {
         const int N = params->resolution;

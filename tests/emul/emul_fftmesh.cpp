@@ -316,4 +316,10 @@ void emul_gerstner(const float* pos, long nverts, const float* waves, int nwaves
                         &out[3 * v + 1], &out[3 * v + 2]);
 }
 
+// pass-1 block mapping (speed-only remap; must be a bijection onto (column job, step) plus padding blocks)
+int emul_p1_block_map(int bid, int gx, int nsteps, int tgroup, int* jb, int* step) {
+    return p1_block_map(bid, gx, nsteps, tgroup, jb, step) ? 1 : 0;
+}
+int emul_p1_grid_blocks(int gx, int nsteps, int tgroup) { return p1_grid_blocks(gx, nsteps, tgroup); }
+
 }  // extern "C"

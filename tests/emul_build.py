@@ -88,6 +88,16 @@ class Emul:
         assert r == 0
         return h, d, n, w, g
 
+    def p1_block_map(self, gx, nsteps, tgroup):
+        """-> list of (jb, step) or None (padding block) for every block of the 1-D pass-1 grid."""
+        nb = self.L.emul_p1_grid_blocks(gx, nsteps, tgroup)
+        jb, st = C.c_int(), C.c_int()
+        out = []
+        for b in range(nb):
+            ok = self.L.emul_p1_block_map(b, gx, nsteps, tgroup, C.byref(jb), C.byref(st))
+            out.append((jb.value, st.value) if ok else None)
+        return out
+
     def gerstner(self, pos, waves, amplitude, frequency, steepness, t):
         pos = np.ascontiguousarray(pos, np.float32)
         wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)

@@ -128,3 +128,19 @@ def test_gerstner_vs_oracle(emul, oracle):
         oz += np.cos(th) * np.float32(P["steepness"]) * np.float32(P["amplitude"]) * np.float32(dy)
         oy += np.float32(P["amplitude"]) * np.sin(th)
     assert np.abs(want - np.stack([ox, oy, oz], 1)).max() < 1e-6
+
+
+@pytest.mark.parametrize("gx,nsteps,tgroup", [(257, 32, 8), (257, 8, 4), (17, 4, 2), (65, 16, 8), (1025, 2, 2)])
+def test_pass1_time_group_block_map_is_a_bijection(emul, gx, nsteps, tgroup):
+    blocks = emul.p1_block_map(gx, nsteps, tgroup)
+    live = [b for b in blocks if b is not None]
+    assert sorted(live) == [(jb, s) for jb in range(gx) for s in range(nsteps)]
+    assert len(blocks) - len(live) < 8 * tgroup
+    # the tgroup steps of one column job sit in consecutive slots of one XCD
+    for b, v in enumerate(blocks):
+        if v is None:
+            continue
+        slot, xcd = b // 8, b % 8
+        if slot % tgroup:
+            prev = blocks[(slot - 1) * 8 + xcd]
+            assert prev == (v[0], v[1] - 1)

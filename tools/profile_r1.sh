@@ -6,9 +6,9 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$1
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py --steps 400 --no-cpu-baseline > $OUT/bench_stdout.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py --steps 1600 --no-cpu-baseline > $OUT/bench_stdout.txt 2>&1
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr " " "_" | cut -c1-28)
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$tag -o pmc -- python bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-parity > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$tag -o pmc -- python bench.py --steps 64 --warmup 32 --preheat-ms 0 --no-cpu-baseline --no-parity > /dev/null 2>&1
 done
 find $OUT -name "*.csv" | head -40
