@@ -156,6 +156,27 @@ mw_status mw_gerstner_displace_device(const void* d_pos_xyz, int64_t nverts, con
                                       float amplitude, float frequency, float steepness, float t, void* d_out_xyz,
                                       void* hip_stream);
 
+/* ---- pond: the material's whole vertex-stage Displacement()  (W/MistralWaterLib.cginc:154-180) with every
+ * displacement mode of the shader library.  Fields are the material properties of W/MistralWaterProperty.cginc /
+ * W/MistralWaterLib.cginc:53-66 under their own names; `amplitude` is the raw _Amplitude (the x0.01 of :134/:172 is
+ * applied inside, as the shader does).  Object space = world space.                                             */
+#define MW_POND_WAVE 0               /* Wave(), :127-152: y only, finite-difference normal with _Smoothing        */
+#define MW_POND_GERSTNER 1           /* Gerstner(), :71-99: 4 waves = _WDirectionAB.xy/.zw, _WDirectionCD.xy/.zw  */
+#define MW_POND_GERSTNER_LEVEL_ONE 2 /* GerstnerLevelOne(), :101-125: 5 built-in waves                           */
+typedef struct mw_pond_params {
+    int32_t mode;
+    float amplitude, frequency, speed, steepness, smoothing; /* _Amplitude _Frequency _Speed _Steepness _Smoothing */
+    float wspeed[4];                                         /* _WSpeed                                           */
+    float dir_ab[4], dir_cd[4];                              /* _WDirectionAB, _WDirectionCD                      */
+} mw_pond_params;
+/* out_xyz = displaced vertex, out_normal_xyz (may be NULL) = v.normal as the shader leaves it.  Host pointers,
+ * synchronous; t = _Time.y.                                                                                      */
+mw_status mw_pond_displace(const mw_pond_params* p, const float* pos_xyz, int64_t nverts, float t, float* out_xyz,
+                           float* out_normal_xyz, int32_t device);
+/* device-pointer form, asynchronous on hip_stream (NULL = default stream) */
+mw_status mw_pond_displace_device(const mw_pond_params* p, const void* d_pos_xyz, int64_t nverts, float t,
+                                  void* d_out_xyz, void* d_out_normal_xyz, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

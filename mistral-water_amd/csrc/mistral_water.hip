@@ -17,6 +17,7 @@
 #include "direct_kernels.h"
 #include "ocean_renderer_device.h"
 #include "gerstner_kernels.h"
+#include "pond_kernels.h"
 
 #ifndef MW_WAVES_P1
 #define MW_WAVES_P1 6  // min waves per SIMD the register allocator must leave room for (measured best)
@@ -911,6 +912,58 @@ mw_status mw_gerstner_displace(const float* pos_xyz, int64_t nverts, const float
     if (s == MW_OK && hipMemcpy(out_xyz, dq, bytes, hipMemcpyDeviceToHost) != hipSuccess) s = fail(MW_EDEVICE, "D2H failed");
     hipFree(dp);
     hipFree(dq);
+    return s;
+}
+
+static mw_status pond_params_of(const mw_pond_params* p, PondParams* P, const char* who) {
+    if (!p) return fail(MW_EINVAL, std::string(who) + ": NULL params");
+    if (p->mode != MW_POND_WAVE && p->mode != MW_POND_GERSTNER && p->mode != MW_POND_GERSTNER_LEVEL_ONE)
+        return fail(MW_EINVAL, std::string(who) + ": unknown displacement mode");
+    P->mode = p->mode; P->amplitude = p->amplitude; P->frequency = p->frequency; P->speed = p->speed;
+    P->steepness = p->steepness; P->smoothing = p->smoothing;
+    for (int i = 0; i < 4; i++) { P->wspeed[i] = p->wspeed[i]; P->dir_ab[i] = p->dir_ab[i]; P->dir_cd[i] = p->dir_cd[i]; }
+    return MW_OK;
+}
+
+mw_status mw_pond_displace_device(const mw_pond_params* p, const void* d_pos_xyz, int64_t nverts, float t, void* d_out_xyz,
+                                  void* d_out_normal_xyz, void* hip_stream) {
+    PondParams P;
+    mw_status s = pond_params_of(p, &P, "mw_pond_displace_device");
+    if (s != MW_OK) return s;
+    if (nverts < 0) return fail(MW_EINVAL, "nverts < 0");
+    if (nverts == 0) return MW_OK;
+    if (!d_pos_xyz || !d_out_xyz) return fail(MW_EINVAL, "mw_pond_displace_device: NULL argument");
+    hipError_t e = pond_launch(P, (const float*)d_pos_xyz, nverts, t, (float*)d_out_xyz, (float*)d_out_normal_xyz,
+                               reinterpret_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pond launch: ") + hipGetErrorString(e));
+    return MW_OK;
+}
+
+mw_status mw_pond_displace(const mw_pond_params* p, const float* pos_xyz, int64_t nverts, float t, float* out_xyz,
+                           float* out_normal_xyz, int32_t device) {
+    PondParams P;
+    mw_status s = pond_params_of(p, &P, "mw_pond_displace");
+    if (s != MW_OK) return s;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MW_EDEVICE, "mw_pond_displace: no HIP device visible (no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(MW_EINVAL, "bad device ordinal");
+    if (nverts <= 0) return nverts == 0 ? MW_OK : fail(MW_EINVAL, "nverts < 0");
+    if (!pos_xyz || !out_xyz) return fail(MW_EINVAL, "mw_pond_displace: NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    float *dp = nullptr, *dq = nullptr, *dn = nullptr;
+    const size_t bytes = (size_t)nverts * 3 * sizeof(float);
+    if (hipMalloc((void**)&dp, bytes) != hipSuccess || hipMalloc((void**)&dq, bytes) != hipSuccess ||
+        (out_normal_xyz && hipMalloc((void**)&dn, bytes) != hipSuccess)) {
+        hipFree(dp); hipFree(dq); hipFree(dn);
+        return fail(MW_ENOMEM, "hipMalloc failed");
+    }
+    if (hipMemcpy(dp, pos_xyz, bytes, hipMemcpyHostToDevice) != hipSuccess) s = fail(MW_EDEVICE, "H2D failed");
+    if (s == MW_OK) s = mw_pond_displace_device(p, dp, nverts, t, dq, dn, nullptr);
+    if (s == MW_OK && hipDeviceSynchronize() != hipSuccess) s = fail(MW_EDEVICE, "pond kernel failed");
+    if (s == MW_OK && hipMemcpy(out_xyz, dq, bytes, hipMemcpyDeviceToHost) != hipSuccess) s = fail(MW_EDEVICE, "D2H failed");
+    if (s == MW_OK && dn && hipMemcpy(out_normal_xyz, dn, bytes, hipMemcpyDeviceToHost) != hipSuccess) s = fail(MW_EDEVICE, "D2H failed");
+    hipFree(dp); hipFree(dq); hipFree(dn);
     return s;
 }
 

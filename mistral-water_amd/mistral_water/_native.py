@@ -30,6 +30,16 @@ class MwParams(C.Structure):
                 ("device", C.c_int32)]
 
 
+MW_POND_WAVE, MW_POND_GERSTNER, MW_POND_GERSTNER_LEVEL_ONE = 0, 1, 2
+
+
+class MwPondParams(C.Structure):
+    """mw_pond_params (include/mistral_water.h): the pond material's displacement properties."""
+    _fields_ = [("mode", C.c_int32), ("amplitude", C.c_float), ("frequency", C.c_float), ("speed", C.c_float),
+                ("steepness", C.c_float), ("smoothing", C.c_float), ("wspeed", C.c_float * 4), ("dir_ab", C.c_float * 4),
+                ("dir_cd", C.c_float * 4)]
+
+
 class MistralWaterError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
@@ -96,6 +106,8 @@ def lib():
                                            f32p, C.c_int32]),
         "mw_gerstner_displace_device": (C.c_int, [vp, C.c_int64, f32p, C.c_int32, C.c_float, C.c_float, C.c_float,
                                                   C.c_float, vp, vp]),
+        "mw_pond_displace": (C.c_int, [C.POINTER(MwPondParams), f32p, C.c_int64, C.c_float, f32p, f32p, C.c_int32]),
+        "mw_pond_displace_device": (C.c_int, [C.POINTER(MwPondParams), vp, C.c_int64, C.c_float, vp, vp, vp]),
         "mw_debug_omega_t": (C.c_int, [vp, C.c_float, f32p]),
         "mw_debug_get_omega": (C.c_int, [vp, f32p]),
         "mw_debug_sincos": (C.c_int, [f32p, C.c_int32, f32p, f32p]),
@@ -117,7 +129,7 @@ ABI_SYMBOLS = [
     "mw_ocean_grid_size", "mw_ocean_evaluate", "mw_ocean_update", "mw_ocean_timer", "mw_ocean_reset_timer",
     "mw_ocean_evaluate_device", "mw_ocean_max_batch", "mw_ocean_generate_texture",
     "mw_ocean_generate_texture_device", "mw_ocean_profile_kernels", "mw_gerstner_displace",
-    "mw_gerstner_displace_device", "mw_debug_omega_t", "mw_debug_get_omega", "mw_debug_sincos", "mw_debug_stream_read",
+    "mw_gerstner_displace_device", "mw_pond_displace", "mw_pond_displace_device", "mw_debug_omega_t", "mw_debug_get_omega", "mw_debug_sincos", "mw_debug_stream_read",
 ]
 
 

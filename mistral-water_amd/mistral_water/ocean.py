@@ -263,3 +263,42 @@ def gerstner_displace(pos_xyz, waves, amplitude: float, frequency: float, steepn
     nat.check(nat.lib().mw_gerstner_displace(_p(pos), pos.size // 3, _p(wv), wv.shape[0], C.c_float(amplitude),
                                              C.c_float(frequency), C.c_float(steepness), C.c_float(t), _p(out), device))
     return out
+
+
+class PondMaterial:
+    """Displacement properties of the pond material (W/MistralWaterProperty.cginc, W/MistralWaterLib.cginc:53-66), under
+    the material's own property names, and its vertex-stage ``Displacement()`` (:154-180) on host or device arrays.
+
+    ``mode``: ``MW_POND_WAVE`` (Wave, :127-152), ``MW_POND_GERSTNER`` (Gerstner, :71-99) or
+    ``MW_POND_GERSTNER_LEVEL_ONE`` (GerstnerLevelOne, :101-125)."""
+
+    def __init__(self, mode=nat.MW_POND_GERSTNER, _Amplitude=10.0, _Frequency=2.58, _Speed=1.0, _Steepness=0.99,
+                 _Smoothing=1.0, _WSpeed=(0, 0, 0, 0), _WDirectionAB=(0, 0, 0, 0), _WDirectionCD=(0, 0, 0, 0)):
+        self.mode = mode
+        self._Amplitude, self._Frequency, self._Speed = _Amplitude, _Frequency, _Speed
+        self._Steepness, self._Smoothing = _Steepness, _Smoothing
+        self._WSpeed, self._WDirectionAB, self._WDirectionCD = tuple(_WSpeed), tuple(_WDirectionAB), tuple(_WDirectionCD)
+
+    def _c(self):
+        p = nat.MwPondParams()
+        p.mode, p.amplitude, p.frequency, p.speed = self.mode, self._Amplitude, self._Frequency, self._Speed
+        p.steepness, p.smoothing = self._Steepness, self._Smoothing
+        p.wspeed[:], p.dir_ab[:], p.dir_cd[:] = list(self._WSpeed), list(self._WDirectionAB), list(self._WDirectionCD)
+        return p
+
+    def displace(self, pos_xyz, t: float, normals: bool = True, device: int = 0):
+        """-> (displaced vertices, normals or None) for host vertices [n,3] at _Time.y = t."""
+        pos = np.ascontiguousarray(pos_xyz, np.float32)
+        out = np.empty_like(pos)
+        nrm = np.empty_like(pos) if normals else None
+        p = self._c()
+        nat.check(nat.lib().mw_pond_displace(C.byref(p), _p(pos), pos.size // 3, C.c_float(t), _p(out),
+                                             _p(nrm) if normals else None, device))
+        return out, nrm
+
+    def displace_device(self, d_pos: int, nverts: int, t: float, d_out: int, d_normals: int = 0, stream: int = 0):
+        """Device pointers (ints), asynchronous on ``stream`` (a hipStream_t as int, 0 = default stream)."""
+        p = self._c()
+        nat.check(nat.lib().mw_pond_displace_device(C.byref(p), C.c_void_p(d_pos), nverts, C.c_float(t), C.c_void_p(d_out),
+                                                    C.c_void_p(d_normals) if d_normals else None,
+                                                    C.c_void_p(stream) if stream else None))

@@ -257,3 +257,29 @@ def gerstner_f64(pos_xyz, waves, amplitude, frequency, steepness, t):
     lib().orc_gerstner_f64(_fp(pos), C.c_int64(pos.size // 3), _fp(wv), C.c_int(wv.shape[0]), C.c_float(amplitude),
                            C.c_float(frequency), C.c_float(steepness), C.c_float(t), _fp(out))
     return out
+
+
+class PondParams(C.Structure):
+    """Material properties of the pond shader (W/MistralWaterLib.cginc:53-66); layout of mw_pond_params."""
+    _fields_ = [("mode", C.c_int32), ("amplitude", C.c_float), ("frequency", C.c_float), ("speed", C.c_float),
+                ("steepness", C.c_float), ("smoothing", C.c_float), ("wspeed", C.c_float * 4), ("dir_ab", C.c_float * 4),
+                ("dir_cd", C.c_float * 4)]
+
+
+def pond_params(mode, amplitude, frequency, speed=0.0, steepness=0.0, smoothing=1.0, wspeed=(0, 0, 0, 0),
+                dir_ab=(0, 0, 0, 0), dir_cd=(0, 0, 0, 0)):
+    p = PondParams()
+    p.mode, p.amplitude, p.frequency, p.speed, p.steepness, p.smoothing = mode, amplitude, frequency, speed, steepness, smoothing
+    p.wspeed[:], p.dir_ab[:], p.dir_cd[:] = list(wspeed), list(dir_ab), list(dir_cd)
+    return p
+
+
+def pond_displace_f64(p, pos_xyz, t):
+    """W/MistralWaterLib.cginc:154-180 Displacement() in f64 (oracle/pond_oracle.c) -> (positions, normals)."""
+    pos = np.ascontiguousarray(pos_xyz, np.float32)
+    out = np.empty(pos.shape, np.float64)
+    nrm = np.empty(pos.shape, np.float64)
+    rc = lib().orc_pond_displace_f64(C.byref(p), _fp(pos), C.c_int64(pos.size // 3), C.c_float(t), _fp(out), _fp(nrm))
+    if rc:
+        raise ValueError("unknown pond displacement mode")
+    return out, nrm

@@ -15,6 +15,7 @@
 
 #include "../../mistral-water_amd/csrc/fftmesh_kernels.h"
 #include "../../mistral-water_amd/csrc/gerstner_kernels.h"
+#include "../../mistral-water_amd/csrc/pond_kernels.h"
 #include "../../mistral-water_amd/csrc/ocean_renderer_kernels.h"
 
 using namespace mw;
@@ -314,6 +315,15 @@ void emul_gerstner(const float* pos, long nverts, const float* waves, int nwaves
     for (long v = 0; v < nverts; v++)
         gerstner_vertex(wv, nwaves, amplitude, frequency, steepness, t, pos[3 * v], pos[3 * v + 1], pos[3 * v + 2], &out[3 * v],
                         &out[3 * v + 1], &out[3 * v + 2]);
+}
+
+// pond Displacement(): p is an mw_pond_params
+void emul_pond(const mw_pond_params* p, const float* pos, long nverts, float t, float* out, float* nrm) {
+    PondParams P;
+    P.mode = p->mode; P.amplitude = p->amplitude; P.frequency = p->frequency; P.speed = p->speed;
+    P.steepness = p->steepness; P.smoothing = p->smoothing;
+    for (int i = 0; i < 4; i++) { P.wspeed[i] = p->wspeed[i]; P.dir_ab[i] = p->dir_ab[i]; P.dir_cd[i] = p->dir_cd[i]; }
+    for (long v = 0; v < nverts; v++) pond_vertex(P, t, pos[3 * v], pos[3 * v + 1], pos[3 * v + 2], &out[3 * v], &nrm[3 * v]);
 }
 
 // pass-1 block mapping (speed-only remap; must be a bijection onto (column job, step) plus padding blocks)

@@ -88,6 +88,13 @@ class Emul:
         assert r == 0
         return h, d, n, w, g
 
+    def pond(self, params, pos, t):
+        """params: a ctypes struct with the mw_pond_params layout (oracle.PondParams) -> (positions, normals) f32."""
+        pos = np.ascontiguousarray(pos, np.float32)
+        out, nrm = np.empty_like(pos), np.empty_like(pos)
+        self.L.emul_pond(C.byref(params), _p(pos), C.c_long(pos.size // 3), C.c_float(t), _p(out), _p(nrm))
+        return out, nrm
+
     def p1_block_map(self, gx, nsteps, tgroup):
         """-> list of (jb, step) or None (padding block) for every block of the 1-D pass-1 grid."""
         nb = self.L.emul_p1_grid_blocks(gx, nsteps, tgroup)

@@ -60,6 +60,9 @@ def test_no_cpu_fallback_without_gpu(mw):
     with pytest.raises(mw.MistralWaterError) as e:
         mw.gerstner_displace(np.zeros((4, 3), np.float32), [(1, 0, 1)], 0.1, 1.0, 0.5, 0.0)
     assert e.value.status == mw.MW_EDEVICE
+    with pytest.raises(mw.MistralWaterError) as e:
+        mw.PondMaterial().displace(np.zeros((4, 3), np.float32), 0.0)
+    assert e.value.status == mw.MW_EDEVICE
 
 
 def test_bad_arguments_are_status_codes_not_crashes(mw):

@@ -144,3 +144,29 @@ def test_pass1_time_group_block_map_is_a_bijection(emul, gx, nsteps, tgroup):
         if slot % tgroup:
             prev = blocks[(slot - 1) * 8 + xcd]
             assert prev == (v[0], v[1] - 1)
+
+
+def _pond_cases(oracle):
+    M = workloads.POND_MATERIAL
+    common = dict(amplitude=M["_Amplitude"], frequency=M["_Frequency"], speed=M["_Speed"], steepness=M["_Steepness"],
+                  wspeed=M["_WSpeed"], dir_ab=M["_WDirectionAB"], dir_cd=M["_WDirectionCD"])
+    return [("wave", oracle.pond_params(0, smoothing=1.0, **common)),
+            ("wave_smooth", oracle.pond_params(0, smoothing=0.35, **common)),
+            ("gerstner", oracle.pond_params(1, smoothing=1.0, **common)),
+            ("level_one", oracle.pond_params(2, smoothing=1.0, **{**common, "amplitude": 0.1}))]
+
+
+def test_pond_displacement_modes_vs_oracle(emul, oracle):
+    """W/MistralWaterLib.cginc:154-180 Displacement() -- Wave, Gerstner, GerstnerLevelOne -- host-stepped kernel body vs f64."""
+    pos = workloads.pond_lattice(64, y=0.25, seed=3)
+    for name, p in _pond_cases(oracle):
+        for t in (0.0, 3.25, 61.7):
+            out, nrm = emul.pond(p, pos, t)
+            want, wn = oracle.pond_displace_f64(p, pos, t)
+            assert np.abs(out - want).max() < 6e-6, (name, t)     # coordinates up to 50: 1 ulp = 3.8e-6
+            assert np.abs(nrm - wn).max() < 6e-6, (name, t)       # phase rounding at |x f| ~ 130 rad: 1.5e-5 rad
+    # the Gerstner mode equals the round's first pond entry point (mw_gerstner_displace) on the shipped 4 waves
+    P = workloads.POND
+    a = emul.gerstner(pos, P["waves"], P["amplitude"], P["frequency"], P["steepness"], 3.25)
+    b, _ = emul.pond(_pond_cases(oracle)[2][1], pos, 3.25)
+    assert np.abs(a - b).max() < 4e-6

@@ -255,6 +255,52 @@ def test_gerstner_pond(mw, oracle):
     assert np.abs(out - oracle.gerstner_f64(pos, P["waves"], P["amplitude"], P["frequency"], P["steepness"], 0.7)).max() < 3e-6
 
 
+def test_pond_material_displacement_modes(mw, oracle):
+    """W/MistralWaterLib.cginc:154-180 Displacement() in its three modes (Wave with its finite-difference normal, Gerstner,
+    GerstnerLevelOne) through mw_pond_displace, vs the f64 oracle (oracle/pond_oracle.c); 1M-vertex and ragged sizes."""
+    import torch
+    M = workloads.POND_MATERIAL
+    common = dict(amplitude=M["_Amplitude"], frequency=M["_Frequency"], speed=M["_Speed"], steepness=M["_Steepness"],
+                  wspeed=M["_WSpeed"], dir_ab=M["_WDirectionAB"], dir_cd=M["_WDirectionCD"])
+    cases = [(mw.MW_POND_WAVE, 1.0, M["_Amplitude"]), (mw.MW_POND_WAVE, 0.35, M["_Amplitude"]),
+             (mw.MW_POND_GERSTNER, 1.0, M["_Amplitude"]), (mw.MW_POND_GERSTNER_LEVEL_ONE, 1.0, 0.1)]
+    for mode, smoothing, amp in cases:
+        mat = mw.PondMaterial(mode=mode, _Amplitude=amp, _Frequency=M["_Frequency"], _Speed=M["_Speed"],
+                              _Steepness=M["_Steepness"], _Smoothing=smoothing, _WSpeed=M["_WSpeed"],
+                              _WDirectionAB=M["_WDirectionAB"], _WDirectionCD=M["_WDirectionCD"])
+        op = oracle.pond_params(mode, smoothing=smoothing, **{**common, "amplitude": amp})
+        for n, t in ((1000, 3.25), (37, 61.7), (1, 0.0)):
+            pos = workloads.pond_lattice(n, y=0.25, seed=n)
+            if n == 37:
+                pos = pos[:-2]        # 1367 vertices: not a multiple of 4 (tail path)
+            out, nrm = mat.displace(pos, t)
+            want, wn = oracle.pond_displace_f64(op, pos, t)
+            assert np.abs(out - want).max() < 6e-6, (mode, n)
+            assert np.abs(nrm - wn).max() < 6e-6, (mode, n)
+            out2, none = mat.displace(pos, t, normals=False)
+            assert none is None and (out2 == out).all()
+    # Gerstner mode == the 4-wave call of mw_gerstner_displace on the shipped material, bit for bit or within 1 ulp
+    P = workloads.POND
+    pos = workloads.pond_lattice(100, seed=1)
+    a = mw.gerstner_displace(pos, P["waves"], P["amplitude"], P["frequency"], P["steepness"], 3.25)
+    b, _ = mw.PondMaterial(mode=mw.MW_POND_GERSTNER, **M).displace(pos, 3.25)
+    assert np.abs(a - b).max() < 4e-6
+    # device-pointer form on a torch stream
+    dp = torch.from_numpy(pos).cuda()
+    do, dn = torch.empty_like(dp), torch.empty_like(dp)
+    mat = mw.PondMaterial(mode=mw.MW_POND_WAVE, **M)
+    mat.displace_device(dp.data_ptr(), pos.shape[0], 2.0, do.data_ptr(), dn.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ho, hn = mat.displace(pos, 2.0)
+    assert (do.cpu().numpy() == ho).all() and (dn.cpu().numpy() == hn).all()
+    # errors: unknown mode, empty input
+    with pytest.raises(mw.MistralWaterError) as e:
+        mw.PondMaterial(mode=7, **M).displace(pos, 0.0)
+    assert e.value.status == mw.MW_EINVAL
+    out, nrm = mw.PondMaterial(**M).displace(np.zeros((0, 3), np.float32), 0.0)
+    assert out.shape == (0, 3)
+
+
 def test_batch_limits_and_empty_inputs(mw, oracle):
     """Maximum batch (32 steps per enqueue) equals single steps; one more is MW_EINVAL; empty pond input is a no-op."""
     import torch

@@ -20,6 +20,21 @@ POND = dict(amplitude=10 * 0.01, frequency=2.58, steepness=0.99,
             waves=[(0.3, 0.73, 1.2), (0.85, 0.25, 0.71), (-0.25, 1.11, 1.1), (0.5, 0.5, 0.73)])
 
 
+# the shipped pond material, property by property (M/Pond Water Mat.mat:90-136); _Speed is 0 there, 1.5 is used for Wave
+POND_MATERIAL = dict(_Amplitude=10.0, _Frequency=2.58, _Speed=1.5, _Steepness=0.99, _Smoothing=1.0,
+                     _WSpeed=(1.2, 0.71, 1.1, 0.73), _WDirectionAB=(0.3, 0.73, 0.85, 0.25), _WDirectionCD=(-0.25, 1.11, 0.5, 0.5))
+
+
+def pond_lattice(n, y=0.0, seed=None):
+    """n x n lattice on x,z in [-50,50); optional jitter so no two vertices share a phase."""
+    import numpy as np
+    g = np.linspace(-50, 50, n, endpoint=False, dtype=np.float32)
+    pos = np.stack([np.repeat(g, n), np.full(n * n, y, np.float32), np.tile(g, n)], -1)
+    if seed is not None:
+        pos += np.random.default_rng(seed).uniform(-0.04, 0.04, pos.shape).astype(np.float32)
+    return np.ascontiguousarray(pos, np.float32)
+
+
 def pond_waves8():
     """BASELINE config 5 '8 waves': the 4 shipped + the same 4 rotated 90 degrees at half speed."""
     w = list(POND["waves"])
