@@ -129,6 +129,27 @@ mw_status mw_ocean_generate_texture(mw_ocean* o, float delta_time, float* height
 mw_status mw_ocean_generate_texture_device(mw_ocean* o, float delta_time, void* d_height, void* d_disp_xz,
                                            void* d_normal_xyz, void* d_white);
 
+/* ---- OceanRenderer semantics, consumer-side packing ---------------------------------------------------------
+ * One GenerateTexture() delivered as the reference's four ARGBFloat render targets (S/OceanRenderer.cs:143-146,
+ * bound to the ocean material at :310-313), [M*M*4] floats each, texel (px,py) at (py*M + px)*4:
+ *   height_rgba = (Re h, Im h, Re h, Im h)      F/SpectrumHeight.shader:46 + F/Stockham.shader:56
+ *   disp_rgba   = (Re Dx, Im Dx, Re Dz, Im Dz)  F/Spectrum.shader:50      + F/Stockham.shader:56
+ *   normal_rgba = (n.x, n.y, n.z, 1)            F/OceanNormal.shader:55
+ *   white_rgba  = (w, w, w, 1)                  F/WhiteCap.shader:44
+ * Any destination may be NULL.  Host form synchronous, device form asynchronous on the handle's stream.          */
+mw_status mw_ocean_generate_texture_rgba(mw_ocean* o, float delta_time, float* height_rgba, float* disp_rgba,
+                                         float* normal_rgba, float* white_rgba);
+mw_status mw_ocean_generate_texture_rgba_device(mw_ocean* o, float delta_time, void* d_height_rgba, void* d_disp_rgba,
+                                                void* d_normal_rgba, void* d_white_rgba);
+/* The ocean material's vertex stage on the resolution x resolution mesh of S/OceanRenderer.cs:172-207, sampling the
+ * textures of the LATEST GenerateTexture() bilinearly at the vertex uv (tex2Dlod, clamp):
+ *   vertex = rest + (_Anim.r, _Height.r, _Anim.b) / 8      W/TestOcean.shader:65-66, W/MistralWaterCommon.cginc:22-23
+ *   normal = normalize(_Bump.rgb)                          W/TestOcean.shader:70
+ *   color  = _White.r   (1 float per vertex)               W/TestOcean.shader:72, W/MistralWaterCommon.cginc:56
+ * normals/colors may be NULL.  MW_ESTATE before the first GenerateTexture().                                      */
+mw_status mw_ocean_displace_mesh(mw_ocean* o, float* vertices_xyz, float* normals_xyz, float* colors);
+mw_status mw_ocean_displace_mesh_device(mw_ocean* o, void* d_vertices_xyz, void* d_normals_xyz, void* d_colors);
+
 /* ---- measurement hook (bench.py): times each kernel of one FFTMesh step with hipEvents on the
  * handle's stream.  ms_out[k] = mean duration of kernel k over iters launches of `nsteps` batched
  * time-steps; names_out[k] = static kernel name.  Returns the kernel count through *nkernels.      */

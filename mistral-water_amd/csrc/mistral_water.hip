@@ -763,6 +763,68 @@ mw_status mw_ocean_generate_texture(mw_ocean* o, float delta_time, float* height
     return MW_OK;
 }
 
+mw_status mw_ocean_generate_texture_rgba_device(mw_ocean* o, float delta_time, void* d_height_rgba, void* d_disp_rgba,
+                                                void* d_normal_rgba, void* d_white_rgba) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_generate_texture_rgba: OceanRenderer semantics only");
+    HIP_TRY(hipSetDevice(o->device));
+    o->orr.choppiness = o->p.choppiness;
+    mw_status s = or_generate_rgba(o->orr, delta_time, (f4*)d_height_rgba, (f4*)d_disp_rgba, (f4*)d_normal_rgba,
+                                   (f4*)d_white_rgba, o->stream);
+    if (s != MW_OK) return fail(s, or_last_error());
+    return MW_OK;
+}
+
+mw_status mw_ocean_generate_texture_rgba(mw_ocean* o, float delta_time, float* height_rgba, float* disp_rgba,
+                                         float* normal_rgba, float* white_rgba) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_generate_texture_rgba: OceanRenderer semantics only");
+    HIP_TRY(hipSetDevice(o->device));
+    const size_t bytes = (size_t)o->N * o->N * 4 * sizeof(float);
+    float* host[4] = {height_rgba, disp_rgba, normal_rgba, white_rgba};
+    float* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    mw_status s = MW_OK;
+    for (int k = 0; k < 4 && s == MW_OK; k++)
+        if (host[k] && hipMalloc((void**)&dev[k], bytes) != hipSuccess) s = fail(MW_ENOMEM, "hipMalloc failed");
+    if (s == MW_OK) s = mw_ocean_generate_texture_rgba_device(o, delta_time, dev[0], dev[1], dev[2], dev[3]);
+    for (int k = 0; k < 4 && s == MW_OK; k++)
+        if (host[k] && hipMemcpyAsync(host[k], dev[k], bytes, hipMemcpyDeviceToHost, o->stream) != hipSuccess)
+            s = fail(MW_EDEVICE, "D2H failed");
+    if (hipStreamSynchronize(o->stream) != hipSuccess && s == MW_OK) s = fail(MW_EDEVICE, "stream sync failed");
+    for (int k = 0; k < 4; k++) hipFree(dev[k]);
+    return s;
+}
+
+mw_status mw_ocean_displace_mesh_device(mw_ocean* o, void* d_vertices_xyz, void* d_normals_xyz, void* d_colors) {
+    if (!o || !d_vertices_xyz) return fail(MW_EINVAL, "mw_ocean_displace_mesh: NULL argument");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_displace_mesh: OceanRenderer semantics only");
+    HIP_TRY(hipSetDevice(o->device));
+    mw_status s = or_displace_mesh(o->orr, o->p.resolution, o->p.unit_width, (float*)d_vertices_xyz, (float*)d_normals_xyz,
+                                   (float*)d_colors, o->stream);
+    if (s != MW_OK) return fail(s, or_last_error());
+    return MW_OK;
+}
+
+mw_status mw_ocean_displace_mesh(mw_ocean* o, float* vertices_xyz, float* normals_xyz, float* colors) {
+    if (!o || !vertices_xyz) return fail(MW_EINVAL, "mw_ocean_displace_mesh: NULL argument");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_displace_mesh: OceanRenderer semantics only");
+    HIP_TRY(hipSetDevice(o->device));
+    const size_t nv = (size_t)o->p.resolution * o->p.resolution;
+    float *dv = nullptr, *dn = nullptr, *dc = nullptr;
+    mw_status s = dmalloc(&dv, nv * 3);
+    if (s == MW_OK && normals_xyz) s = dmalloc(&dn, nv * 3);
+    if (s == MW_OK && colors) s = dmalloc(&dc, nv);
+    if (s == MW_OK) s = mw_ocean_displace_mesh_device(o, dv, dn, dc);
+    if (s == MW_OK) {
+        hipMemcpyAsync(vertices_xyz, dv, nv * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream);
+        if (dn) hipMemcpyAsync(normals_xyz, dn, nv * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream);
+        if (dc) hipMemcpyAsync(colors, dc, nv * sizeof(float), hipMemcpyDeviceToHost, o->stream);
+        if (hipStreamSynchronize(o->stream) != hipSuccess) s = fail(MW_EDEVICE, "displace_mesh sync failed");
+    }
+    hipFree(dv); hipFree(dn); hipFree(dc);
+    return s;
+}
+
 mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, const char** names_out,
                                    int32_t* nkernels) {
     if (!o || !ms_out || !nkernels || iters < 1) return fail(MW_EINVAL, "mw_ocean_profile_kernels: bad argument");

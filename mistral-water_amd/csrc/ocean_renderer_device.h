@@ -20,6 +20,8 @@ struct OrState {
     float *out_height = nullptr, *out_disp_g = nullptr, *out_normal = nullptr, *out_white = nullptr;
     cf* out_disp_cf = nullptr;
     float* out_disp = nullptr;  // alias of out_disp_cf as floats (r, b)
+    float *out_height_g = nullptr, *out_disp_a = nullptr;  // Im h, Im Dz: written only once the RGBA layout was asked for
+    bool want_imag = false, have_imag = false, have_frame = false;
 };
 static thread_local std::string g_or_err;
 static inline const char* or_last_error() { return g_or_err.c_str(); }
@@ -123,12 +125,25 @@ __global__ void k_or_white(OrConsts c, const cf* disp, const float* normal, floa
     or_white_element(c, idx % c.M, idx / c.M, disp, normal, white);
 }
 
+__global__ void k_or_pack_rgba(int M, const float* height, const float* height_g, const cf* disp, const float* disp_g,
+                               const float* disp_a, const float* normal, const float* white, f4* H, f4* D, f4* Nn, f4* W) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)M * M) return;
+    or_pack_rgba_element(idx, height, height_g, disp, disp_g, disp_a, normal, white, H, D, Nn, W);
+}
+__global__ void k_or_displace_mesh(int M, int res, float unit_width, const float* height, const cf* disp, const float* normal,
+                                   const float* white, float* vert, float* nrm, float* col) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= res * res) return;
+    or_mesh_vertex(M, res, unit_width, idx / res, idx % res, height, disp, normal, white, vert, nrm, col);
+}
+
 std::vector<cf> build_twiddle_table(int N, int P, int sgn);  // mistral_water.hip
 int plan_points_host(int N);
 
 static inline void or_free(OrState& s) {
     hipFree(s.initT); hipFree(s.phaseT); hipFree(s.TW); hipFree(s.E); hipFree(s.out_height); hipFree(s.out_disp_cf);
-    hipFree(s.out_disp_g); hipFree(s.out_normal); hipFree(s.out_white);
+    hipFree(s.out_disp_g); hipFree(s.out_normal); hipFree(s.out_white); hipFree(s.out_height_g); hipFree(s.out_disp_a);
     s = OrState();
 }
 
@@ -173,6 +188,8 @@ static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
     k_or_pass1<N, P><<<dim3(N / 4), dim3(NT1), LB1, st>>>(A1);
     OrP2Args A2;
     A2.E = s.E; A2.TW = s.TW; A2.height = s.out_height; A2.disp = s.out_disp_cf; A2.disp_g = s.out_disp_g; A2.c = s.c;
+    A2.height_g = s.want_imag ? s.out_height_g : nullptr;
+    A2.disp_a = s.want_imag ? s.out_disp_a : nullptr;
     constexpr int NT2 = OrP2Geom<N, P>::NTHREADS, LB2 = OrP2Geom<N, P>::LDS_BYTES;
     k_or_pass2<N, P><<<dim3(N / 4), dim3(NT2), LB2, st>>>(A2);
     return hipGetLastError();
@@ -183,6 +200,13 @@ static inline mw_status or_generate(OrState& s, float delta_time, float* d_heigh
                                     hipStream_t st) {
     s.c.choppiness = s.choppiness;
     const float dt = delta_time * s.mult;  // S/OceanRenderer.cs:223
+    if (s.want_imag && !s.out_height_g) {
+        const size_t bytes = sizeof(float) * (size_t)s.M * s.M;
+        if (hipMalloc((void**)&s.out_height_g, bytes) != hipSuccess || hipMalloc((void**)&s.out_disp_a, bytes) != hipSuccess) {
+            g_or_err = "OceanRenderer: hipMalloc failed";
+            return MW_ENOMEM;
+        }
+    }
     hipError_t e = hipSuccess;
     switch (s.M) {
         case 64: e = or_launch_passes<64>(s, dt, st); break;
@@ -200,10 +224,38 @@ static inline mw_status or_generate(OrState& s, float delta_time, float* d_heigh
     k_or_normal<<<dim3(nb), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal);
     k_or_white<<<dim3(nb), dim3(256), 0, st>>>(s.c, s.out_disp_cf, s.out_normal, s.out_white);
     if (hipGetLastError() != hipSuccess) { g_or_err = "OceanRenderer normal/white launch failed"; return MW_EDEVICE; }
+    s.have_frame = true;
+    s.have_imag = s.want_imag;
     if (d_height) hipMemcpyAsync(d_height, s.out_height, MM * 4, hipMemcpyDeviceToDevice, st);
     if (d_disp) hipMemcpyAsync(d_disp, s.out_disp_cf, MM * 8, hipMemcpyDeviceToDevice, st);
     if (d_normal) hipMemcpyAsync(d_normal, s.out_normal, MM * 12, hipMemcpyDeviceToDevice, st);
     if (d_white) hipMemcpyAsync(d_white, s.out_white, MM * 4, hipMemcpyDeviceToDevice, st);
+    return MW_OK;
+}
+
+// one GenerateTexture() delivered as the reference's four ARGBFloat render targets (any destination may be NULL)
+static inline mw_status or_generate_rgba(OrState& s, float delta_time, f4* d_height, f4* d_disp, f4* d_normal, f4* d_white,
+                                         hipStream_t st) {
+    s.want_imag = true;
+    mw_status r = or_generate(s, delta_time, nullptr, nullptr, nullptr, nullptr, st);
+    if (r != MW_OK) return r;
+    const size_t MM = (size_t)s.M * s.M;
+    k_or_pack_rgba<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(s.M, s.out_height, s.out_height_g, s.out_disp_cf,
+                                                                              s.out_disp_g, s.out_disp_a, s.out_normal,
+                                                                              s.out_white, d_height, d_disp, d_normal, d_white);
+    if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_pack_rgba launch failed"; return MW_EDEVICE; }
+    return MW_OK;
+}
+
+// the ocean material's vertex stage on the res x res mesh, from the textures of the latest GenerateTexture()
+static inline mw_status or_displace_mesh(OrState& s, int res, float unit_width, float* d_vert, float* d_nrm, float* d_col,
+                                         hipStream_t st) {
+    if (!s.have_frame) { g_or_err = "displace_mesh: no GenerateTexture() yet"; return MW_ESTATE; }
+    const int nv = res * res;
+    k_or_displace_mesh<<<dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st>>>(s.M, res, unit_width, s.out_height,
+                                                                                 s.out_disp_cf, s.out_normal, s.out_white,
+                                                                                 d_vert, d_nrm, d_col);
+    if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_displace_mesh launch failed"; return MW_EDEVICE; }
     return MW_OK;
 }
 

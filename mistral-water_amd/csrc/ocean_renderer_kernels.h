@@ -138,6 +138,8 @@ struct OrP2Args {
     float* height;  // [py][px]          heightTexture.r
     cf* disp;       // [py][px] (r, b)   displacementTexture.rb
     float* disp_g;  // [py][px]          displacementTexture.g  (read by OceanNormal's `center`, :44)
+    float* height_g;  // [py][px] heightTexture.g = Im h, or NULL   (only the RGBA texture layout needs these two)
+    float* disp_a;    // [py][px] displacementTexture.a = Im Dz, or NULL
     OrConsts c;
 };
 template <int N, int P>
@@ -174,8 +176,8 @@ MW_HD void or_p2_finish(const OrP2Args& A, const Twiddles& tw, int ab, int tid, 
     for (int q = 0; q < P; q++) {
         const int b = u + T * q;
         if (f == 1) { dx[q] = x[q].x; A.disp_g[rowoff + b] = x[q].y; }
-        else if (f == 2) A.disp[rowoff + b] = mk(dx[q], x[q].x);
-        else A.height[rowoff + b] = x[q].x;
+        else if (f == 2) { A.disp[rowoff + b] = mk(dx[q], x[q].x); if (A.disp_a) A.disp_a[rowoff + b] = x[q].y; }
+        else { A.height[rowoff + b] = x[q].x; if (A.height_g) A.height_g[rowoff + b] = x[q].y; }
     }
 }
 
@@ -213,6 +215,65 @@ MW_HD void or_white_element(const OrConsts& c, int px, int py, const cf* disp, c
     const float turb = fmaxf(0.f, 1.f - jac + sqrtf(n0 * n0 + n1 * n1));                    // :40
     const float t = turb > 1.f ? 1.f : turb;
     white[idx] = t * t * (3.f - 2.f * t);                                                    // smoothstep(0,1,turb), :43
+}
+
+
+// ---- consumer-side packing -----------------------------------------------------------------
+// The four ARGBFloat render targets exactly as the shaders leave them (S/OceanRenderer.cs:143-146,310-313):
+//   heightTexture       = (Re h, Im h, Re h, Im h)     SpectrumHeight returns float4(h, h) (F/SpectrumHeight.shader:46),
+//                                                      the Stockham passes transform both complex halves alike
+//   displacementTexture = (Re Dx, Im Dx, Re Dz, Im Dz) (F/Spectrum.shader:50, F/Stockham.shader:56)
+//   normalTexture       = (n.xyz, 1)                   (F/OceanNormal.shader:55)
+//   whiteTexture        = (w, w, w, 1)                 (F/WhiteCap.shader:44)
+MW_HD void or_pack_rgba_element(size_t idx, const float* height, const float* height_g, const cf* disp, const float* disp_g,
+                                const float* disp_a, const float* normal, const float* white, f4* H, f4* D, f4* Nn, f4* W) {
+    f4 v;
+    if (H) { v.x = height[idx]; v.y = height_g[idx]; v.z = v.x; v.w = v.y; H[idx] = v; }
+    if (D) { v.x = disp[idx].x; v.y = disp_g[idx]; v.z = disp[idx].y; v.w = disp_a[idx]; D[idx] = v; }
+    if (Nn) { v.x = normal[3 * idx]; v.y = normal[3 * idx + 1]; v.z = normal[3 * idx + 2]; v.w = 1.f; Nn[idx] = v; }
+    if (W) { v.x = v.y = v.z = white[idx]; v.w = 1.f; W[idx] = v; }
+}
+
+// tex2Dlod(tex, float4(uv, 0, 0)) on an M x M bilinear, clamp-addressed texture (Unity's RenderTexture defaults): texel
+// centres sit at (p + 0.5) / M.  Exact f32 weights, not the 8-bit fixed-point weights of a texture unit.
+MW_HD void or_bilinear_axis(int M, float u, int* p0, int* p1, float* w) {
+    const float x = u * (float)M - 0.5f, fl = floorf(x);
+    const int i0 = (int)fl;
+    *w = x - fl;
+    *p0 = or_clamp(i0, M - 1);
+    *p1 = or_clamp(i0 + 1, M - 1);
+}
+MW_HD float or_lerp2(float a00, float a10, float a01, float a11, float wx, float wy) {
+    const float a0 = a00 + (a10 - a00) * wx, a1 = a01 + (a11 - a01) * wx;
+    return a0 + (a1 - a0) * wy;
+}
+// The ocean material's vertex stage for mesh vertex (i, j) of the res x res grid of S/OceanRenderer.cs:172-207:
+//   v.vertex.y += _Height(uv).r / 8;  v.vertex.xz += _Anim(uv).rb / 8      (W/TestOcean.shader:65-66,
+//                                                                            W/MistralWaterCommon.cginc:22-23)
+//   normal = normalize(_Bump(uv).rgb)  (W/TestOcean.shader:70, identity object-to-world)   color = _White(uv).r  (:72)
+MW_HD void or_mesh_vertex(int M, int res, float unit_width, int i, int j, const float* height, const cf* disp,
+                          const float* normal, const float* white, float* vert, float* nrm, float* col) {
+    const float u = sdiv((float)i, (float)(res - 1)), v = sdiv((float)j, (float)(res - 1));  // S/OceanRenderer.cs:184
+    int x0, x1, y0, y1;
+    float wx, wy;
+    or_bilinear_axis(M, u, &x0, &x1, &wx);
+    or_bilinear_axis(M, v, &y0, &y1, &wy);
+    const size_t i00 = (size_t)y0 * M + x0, i10 = (size_t)y0 * M + x1, i01 = (size_t)y1 * M + x0, i11 = (size_t)y1 * M + x1;
+    const size_t cur = (size_t)i * res + j;
+    const float h = or_lerp2(height[i00], height[i10], height[i01], height[i11], wx, wy);
+    const float dx = or_lerp2(disp[i00].x, disp[i10].x, disp[i01].x, disp[i11].x, wx, wy);
+    const float dz = or_lerp2(disp[i00].y, disp[i10].y, disp[i01].y, disp[i11].y, wx, wy);
+    vert[3 * cur] = rest_coord(res, unit_width, i) + dx / 8.f;
+    vert[3 * cur + 1] = h / 8.f;
+    vert[3 * cur + 2] = rest_coord(res, unit_width, j) + dz / 8.f;
+    if (nrm) {
+        float n[3];
+        for (int k = 0; k < 3; k++)
+            n[k] = or_lerp2(normal[3 * i00 + k], normal[3 * i10 + k], normal[3 * i01 + k], normal[3 * i11 + k], wx, wy);
+        const float inv = 1.f / sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        nrm[3 * cur] = n[0] * inv; nrm[3 * cur + 1] = n[1] * inv; nrm[3 * cur + 2] = n[2] * inv;
+    }
+    if (col) col[cur] = or_lerp2(white[i00], white[i10], white[i01], white[i11], wx, wy);
 }
 
 }  // namespace mw

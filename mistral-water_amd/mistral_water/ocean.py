@@ -144,6 +144,23 @@ class Ocean:
         nat.check(nat.lib().mw_ocean_generate_texture(self._h, C.c_float(delta_time), _p(h), _p(d), _p(n), _p(w)))
         return h, d, n, w
 
+    def generate_texture_rgba(self, delta_time: float):
+        """One GenerateTexture() as the reference's four ARGBFloat render targets, [M,M,4] each
+        (S/OceanRenderer.cs:143-146): height (Re h, Im h, Re h, Im h), displacement (Re Dx, Im Dx, Re Dz, Im Dz),
+        normal (n, 1), white (w, w, w, 1)."""
+        M = self.N
+        t = [np.empty((M, M, 4), np.float32) for _ in range(4)]
+        nat.check(nat.lib().mw_ocean_generate_texture_rgba(self._h, C.c_float(delta_time), *[_p(a) for a in t]))
+        return tuple(t)
+
+    def displace_mesh(self):
+        """The ocean material's vertex stage (W/TestOcean.shader:61-79) on the resolution^2 mesh, from the textures
+        of the latest generate_texture*(): -> (vertices [n,3], normals [n,3], colors [n])."""
+        n = self.mesh_resolution * self.mesh_resolution
+        v, nr, c = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty(n, np.float32)
+        nat.check(nat.lib().mw_ocean_displace_mesh(self._h, _p(v), _p(nr), _p(c)))
+        return v, nr, c
+
 
 class _Mesh:
     """The handful of UnityEngine.Mesh members the reference assigns (S/FFTMesh.cs:134-138,277-279)."""

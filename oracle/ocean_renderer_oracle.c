@@ -267,3 +267,42 @@ void orr_normal_white_f64(const orr_params* p, const double* dtex, const double*
             white[idx] = tt * tt * (3.0 - 2.0 * tt);
         }
 }
+
+/* ---- the ocean material's vertex stage on the OceanRenderer mesh ------------------------------------------------
+ * S/OceanRenderer.cs:172-207 builds a res x res grid (res = resolution/8 after :169) with
+ *   vertex(i,j) = ((i - res/2) uw + (res even ? uw/2 : 0), 0, (j - res/2) uw + ...),  uv = (i/(res-1), j/(res-1)).
+ * W/TestOcean.shader:61-79 (and W/MistralWaterCommon.cginc:19-25,54-56) then displace it from the four textures:
+ *   v.y += _Height(uv).r / 8;  v.xz += _Anim(uv).rb / 8;  normal = normalize(_Bump(uv).rgb);  color = _White(uv).r
+ * tex2Dlod at lod 0 on a bilinear, clamp-addressed texture [unity defaults]: texel centres at (p + .5)/M.
+ * Inputs (double): height [M*M], disp_rb [M*M*2], normal [M*M*3], white [M*M], texel (px,py) at py*M + px.          */
+static double bilinear(const double* tex, int M, int stride, int comp, double u, double v) {
+    double x = u * M - 0.5, y = v * M - 0.5;
+    double fx = floor(x), fy = floor(y), wx = x - fx, wy = y - fy;
+    int x0 = clampi((int)fx, 0, M - 1), x1 = clampi((int)fx + 1, 0, M - 1);
+    int y0 = clampi((int)fy, 0, M - 1), y1 = clampi((int)fy + 1, 0, M - 1);
+    double a00 = tex[((size_t)y0 * M + x0) * stride + comp], a10 = tex[((size_t)y0 * M + x1) * stride + comp];
+    double a01 = tex[((size_t)y1 * M + x0) * stride + comp], a11 = tex[((size_t)y1 * M + x1) * stride + comp];
+    double a0 = a00 + (a10 - a00) * wx, a1 = a01 + (a11 - a01) * wx;
+    return a0 + (a1 - a0) * wy;
+}
+void orr_mesh_vertex_stage_f64(int M, int res, float unit_width, const double* height, const double* disp_rb,
+                               const double* normal, const double* white, double* out_v, double* out_n, double* out_c) {
+    int half = res / 2;
+    for (int i = 0; i < res; i++)
+        for (int j = 0; j < res; j++) {
+            size_t cur = (size_t)i * res + j;
+            /* uv in float32 as the C# stores it (Vector2 of floats, :184) */
+            float uf = (float)i * 1.0f / (float)(res - 1), vf = (float)j * 1.0f / (float)(res - 1);
+            double u = uf, v = vf;
+            float hx = (float)(i - half) * unit_width + (res % 2 == 0 ? unit_width / 2.0f : 0.0f); /* :178-183 */
+            float hz = (float)(j - half) * unit_width + (res % 2 == 0 ? unit_width / 2.0f : 0.0f);
+            out_v[3 * cur] = (double)hx + bilinear(disp_rb, M, 2, 0, u, v) / 8.0;
+            out_v[3 * cur + 1] = bilinear(height, M, 1, 0, u, v) / 8.0;
+            out_v[3 * cur + 2] = (double)hz + bilinear(disp_rb, M, 2, 1, u, v) / 8.0;
+            double n[3];
+            for (int k = 0; k < 3; k++) n[k] = bilinear(normal, M, 3, k, u, v);
+            double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            out_n[3 * cur] = n[0] / len; out_n[3 * cur + 1] = n[1] / len; out_n[3 * cur + 2] = n[2] / len;
+            out_c[cur] = bilinear(white, M, 1, 0, u, v);
+        }
+}

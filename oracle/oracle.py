@@ -249,6 +249,44 @@ def renderer_step_f64(p: RendererParams, init4, phase, delta_time: float, litera
     return hre, np.ascontiguousarray(dtex[..., [0, 2]]), n, w, np.ascontiguousarray(dtex[..., 1])
 
 
+def renderer_textures_f64(p: RendererParams, init4, phase, delta_time: float):
+    """One GenerateTexture() as the four ARGBFloat render targets of S/OceanRenderer.cs:143-146 ([M,M,4] each):
+    height (Re h, Im h, Re h, Im h), displacement (Re Dx, Im Dx, Re Dz, Im Dz), normal (n, 1), white (w, w, w, 1).
+    Transform by numpy's fft2 (the literal pass schedule is validated equal to it in tests/test_ocean_renderer.py)."""
+    M = p.M
+    init4 = np.ascontiguousarray(init4, np.float32)
+    sd = np.empty((M, M, 4), np.float64)
+    sh = np.empty((M, M, 2), np.float64)
+    lib().orr_spectra_f64(C.byref(p.c()), _fp(init4), _fp(phase), C.c_float(delta_time), _fp(sd), _fp(sh))
+    hx = np.fft.fft2(sd[..., 0] + 1j * sd[..., 1])
+    hz = np.fft.fft2(sd[..., 2] + 1j * sd[..., 3])
+    hh = np.fft.fft2(sh[..., 0] + 1j * sh[..., 1])
+    dtex = np.ascontiguousarray(np.stack([hx.real, hx.imag, hz.real, hz.imag], -1))
+    hre = np.ascontiguousarray(hh.real)
+    n = np.empty((M, M, 3), np.float64)
+    w = np.empty((M, M), np.float64)
+    lib().orr_normal_white_f64(C.byref(p.c()), _fp(dtex), _fp(hre), _fp(n), _fp(w))
+    htex = np.stack([hh.real, hh.imag, hh.real, hh.imag], -1)
+    ntex = np.concatenate([n, np.ones((M, M, 1))], -1)
+    wtex = np.stack([w, w, w, np.ones_like(w)], -1)
+    return htex, dtex, ntex, wtex
+
+
+def renderer_mesh_vertex_stage_f64(p: RendererParams, unit_width, height, disp_rb, normal, white):
+    """W/TestOcean.shader:61-79 on the res x res mesh of S/OceanRenderer.cs:172-207 -> (vertices, normals, colors)."""
+    M, res = p.M, p.resolution
+    height = np.ascontiguousarray(height, np.float64)
+    disp_rb = np.ascontiguousarray(disp_rb, np.float64)
+    normal = np.ascontiguousarray(normal, np.float64)
+    white = np.ascontiguousarray(white, np.float64)
+    v = np.empty((res * res, 3), np.float64)
+    n = np.empty((res * res, 3), np.float64)
+    c = np.empty(res * res, np.float64)
+    lib().orr_mesh_vertex_stage_f64(C.c_int(M), C.c_int(res), C.c_float(unit_width), _fp(height), _fp(disp_rb), _fp(normal),
+                                    _fp(white), _fp(v), _fp(n), _fp(c))
+    return v, n, c
+
+
 def gerstner_f64(pos_xyz, waves, amplitude, frequency, steepness, t):
     """W/MistralWaterLib.cginc:71-99,154-180 in f64 (oracle/gerstner_oracle.c)."""
     pos = np.ascontiguousarray(pos_xyz, np.float32)

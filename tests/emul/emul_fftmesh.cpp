@@ -173,7 +173,7 @@ int fft1d_np(const float* in_xy, float* out_xy) {
 // ---- OceanRenderer semantics: one GenerateTexture() stepped through the kernels' phase functions ----------
 template <int N, int P>
 int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, float* height, cf* disp, float* disp_g,
-               float* normal, float* white) {
+               float* normal, float* white, float* height_g, float* disp_a) {
     constexpr int T = FftGeom<N, P>::T;
     Tables tb(N, P, -1);
     const Twiddles tw = TwGeom<N, P>::view(tb.TW.data());
@@ -203,6 +203,7 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
     {
         OrP2Args A;
         A.E = E.data(); A.TW = tb.TW.data(); A.height = height; A.disp = disp; A.disp_g = disp_g; A.c = C;
+        A.height_g = height_g; A.disp_a = disp_a;
         constexpr int NT = OrP2Geom<N, P>::NTHREADS, BS = OrP2Geom<N, P>::BUFSTRIDE;
         std::vector<cf> lds(4 * BS);
         struct St { cf x[P]; float dx[P]; };
@@ -271,19 +272,33 @@ void emul_or_init(int M, float length, float wind_x, float wind_y, float amplitu
             or_init_element(M, length, wind_x, wind_y, amplitude / 10000.f, gravity, seed, px, py, reinterpret_cast<f4*>(initT), phaseT);
 }
 int emul_or_step(int M, float length, float gravity, float choppiness, float dt, const float* initT, float* phaseT,
-                 float* height, float* disp, float* disp_g, float* normal, float* white) {
+                 float* height, float* disp, float* disp_g, float* normal, float* white, float* height_g, float* disp_a) {
     OrConsts C;
     C.M = M; C.length = length; C.gravity = gravity; C.choppiness = choppiness;
     const f4* it = reinterpret_cast<const f4*>(initT);
     cf* d = reinterpret_cast<cf*>(disp);
     switch (M) {
-        case 64: return or_step_np<64, Plan<64>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white);
-        case 128: return or_step_np<128, Plan<128>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white);
-        case 256: return or_step_np<256, Plan<256>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white);
-        case 512: return or_step_np<512, Plan<512>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white);
-        case 1024: return or_step_np<1024, Plan<1024>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white);
+        case 64: return or_step_np<64, Plan<64>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a);
+        case 128: return or_step_np<128, Plan<128>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a);
+        case 256: return or_step_np<256, Plan<256>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a);
+        case 512: return or_step_np<512, Plan<512>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a);
+        case 1024: return or_step_np<1024, Plan<1024>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a);
         default: return 1;
     }
+}
+
+// consumer-side packing of one frame: the four RGBA render targets and the material's vertex stage on the mesh
+void emul_or_pack_rgba(int M, const float* height, const float* height_g, const float* disp, const float* disp_g,
+                       const float* disp_a, const float* normal, const float* white, float* H, float* D, float* Nn, float* W) {
+    for (size_t idx = 0; idx < (size_t)M * M; idx++)
+        or_pack_rgba_element(idx, height, height_g, reinterpret_cast<const cf*>(disp), disp_g, disp_a, normal, white,
+                             reinterpret_cast<f4*>(H), reinterpret_cast<f4*>(D), reinterpret_cast<f4*>(Nn), reinterpret_cast<f4*>(W));
+}
+void emul_or_displace_mesh(int M, int res, float unit_width, const float* height, const float* disp, const float* normal,
+                           const float* white, float* vert, float* nrm, float* col) {
+    for (int i = 0; i < res; i++)
+        for (int j = 0; j < res; j++)
+            or_mesh_vertex(M, res, unit_width, i, j, height, reinterpret_cast<const cf*>(disp), normal, white, vert, nrm, col);
 }
 
 void emul_rest_mesh(int N, float unit_width, float* vertices, float* normals, float* uvs, int32_t* indices) {

@@ -75,8 +75,11 @@ class Emul:
                             C.c_float(rp.gravity), C.c_uint64(seed), _p(initT), _p(phaseT))
         return initT, phaseT
 
-    def or_step(self, rp, initT, phaseT, delta_time):
+    def or_step(self, rp, initT, phaseT, delta_time, imag=False):
+        """imag=True also returns heightTexture.g (Im h) and displacementTexture.a (Im Dz) as two extra arrays."""
         M = rp.M
+        hg = np.empty((M, M), np.float32) if imag else None
+        da = np.empty((M, M), np.float32) if imag else None
         h = np.empty((M, M), np.float32)
         d = np.empty((M, M, 2), np.float32)
         g = np.empty((M, M), np.float32)
@@ -84,9 +87,21 @@ class Emul:
         w = np.empty((M, M), np.float32)
         dt = np.float32(delta_time) * np.float32(rp.mult)
         r = self.L.emul_or_step(M, C.c_float(rp.length), C.c_float(rp.gravity), C.c_float(rp.choppiness), C.c_float(dt),
-                                _p(initT), _p(phaseT), _p(h), _p(d), _p(g), _p(n), _p(w))
+                                _p(initT), _p(phaseT), _p(h), _p(d), _p(g), _p(n), _p(w),
+                                _p(hg) if imag else None, _p(da) if imag else None)
         assert r == 0
-        return h, d, n, w, g
+        return (h, d, n, w, g, hg, da) if imag else (h, d, n, w, g)
+
+    def or_pack_rgba(self, h, hg, d, g, da, n, w):
+        M = h.shape[0]
+        t = [np.empty((M, M, 4), np.float32) for _ in range(4)]
+        self.L.emul_or_pack_rgba(M, _p(h), _p(hg), _p(d), _p(g), _p(da), _p(n), _p(w), *[_p(a) for a in t])
+        return tuple(t)
+
+    def or_displace_mesh(self, M, res, unit_width, h, d, n, w):
+        v, nr, c = np.empty((res * res, 3), np.float32), np.empty((res * res, 3), np.float32), np.empty(res * res, np.float32)
+        self.L.emul_or_displace_mesh(M, res, C.c_float(unit_width), _p(h), _p(d), _p(n), _p(w), _p(v), _p(nr), _p(c))
+        return v, nr, c
 
     def pond(self, params, pos, t):
         """params: a ctypes struct with the mw_pond_params layout (oracle.PondParams) -> (positions, normals) f32."""

@@ -91,6 +91,83 @@ def test_emulated_kernels_vs_oracle(emul, oracle, resolution):
         assert np.abs(w - W).max() < 5e-5
 
 
+def _rgba_checks(tex, want):
+    (Ht, Dt, Nt, Wt), (HT, DT, NT, WT) = tex, want
+    tol_check(Ht, HT, 3e-6, "height rgba"); tol_check(Dt, DT, 3e-6, "disp rgba")
+    assert (Ht[..., 0] == Ht[..., 2]).all() and (Ht[..., 1] == Ht[..., 3]).all()     # float4(h, h)
+    assert (Nt[..., 3] == 1).all() and (Wt[..., 3] == 1).all()
+    assert (Wt[..., 0] == Wt[..., 1]).all() and (Wt[..., 0] == Wt[..., 2]).all()
+    en, ew = np.abs(Nt[..., :3] - NT[..., :3]).max(-1).ravel(), np.abs(Wt[..., 0] - WT[..., 0]).ravel()
+    assert np.quantile(en, 0.999) < 1e-4 and en.max() < 1e-2
+    assert np.quantile(ew, 0.999) < 1e-4 and ew.max() < 1e-2
+
+
+def _mesh_checks(got, want, hscale):
+    (v, n, c), (V, Nn, Cc) = got, want
+    assert np.abs(v - V).max() < 4e-6 * max(hscale, 1.0) + 4e-6 * np.abs(V).max()
+    en = np.abs(n - Nn).max(-1)
+    assert np.quantile(en, 0.99) < 1e-4 and en.max() < 1e-2
+    ec = np.abs(c - Cc)
+    assert np.quantile(ec, 0.99) < 1e-4 and ec.max() < 1e-2
+
+
+def test_emulated_rgba_textures_and_mesh_vertex_stage(emul, oracle):
+    """Consumer-side packing: the four ARGBFloat targets in the shaders' channel layout and
+    W/TestOcean.shader:61-79 on the S/OceanRenderer.cs:172-207 mesh, host-stepped kernel bodies vs the f64 oracle."""
+    rp = shipped(16)
+    M = rp.M
+    init4 = oracle.renderer_initial_spectrum(rp, 5)
+    initT = np.ascontiguousarray(init4.transpose(1, 0, 2))
+    phaseT = np.zeros((M, M), np.float32)
+    ph = np.zeros((M, M), np.float32)
+    for dt in (0.016, 0.3):
+        h, d, n, w, g, hg, da = emul.or_step(rp, initT, phaseT, dt, imag=True)
+        want = oracle.renderer_textures_f64(rp, init4, ph, dt)
+        _rgba_checks(emul.or_pack_rgba(h, hg, d, g, da, n, w), want)
+    HT, DT, NT, WT = want
+    for uw in (1.0, 0.37):
+        got = emul.or_displace_mesh(M, rp.resolution, uw, h, d, n, w)
+        ref = oracle.renderer_mesh_vertex_stage_f64(rp, uw, HT[..., 0], DT[..., [0, 2]], NT[..., :3], WT[..., 0])
+        _mesh_checks(got, ref, np.abs(HT[..., 0]).max() / 8)
+    # corner vertices sample the clamped corner texels: uv = 0 -> texel 0, uv = 1 -> texel M-1
+    v = got[0]
+    res = rp.resolution
+    assert abs(v[0, 1] - h[0, 0] / 8) < 1e-6 and abs(v[res * res - 1, 1] - h[M - 1, M - 1] / 8) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resolution", [8, 128])
+def test_gpu_rgba_textures_and_mesh_vertex_stage(mw, oracle, resolution):
+    rp = shipped(resolution)
+    M = rp.M
+    uw = 0.75
+    o = mw.Ocean(resolution=resolution, unit_width=uw, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude,
+                 choppiness=rp.choppiness, gravity=rp.gravity, mult=rp.mult, seed=5, semantics=mw.MW_SEM_OCEANRENDERER)
+    with pytest.raises(mw.MistralWaterError) as e:
+        o.displace_mesh()                       # no frame yet
+    assert e.value.status == mw.MW_ESTATE
+    init4 = oracle.renderer_initial_spectrum(rp, 5)
+    o.set_spectrum(init4[..., :2], init4[..., 2:])
+    ph = np.zeros((M, M), np.float32)
+    h0, d0, n0, w0 = o.generate_texture(0.016)                    # compact frame first, RGBA frames afterwards
+    oracle.renderer_textures_f64(rp, init4, ph, 0.016)
+    for dt in (0.033, 0.3):
+        tex = o.generate_texture_rgba(dt)
+        want = oracle.renderer_textures_f64(rp, init4, ph, dt)
+        _rgba_checks(tex, want)
+    HT, DT, NT, WT = want
+    got = o.displace_mesh()
+    ref = oracle.renderer_mesh_vertex_stage_f64(rp, uw, HT[..., 0], DT[..., [0, 2]], NT[..., :3], WT[..., 0])
+    _mesh_checks(got, ref, np.abs(HT[..., 0]).max() / 8)
+    rest = o.rest_mesh()[0]
+    assert np.abs(got[0][:, [0, 2]] - rest[:, [0, 2]]).max() <= np.abs(DT[..., [0, 2]]).max() / 8 * 1.001
+    o.close()
+    with mw.Ocean(resolution=64, length=64.0) as f:               # FFTMesh handle: wrong semantics
+        with pytest.raises(mw.MistralWaterError) as e:
+            f.generate_texture_rgba(0.1)
+        assert e.value.status == mw.MW_ESTATE
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("resolution", [8, 32, 128])
 def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
