@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mistral_water.h"
@@ -15,7 +16,8 @@ struct OrState {
     OrConsts c{};
     float mult = 1.f, choppiness = 0.f;
     f4* initT = nullptr;
-    float* phaseT = nullptr;
+    float* omT = nullptr;  // [px][py] angular frequency (or_omega), fixed per handle
+    float *phaseT = nullptr, *phaseT2 = nullptr;  // current phase / next phase (swapped after every frame)
     cf *TW = nullptr, *E = nullptr;
     float *out_height = nullptr, *out_disp_g = nullptr, *out_normal = nullptr, *out_white = nullptr;
     cf* out_disp_cf = nullptr;
@@ -26,6 +28,11 @@ struct OrState {
 static thread_local std::string g_or_err;
 static inline const char* or_last_error() { return g_or_err.c_str(); }
 
+__global__ void k_or_omega(OrConsts c, float* omT) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= c.M * c.M) return;
+    omT[idx] = or_omega(c, idx / c.M, idx % c.M);  // transposed enumeration [px][py]
+}
 __global__ void k_or_init(int M, float length, float wind_x, float wind_y, float amp, float gravity, uint64_t seed, f4* initT,
                           float* phaseT) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,18 +66,16 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Arg
     using G = OrP1Geom<N, P>;
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = FftGeom<N, P>::T;
-    const int tid = threadIdx.x, jb = blockIdx.x;
+    const int tid = threadIdx.x, jb = blockIdx.x, f = blockIdx.y;  // one field per block
     const int w = tid / T, u = tid % T;
     if (TwGeom<N, P>::IN_LDS)
         for (int i = tid; i < TwGeom<N, P>::TOTAL; i += G::NTHREADS) lds[i] = A.TW[i];
     const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
     cf* set0 = lds + G::TW_LDS;
     cf h[P], x[P];
-    or_p1_animate<N, P>(A, jb, tid, h);
-#pragma unroll
-    for (int f = 0; f < 3; f++) {
+    or_p1_animate<N, P>(A, jb, tid, f == 0, h);
+    {
         or_p1_build<N, P>(A, jb, tid, f, h, x);
-        if (f) __syncthreads();
         stage0_store<N, P, -1>(x, u, set0 + w * G::BUFSTRIDE);
         __syncthreads();
 #pragma unroll
@@ -97,10 +102,11 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
     cf* set0 = lds + G::TW_LDS;
     cf x[P];
     float dx[P];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
+    // grid.y = 0: hx then hz (their real parts leave interleaved as displacementTexture.rb); grid.y = 1: h
+    const int k0 = blockIdx.y == 0 ? 0 : 2, k1 = blockIdx.y == 0 ? 2 : 3;
+    for (int k = k0; k < k1; k++) {
         const int f = or_p2_field(k);
-        if (k) __syncthreads();
+        if (k != k0) __syncthreads();
         or_p2_load<N, P>(A, ab, tid, f, x, set0);
         __syncthreads();
 #pragma unroll
@@ -114,14 +120,13 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
     }
 }
 
-__global__ void k_or_normal(OrConsts c, const float* height, const cf* disp, const float* disp_g, float* normal) {
+// F/OceanNormal.shader + F/WhiteCap.shader in one launch: WhiteCap reads _Bump at its own texel only (:38), so the thread
+// that produced the normal goes straight on to the whitecap (its own global write is visible to itself).
+__global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float* height, const cf* disp, const float* disp_g,
+                                                         float* normal, float* white) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= c.M * c.M) return;
     or_normal_element(c, idx % c.M, idx / c.M, height, disp, disp_g, normal);
-}
-__global__ void k_or_white(OrConsts c, const cf* disp, const float* normal, float* white) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= c.M * c.M) return;
     or_white_element(c, idx % c.M, idx / c.M, disp, normal, white);
 }
 
@@ -142,7 +147,7 @@ std::vector<cf> build_twiddle_table(int N, int P, int sgn);  // mistral_water.hi
 int plan_points_host(int N);
 
 static inline void or_free(OrState& s) {
-    hipFree(s.initT); hipFree(s.phaseT); hipFree(s.TW); hipFree(s.E); hipFree(s.out_height); hipFree(s.out_disp_cf);
+    hipFree(s.initT); hipFree(s.phaseT); hipFree(s.phaseT2); hipFree(s.omT); hipFree(s.TW); hipFree(s.E); hipFree(s.out_height); hipFree(s.out_disp_cf);
     hipFree(s.out_disp_g); hipFree(s.out_normal); hipFree(s.out_white); hipFree(s.out_height_g); hipFree(s.out_disp_a);
     s = OrState();
 }
@@ -154,7 +159,7 @@ static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStre
     const size_t MM = (size_t)M * M;
     std::vector<cf> tab = build_twiddle_table(M, plan_points_host(M), -1);
 #define OR_ALLOC(ptr, bytes) if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { g_or_err = "OceanRenderer: hipMalloc failed"; return MW_ENOMEM; }
-    OR_ALLOC(s.initT, sizeof(f4) * MM) OR_ALLOC(s.phaseT, sizeof(float) * MM) OR_ALLOC(s.TW, sizeof(cf) * tab.size())
+    OR_ALLOC(s.initT, sizeof(f4) * MM) OR_ALLOC(s.phaseT, sizeof(float) * MM) OR_ALLOC(s.phaseT2, sizeof(float) * MM) OR_ALLOC(s.omT, sizeof(float) * MM) OR_ALLOC(s.TW, sizeof(cf) * tab.size())
     OR_ALLOC(s.E, sizeof(cf) * 3 * MM) OR_ALLOC(s.out_height, sizeof(float) * MM) OR_ALLOC(s.out_disp_cf, sizeof(cf) * MM)
     OR_ALLOC(s.out_disp_g, sizeof(float) * MM) OR_ALLOC(s.out_normal, sizeof(float) * 3 * MM) OR_ALLOC(s.out_white, sizeof(float) * MM)
 #undef OR_ALLOC
@@ -162,6 +167,7 @@ static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStre
     if (hipMemcpy(s.TW, tab.data(), sizeof(cf) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { g_or_err = "twiddle upload failed"; return MW_EDEVICE; }
     k_or_init<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(M, p.length, p.wind_x, p.wind_y, p.amplitude / 10000.f,
                                                                        p.gravity, p.seed, s.initT, s.phaseT);
+    k_or_omega<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(s.c, s.omT);
     if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_init launch failed"; return MW_EDEVICE; }
     return MW_OK;
 }
@@ -183,15 +189,16 @@ static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
         attr_done = true;
     }
     OrP1Args A1;
-    A1.initT = s.initT; A1.phaseT = s.phaseT; A1.TW = s.TW; A1.E = s.E; A1.c = s.c; A1.dt = dt;
+    A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.E = s.E; A1.c = s.c; A1.dt = dt;
     constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
-    k_or_pass1<N, P><<<dim3(N / 4), dim3(NT1), LB1, st>>>(A1);
+    k_or_pass1<N, P><<<dim3(N / 4, 3), dim3(NT1), LB1, st>>>(A1);
+    std::swap(s.phaseT, s.phaseT2);
     OrP2Args A2;
     A2.E = s.E; A2.TW = s.TW; A2.height = s.out_height; A2.disp = s.out_disp_cf; A2.disp_g = s.out_disp_g; A2.c = s.c;
     A2.height_g = s.want_imag ? s.out_height_g : nullptr;
     A2.disp_a = s.want_imag ? s.out_disp_a : nullptr;
     constexpr int NT2 = OrP2Geom<N, P>::NTHREADS, LB2 = OrP2Geom<N, P>::LDS_BYTES;
-    k_or_pass2<N, P><<<dim3(N / 4), dim3(NT2), LB2, st>>>(A2);
+    k_or_pass2<N, P><<<dim3(N / 4, 2), dim3(NT2), LB2, st>>>(A2);
     return hipGetLastError();
 }
 
@@ -221,8 +228,7 @@ static inline mw_status or_generate(OrState& s, float delta_time, float* d_heigh
     if (e != hipSuccess) { g_or_err = std::string("OceanRenderer pass launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
     const size_t MM = (size_t)s.M * s.M;
     const unsigned nb = (unsigned)((MM + 255) / 256);
-    k_or_normal<<<dim3(nb), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal);
-    k_or_white<<<dim3(nb), dim3(256), 0, st>>>(s.c, s.out_disp_cf, s.out_normal, s.out_white);
+    k_or_normal_white<<<dim3(nb), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white);
     if (hipGetLastError() != hipSuccess) { g_or_err = "OceanRenderer normal/white launch failed"; return MW_EDEVICE; }
     s.have_frame = true;
     s.have_imag = s.want_imag;

@@ -1,6 +1,8 @@
 // ocean_renderer_kernels.h -- MW_SEM_OCEANRENDERER: the reference's fragment-shader pipeline ("B", SURVEY.md 8a
 // b1-b13) as three kernels instead of 1 + 45 full-screen blits per frame:
-//   k_or_pass1   Dispersion + Spectrum + SpectrumHeight passes fused with the transform along py
+//   k_or_pass1   Dispersion + Spectrum + SpectrumHeight passes fused with the transform along py; grid (M/4, 3 fields):
+//                a frame is ONE 1024^2 texture, so the launch is latency- not bandwidth-bound and the three fields of
+//                a column job run as three concurrent blocks (each recomputes the cheap h~, one of them stores the phase)
 //                (F/Dispersion.shader:32-41, F/Spectrum.shader:34-51, F/SpectrumHeight.shader:34-47, F/Stockham.shader)
 //   k_or_pass2   transform along px, writes height.r / displacement.rgb      (S/OceanRenderer.cs:229-298)
 //   k_or_normal_white   F/OceanNormal.shader:39-56 + F/WhiteCap.shader:33-45 (need +-1 / +-8 texel neighbours)
@@ -62,20 +64,33 @@ MW_HD void or_init_element(int M, float length, float wind_x, float wind_y, floa
     initT[(size_t)px * M + py] = v;
     phaseT[(size_t)px * M + py] = 0.f;  // the phase render targets start at 0
 }
-// F/FFTCommon.cginc:101-114: phase <- fmod(phase + sqrt(G |k| (1 + |k|^2/370^2)) dt, 2 pi), strict float32
-MW_HD float or_phase_advance(const OrConsts& c, int px, int py, float old_phase, float dt) {
+// F/FFTCommon.cginc:101-114: phase <- fmod(phase + sqrt(G |k| (1 + |k|^2/370^2)) dt, 2 pi), strict float32.
+// The angular frequency does not depend on time: it is tabulated once (or_omega, 4 strict divisions + 2 square roots per
+// texel) and the per-frame update is one multiply, one add and the remainder -- the same operation sequence, bit for bit.
+MW_HD float or_omega(const OrConsts& c, int px, int py) {
     const float kx = or_wave(c.M, c.length, px), kz = or_wave(c.M, c.length, py);
     const float wlen = ssqrt(sadd(smul(kx, kx), smul(kz, kz)));
     const float q = sdiv(sdiv(smul(wlen, wlen), 370.f), 370.f);
     const float inner = smul(smul(c.gravity, wlen), sadd(1.f, q));
-    const float dphi = smul(ssqrt(inner), dt);
-    return fmodf(sadd(old_phase, dphi), smul(2.0f, MW_PI_F));
+    return ssqrt(inner);
+}
+MW_HD float or_phase_step(float omega, float old_phase, float dt) {
+    const float x = sadd(old_phase, smul(omega, dt)), twopi = smul(2.0f, MW_PI_F);
+    // fmod(x, 2 pi) is x on [0, 2 pi) and exactly x - 2 pi on [2 pi, 4 pi) (Sterbenz); anything else takes the library path
+    if (x >= 0.f && x < twopi) return x;
+    if (x >= twopi && x < sadd(twopi, twopi)) return ssub(x, twopi);
+    return fmodf(x, twopi);
+}
+MW_HD float or_phase_advance(const OrConsts& c, int px, int py, float old_phase, float dt) {
+    return or_phase_step(or_omega(c, px, py), old_phase, dt);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 struct OrP1Args {
     const f4* initT;  // [px][py] (h0, conj h0')
-    float* phaseT;    // [px][py] stateful phase
+    const float* omT;       // [px][py] or_omega table
+    const float* phase_in;  // [px][py] stateful phase of the previous frame
+    float* phase_out;       // [px][py] advanced phase (ping-pong like the reference's two R32F targets, S/OceanRenderer.cs:221)
     const cf* TW;     // forward (SGN = -1) twiddle tables, TwGeom layout
     cf* E;            // [3][M/4][M][4]
     OrConsts c;
@@ -90,16 +105,17 @@ struct OrP1Geom {
     static constexpr int LDS_BYTES = (TW_LDS + 4 * BUFSTRIDE) * (int)sizeof(cf);
 };
 // Dispersion + h~ for the 4 texel columns px = 4 jb .. 4 jb + 3 (transform index = py = u + T q)
+// Every field's block recomputes the advanced phase from phase_in; only the field-0 block stores it (write_phase).
 template <int N, int P>
-MW_HD void or_p1_animate(const OrP1Args& A, int jb, int tid, cf (&h)[P]) {
+MW_HD void or_p1_animate(const OrP1Args& A, int jb, int tid, bool write_phase, cf (&h)[P]) {
     constexpr int T = FftGeom<N, P>::T;
     const int w = tid / T, u = tid % T, px = 4 * jb + w;
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int py = u + T * q;
         const size_t idx = (size_t)px * N + py;
-        const float ph = or_phase_advance(A.c, px, py, A.phaseT[idx], A.dt);
-        A.phaseT[idx] = ph;
+        const float ph = or_phase_step(A.omT[idx], A.phase_in[idx], A.dt);
+        if (write_phase) A.phase_out[idx] = ph;
         const f4 v = A.initT[idx];
         float s, c;
         mw_sincos(ph, &s, &c);
@@ -204,7 +220,7 @@ MW_HD void or_normal_element(const OrConsts& c, int px, int py, const float* hei
 }
 MW_HD void or_white_element(const OrConsts& c, int px, int py, const cf* disp, const float* normal, float* white) {
     const int M = c.M;
-    const size_t idx = (size_t)py * M + px;
+    const size_t idx = (size_t)py * M + px;  // reads the normal of its own texel only, so one thread can do both passes
     // texelSize = 1/_Length with _Length = resolution = M/8 (S/OceanRenderer.cs:306): +-8 texels
     const cf ym = disp[(size_t)or_clamp(py - 8, M - 1) * M + px], yp = disp[(size_t)or_clamp(py + 8, M - 1) * M + px];
     const cf xm = disp[(size_t)py * M + or_clamp(px - 8, M - 1)], xp = disp[(size_t)py * M + or_clamp(px + 8, M - 1)];

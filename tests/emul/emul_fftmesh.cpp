@@ -180,14 +180,18 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
     std::vector<cf> E((size_t)3 * N * N);
     {
         OrP1Args A;
-        A.initT = initT; A.phaseT = phaseT; A.TW = tb.TW.data(); A.E = E.data(); A.c = C; A.dt = dt;
+        std::vector<float> phase_next((size_t)N * N), om((size_t)N * N);
+        for (int px = 0; px < N; px++)
+            for (int py = 0; py < N; py++) om[(size_t)px * N + py] = or_omega(C, px, py);
+        A.omT = om.data();
+        A.initT = initT; A.phase_in = phaseT; A.phase_out = phase_next.data(); A.TW = tb.TW.data(); A.E = E.data(); A.c = C; A.dt = dt;
         constexpr int NT = OrP1Geom<N, P>::NTHREADS, BS = OrP1Geom<N, P>::BUFSTRIDE;
         std::vector<cf> lds(4 * BS);
         struct St { cf h[P]; cf x[P]; };
         std::vector<St> st(NT);
-        for (int jb = 0; jb < N / 4; jb++) {
-            for (int tid = 0; tid < NT; tid++) or_p1_animate<N, P>(A, jb, tid, st[tid].h);
-            for (int f = 0; f < 3; f++) {
+        for (int jb = 0; jb < N / 4; jb++)
+            for (int f = 0; f < 3; f++) {  // grid (N/4, 3): one field per block
+                for (int tid = 0; tid < NT; tid++) or_p1_animate<N, P>(A, jb, tid, f == 0, st[tid].h);
                 for (int tid = 0; tid < NT; tid++) {
                     or_p1_build<N, P>(A, jb, tid, f, st[tid].h, st[tid].x);
                     stage0_store<N, P, -1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
@@ -198,7 +202,7 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
                 }
                 for (int tid = 0; tid < NT; tid++) or_p1_finish<N, P>(A, tw, jb, tid, f, st[tid].x, lds.data());
             }
-        }
+        std::memcpy(phaseT, phase_next.data(), sizeof(float) * (size_t)N * N);  // the ping-pong swap
     }
     {
         OrP2Args A;

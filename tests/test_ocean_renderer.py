@@ -82,7 +82,7 @@ def test_emulated_kernels_vs_oracle(emul, oracle, resolution):
     assert np.abs(initT.transpose(1, 0, 2) - init4).max() < 3e-6 * sc   # generation: libm differences only
     initT = np.ascontiguousarray(init4.transpose(1, 0, 2))              # then inject identical spectra
     ph = np.zeros((M, M), np.float32)
-    for frame, dt in enumerate((0.016, 0.033, 0.3)):
+    for frame, dt in enumerate((0.016, 0.033, 0.3, 25.0)):     # 25 s: phase steps beyond 4 pi (library fmod path)
         h, d, n, w, g = emul.or_step(rp, initT, phaseT, dt)
         H, D, Nn, W, G = oracle.renderer_step_f64(rp, init4, ph, dt, literal_passes=(M <= 128))
         assert (phaseT.T == ph).all(), "stateful f32 phase must match bit for bit"
@@ -185,7 +185,7 @@ def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
     # (2) with the SAME spectrum injected, every frame matches to float32 transform accuracy
     o.set_spectrum(init4[..., :2], init4[..., 2:])
     ph = np.zeros((M, M), np.float32)
-    for dt in (0.016, 0.033, 0.3):
+    for dt in (0.016, 0.033, 0.3, 25.0):
         h, d, n, w = o.generate_texture(dt)
         H, D, Nn, W, G = oracle.renderer_step_f64(rp, init4, ph, dt, literal_passes=False)
         tol_check(h, H, 3e-6, "height"); tol_check(d, D, 3e-6, "disp")
@@ -193,7 +193,7 @@ def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
         # nearly cancel: at those isolated texels 1/|n| amplifies float32 rounding.  Bound the bulk tightly and the
         # ill-conditioned tail loosely.
         en, ew = np.abs(n - Nn).max(-1).ravel(), np.abs(w - W).ravel()
-        assert np.quantile(en, 0.999) < 1e-4 and np.median(en) < 2e-6 and en.max() < 1e-2, (float(np.quantile(en, 0.999)), float(en.max()))
+        assert np.quantile(en, 0.999) < 1e-4 and np.median(en) < 3e-6 and en.max() < 1e-2, (float(np.quantile(en, 0.999)), float(en.max()))
         assert np.quantile(ew, 0.999) < 1e-4 and ew.max() < 1e-2, (float(np.quantile(ew, 0.999)), float(ew.max()))
     o.close()
 
