@@ -327,24 +327,35 @@ struct P2Args {
     OceanConsts c;
 };
 
-template <int N, int P, int R2>
+template <int N, int P>
+struct P2Buf { static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4; };  // one row's exchange buffer, cf units
+
+// HS = "sequential halo" variant for large N (Plan<N>::HS): no halo thread group and no halo buffer -- the halo row is
+// transformed by group 0 AFTER the displacement field, in buffer 0, once rows 0..R2-2 have formed their Jacobians from
+// the published rows.  R2 full rows then fit where R2+1 did not (N = 4096: 4 rows = 136 KiB), so a workgroup consumes
+// whole 128-B exchange chunks.
+template <int N, int P, int R2, bool HS = false>
 struct P2Geom {
     static constexpr int T = FftGeom<N, P>::T;
-    static constexpr int NTHREADS = (R2 + 1) * T;
-    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4;
+    static constexpr int NGROUPS = HS ? R2 : R2 + 1;
+    static constexpr int NTHREADS = NGROUPS * T;
+    static constexpr int BUFSTRIDE = P2Buf<N, P>::BUFSTRIDE;
     static constexpr int TW_LDS = TwGeom<N, P>::IN_LDS ? ((TwGeom<N, P>::TOTAL + 1) & ~1) : 0;
-    static constexpr int SETSTRIDE = (R2 + 1) * BUFSTRIDE;
-    static constexpr int NBUF = (MW_DBUF && (TW_LDS + 2 * SETSTRIDE) * 8 <= 100 * 1024) ? 2 : 1;
+    static constexpr int SETSTRIDE = NGROUPS * BUFSTRIDE;
+    static constexpr int NBUF = (!HS && MW_DBUF && (TW_LDS + 2 * SETSTRIDE) * 8 <= 100 * 1024) ? 2 : 1;
     // the whitecap noise term |0.3 n.xz| waits in LDS (R2*N floats) from the slope field to the epilogue instead of
     // in P registers per thread: that is what lets pass 2 fit 80 VGPRs without scratch spills
+    static constexpr bool NOISE_REG = HS || !MW_NOISE_LDS;
     static constexpr int NOISE_OFF = TW_LDS + NBUF * SETSTRIDE;  // cf units
-    static constexpr int LDS_BYTES = NOISE_OFF * (int)sizeof(cf) + (MW_NOISE_LDS ? R2 * N * (int)sizeof(float) : 0);
+    static constexpr int NOISE_CF = NOISE_REG ? 0 : R2 * N / 2;
+    static constexpr int LDS_BYTES = (NOISE_OFF + NOISE_CF) * (int)sizeof(cf);
     static_assert(NTHREADS <= 1024, "workgroup too large");
 };
 
-template <int P>
+template <int P, bool NOISE_REG_ = !MW_NOISE_LDS>
 struct P2State {
-    float noise[MW_NOISE_LDS ? 1 : P];  // |0.3 n.xz| per slot (S/FFTMesh.cs:269-270) when it is not parked in LDS
+    static constexpr bool NOISE_REG = NOISE_REG_;
+    float noise[NOISE_REG_ ? P : 1];  // |0.3 n.xz| per slot (S/FFTMesh.cs:269-270) when it is not parked in LDS
     float h[P];      // height
     cf d[P];         // hds = (d.x, d.z), un-scaled by choppiness (S/FFTMesh.cs:247)
 };
@@ -398,7 +409,7 @@ template <int N, int P, int R2>
 MW_HD void p2_stage0(int tid, cf (&x)[P], cf* lds) {
     int r1, u1;
     p2_load_map<N, P, R2>(tid, &r1, &u1);
-    stage0_store<N, P, +1>(x, u1, lds + r1 * P2Geom<N, P, R2>::BUFSTRIDE);
+    stage0_store<N, P, +1>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE);
 }
 template <int N, int P, int R2>
 MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P], cf* lds) {
@@ -411,22 +422,22 @@ template <int N, int P, int R2>
 MW_HD void p2_mid_load(int tid, cf (&x)[P], const cf* lds) {
     int r1, u1;
     p2_load_map<N, P, R2>(tid, &r1, &u1);
-    load_slots<N, P>(x, u1, lds + r1 * P2Geom<N, P, R2>::BUFSTRIDE);
+    load_slots<N, P>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE);
 }
 template <int N, int P, int R2>
 MW_HD void p2_mid_store(const Twiddles& tw, int tid, int s, cf (&x)[P], cf* lds) {
     int r1, u1;
     p2_load_map<N, P, R2>(tid, &r1, &u1);
-    stage_store<N, P, +1>(x, u1, lds + r1 * P2Geom<N, P, R2>::BUFSTRIDE, tw, s);
+    stage_store<N, P, +1>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE, tw, s);
 }
 
 // final pass in the row-major mapping (thread (g,u) owns row a0+g, columns b = u + T q)
-template <int N, int P, int R2>
-MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int tid, int f, cf (&x)[P], P2State<P>& st,
+template <int N, int P, int R2, class ST>
+MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int tid, int f, cf (&x)[P], ST& st,
                      const cf* lds, float* noise_lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
-    load_slots<N, P>(x, u, lds + g * P2Geom<N, P, R2>::BUFSTRIDE);
+    load_slots<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
     final_stage<N, P, +1>(x, u, tw.TF);
     if (f == 2) {  // slopes -> unit normal (S/FFTMesh.cs:218), stored at once
         float* nblk = A.normals + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;  // block-uniform
@@ -445,7 +456,7 @@ MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int 
             nq[noff + 2] = nz;
             const float n0 = smul(fabsf(nx), 0.3f), n1 = smul(fabsf(nz), 0.3f);
             const float nz_ = ssqrt(sadd(smul(n0, n0), smul(n1, n1)));
-            if (MW_NOISE_LDS) noise_lds[g * N + b] = nz_; else st.noise[MW_NOISE_LDS ? 0 : q] = nz_;
+            if (!ST::NOISE_REG) noise_lds[g * N + b] = nz_; else st.noise[ST::NOISE_REG ? q : 0] = nz_;
         }
     } else if (f == 0) {
 #pragma unroll
@@ -460,55 +471,193 @@ MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int 
 }
 
 // hds rows into LDS (plain index b) so that neighbours (a+1,b) and (a,b+1) can be read back
-template <int N, int P, int R2>
-MW_HD void p2_publish_hds(int tid, const P2State<P>& st, cf* lds) {
+template <int N, int P, int R2, class ST>
+MW_HD void p2_publish_hds(int tid, const ST& st, cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T;
-    cf* row = lds + g * P2Geom<N, P, R2>::BUFSTRIDE;
+    cf* row = lds + g * P2Buf<N, P>::BUFSTRIDE;
 #pragma unroll
     for (int q = 0; q < P; q++) row[u + T * q] = st.d[q];
 }
 
-// S/FFTMesh.cs:243-247 (vertex), :251-276 (Jacobian / whitecap)
-template <int N, int P, int R2>
-MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const P2State<P>& st, const cf* lds,
-                       const float* noise_lds) {
+// S/FFTMesh.cs:243-247: the displaced vertex
+template <int N, int P, int R2, class ST>
+MW_HD void p2_vertices(const P2Args& A, int ab, int step, int tid, const ST& st) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
-    const cf* row = lds + g * P2Geom<N, P, R2>::BUFSTRIDE;
-    const cf* nxt = lds + (g + 1) * P2Geom<N, P, R2>::BUFSTRIDE;
+    float* vblk = A.vertices + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;          // block-uniform
+    const unsigned voff = (unsigned)((g * N + u) * 3);
+    const float rx = rest_coord(N, A.c.unit_width, a);
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int b = u + T * q;
+        const cf d = st.d[q];
+        float* vq = vblk + (size_t)T * q * 3;                                              // uniform
+        vq[voff + 0] = ssub(rx, smul(d.x, A.c.choppiness));                                // :245
+        vq[voff + 1] = st.h[q];                                                            // :243
+        vq[voff + 2] = ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness));  // :244
+    }
+}
+
+// neighbour provider of the halo-group variant: the row's own published copy
+struct NbRow {
+    const cf* row;
+    template <int P>
+    MW_HD cf right(const cf (&)[P], int, int b) const { return row[b + 1]; }
+};
+
+// S/FFTMesh.cs:258-268 for slot q of thread (g,u): 1 - J, J the Jacobian of the choppy displacement from forward
+// differences.  nxt = published hds of row a+1; nb.right() = hds of (a, b+1).
+template <int N, int P, int R2, class ST, class NB>
+MW_HD float p2_one_minus_jacobian(int a, int b, int q, const ST& st, const cf* nxt, const NB& nb) {
+    const bool has_i = (a != N - 1), has_j = (b != N - 1);
+    const cf d = st.d[q];
+    const cf rj = nb.right(st.d, q, has_j ? b : b - 1);
+    const cf dn_i = has_i ? nxt[b] : mk(0.f, 0.f);
+    const cf dn_j = has_j ? rj : mk(0.f, 0.f);
+    float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
+    if (has_i) { ax = smul(0.5f, ssub(d.x, dn_i.x)); ay = smul(0.5f, ssub(d.y, dn_i.y)); }  // :260-263
+    if (has_j) { bx = smul(0.5f, ssub(d.x, dn_j.x)); by = smul(0.5f, ssub(d.y, dn_j.y)); }  // :264-267
+    const float jac = ssub(smul(sadd(1.f, ax), sadd(1.f, by)), smul(ay, bx));              // :268
+    return ssub(1.f, jac);
+}
+// S/FFTMesh.cs:269-274: turbulence = max(1 - J + |0.3 n.xz|, 0) -> smoothstep -> Color
+MW_HD void p2_store_white(float* wq, unsigned woff, int white_stride, float one_minus_jac, float noise) {
+    const float turb = fmaxf(sadd(one_minus_jac, noise), 0.f);  // :270
+    const float xx = smoothstep01(turb);                        // :273
+    if (white_stride == 1) {
+        wq[woff] = xx;
+    } else {
+        wq[woff + 0] = xx; wq[woff + 1] = xx; wq[woff + 2] = xx; wq[woff + 3] = xx;  // :274
+    }
+}
+// halo-group variant: vertex + whitecap of one thread's slots from the rows published in LDS, slot by slot (measured
+// 1 % faster than all vertices first, then all whitecaps)
+template <int N, int P, int R2, class ST>
+MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const ST& st, const cf* lds, const float* noise_lds) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int g = tid / T, u = tid % T, a = ab * R2 + g;
+    NbRow nb;
+    nb.row = lds + g * P2Buf<N, P>::BUFSTRIDE;
+    const cf* nxt = lds + (g + 1) * P2Buf<N, P>::BUFSTRIDE;
     float* vblk = A.vertices + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;          // block-uniform
     float* wblk = A.white + ((size_t)step * N * N + (size_t)ab * R2 * N) * A.white_stride;
     const unsigned voff = (unsigned)((g * N + u) * 3), woff = (unsigned)((g * N + u) * A.white_stride);
     const float rx = rest_coord(N, A.c.unit_width, a);
-    const bool has_i = (a != N - 1);
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int b = u + T * q;
-        const bool has_j = (b != N - 1);
         const cf d = st.d[q];
-        const cf dn_i = has_i ? nxt[b] : mk(0.f, 0.f);
-        const cf dn_j = has_j ? row[b + 1] : mk(0.f, 0.f);
         float* vq = vblk + (size_t)T * q * 3;                                              // uniform
-        float* wq = wblk + (size_t)T * q * A.white_stride;
         vq[voff + 0] = ssub(rx, smul(d.x, A.c.choppiness));                                // :245
         vq[voff + 1] = st.h[q];                                                            // :243
         vq[voff + 2] = ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness));  // :244
-        float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
-        if (has_i) { ax = smul(0.5f, ssub(d.x, dn_i.x)); ay = smul(0.5f, ssub(d.y, dn_i.y)); }  // :260-263
-        if (has_j) { bx = smul(0.5f, ssub(d.x, dn_j.x)); by = smul(0.5f, ssub(d.y, dn_j.y)); }  // :264-267
-        const float jac = ssub(smul(sadd(1.f, ax), sadd(1.f, by)), smul(ay, bx));          // :268
-        const float nz_ = MW_NOISE_LDS ? noise_lds[g * N + b] : st.noise[MW_NOISE_LDS ? 0 : q];
-        const float turb = fmaxf(sadd(ssub(1.f, jac), nz_), 0.f);                          // :270
-        const float xx = smoothstep01(turb);                                               // :273
-        if (A.white_stride == 1) {
-            wq[woff] = xx;
-        } else {
-            wq[woff + 0] = xx; wq[woff + 1] = xx; wq[woff + 2] = xx; wq[woff + 3] = xx;  // :274
-        }
-#if defined(__HIP_DEVICE_COMPILE__) && defined(MW_EPILOGUE_FENCE)
-        __builtin_amdgcn_sched_barrier(0);  // keep the q iterations apart: fewer live temporaries
-#endif
+        const float omj = p2_one_minus_jacobian<N, P, R2>(a, b, q, st, nxt, nb);
+        const float nz_ = !ST::NOISE_REG ? noise_lds[g * N + b] : st.noise[ST::NOISE_REG ? q : 0];
+        p2_store_white(wblk + (size_t)T * q * A.white_stride, woff, A.white_stride, omj, nz_);
+    }
+}
+
+// ---- sequential-halo variant (P2Geom<..., true>) ---------------------------------------------------------------
+// Field order height, displacement, [vertices out, halo row, 1 - J per slot], slopes: the whitecap is finished in the
+// slope field's final pass, so no noise term waits anywhere and at most h+x / d+x / omj+x are live at a time.
+template <int P>
+struct P2StateHS {
+    float h[P];    // height                    (dead once the vertices are stored)
+    cf d[P];       // hds                       (dead once omj is formed)
+    float omj[P];  // 1 - Jacobian per slot     (born after the halo row)
+};
+MW_HD int p2_hs_field(int k) { return k == 0 ? 0 : (k == 1 ? 1 : 2); }
+
+// final pass of the height (f = 0) or displacement (f = 1) field, row-major mapping
+template <int N, int P, int R2>
+MW_HD void p2_hs_finish(const Twiddles& tw, int ab, int tid, int f, cf (&x)[P], P2StateHS<P>& st, const cf* lds) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int g = tid / T, u = tid % T, a = ab * R2 + g;
+    load_slots<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
+    final_stage<N, P, +1>(x, u, tw.TF);
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const float sg = post_sign(a, u + T * q);
+        if (f == 0) st.h[q] = sg * x[q].x;
+        else st.d[q] = mk(sg * x[q].x, sg * x[q].y);
+    }
+}
+// 1 - J of a thread's slots: d from registers, (a, b+1) from the row's own published copy, (a+1, b) from nxt
+template <int N, int P, int R2>
+MW_HD void p2_hs_jacobian(int ab, int tid, P2StateHS<P>& st, const cf* own, const cf* nxt) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int g = tid / T, u = tid % T, a = ab * R2 + g;
+    NbRow nb;
+    nb.row = own;
+#pragma unroll
+    for (int q = 0; q < P; q++) st.omj[q] = p2_one_minus_jacobian<N, P, R2>(a, u + T * q, q, st, nxt, nb);
+}
+// the same for the block's last row, entirely from LDS: own = its published hds row, nxt = the halo row
+template <int P>
+struct P2RowView { cf d[P]; };
+template <int N, int P, int R2>
+MW_HD void p2_hs_jacobian_lds(int ab, int tid, P2StateHS<P>& st, const cf* own, const cf* nxt) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int u = tid % T, a = ab * R2 + R2 - 1;
+    NbRow nb;
+    nb.row = own;
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int b = u + T * q;
+        P2RowView<P> v;
+        v.d[q] = own[b];
+        st.omj[q] = p2_one_minus_jacobian<N, P, R2>(a, b, q, v, nxt, nb);
+    }
+}
+// final pass of the slope field: unit normal (S/FFTMesh.cs:218) and, with the waiting 1 - J, the whitecap
+template <int N, int P, int R2>
+MW_HD void p2_hs_finish_slopes(const P2Args& A, const Twiddles& tw, int ab, int step, int tid, cf (&x)[P],
+                               const P2StateHS<P>& st, const cf* lds) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int g = tid / T, u = tid % T, a = ab * R2 + g;
+    load_slots<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
+    final_stage<N, P, +1>(x, u, tw.TF);
+    float* nblk = A.normals + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;  // block-uniform
+    float* wblk = A.white + ((size_t)step * N * N + (size_t)ab * R2 * N) * A.white_stride;
+    const unsigned noff = (unsigned)((g * N + u) * 3), woff = (unsigned)((g * N + u) * A.white_stride);
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int b = u + T * q;
+        float* nq = nblk + (size_t)T * q * 3;
+        const float sg = post_sign(a, b);
+        const float sx = sg * x[q].x, sz = sg * x[q].y;
+        const float inv = mw_rsqrt(sx * sx + 1.0f + sz * sz);
+        const float nx = sx * inv, ny = inv, nz = sz * inv;
+        nq[noff + 0] = nx;
+        nq[noff + 1] = ny;
+        nq[noff + 2] = nz;
+        const float n0 = smul(fabsf(nx), 0.3f), n1 = smul(fabsf(nz), 0.3f);
+        const float nz_ = ssqrt(sadd(smul(n0, n0), smul(n1, n1)));  // :269
+        p2_store_white(wblk + (size_t)T * q * A.white_stride, woff, A.white_stride, st.omj[q], nz_);
+    }
+}
+
+// halo row a0+R2 of the displacement field, loaded by group 0 in the row-major mapping (thread u: j = u + T q)
+template <int N, int P, int R2>
+MW_HD void p2_hs_halo_fetch(const P2Args& A, int ab, int step, int u, cf (&x)[P]) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int row = ab * R2 + R2;
+    const cf* Ef = A.E + ((size_t)step * 3 + 1) * N * N + (size_t)row * 4;  // block-uniform
+    const unsigned voff = (unsigned)((u >> 2) * N * 4 + (u & 3));
+#pragma unroll
+    for (int q = 0; q < P; q++) x[q] = (Ef + (size_t)(T / 4) * q * N * 4)[voff];
+    if (u == 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + 1) * N + row];  // Nyquist column j = 0
+}
+// transformed halo row -> plain hds row in buffer 0
+template <int N, int P, int R2>
+MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int a = ab * R2 + R2;
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const float sg = post_sign(a, u + T * q);
+        buf0[u + T * q] = mk(sg * x[q].x, sg * x[q].y);
     }
 }
 
@@ -526,7 +675,12 @@ template <int N> struct Plan {
     static constexpr int P = (N >= 2048) ? 16 : MW_PT;    // OceanRenderer passes
     static constexpr int P1 = (N >= 2048) ? 16 : MW_PT1;  // 5 x N/8 threads would exceed 1024 at N = 2048
     static constexpr int P2 = (N >= 2048) ? 16 : MW_PT2;
-    static constexpr int R2 = (N >= 4096) ? 2 : 4;
+#ifndef MW_HS_MIN_N
+#define MW_HS_MIN_N 4096  // grids from this size up use the sequential-halo pass 2 (P2Geom<..., true>); measured:
+                          // 4096^2 +9 % over 2 rows + halo group, 2048^2 -8 % against 4 rows + halo group
+#endif
+    static constexpr bool HS = (N >= MW_HS_MIN_N);
+    static constexpr int R2 = HS ? 4 : ((N >= 4096) ? 2 : 4);
 };
 
 }  // namespace mw

@@ -235,6 +235,77 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
     MW_STAMP(1, 27);
 }
 
+// Pass 2, sequential-halo variant (large N): R2 row groups, no halo group.  Height and displacement fields first; then
+// the vertices leave, every row publishes hds, rows 0..R2-2 form 1 - J, group 0 transforms the halo row in buffer 0, row R2-1 follows;
+// the slope field comes last and its final pass writes normals and whitecap together.
+template <int N, int P, int R2>
+__global__ __launch_bounds__((P2Geom<N, P, R2, true>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(4))) void k_pass2_hs(P2Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = P2Geom<N, P, R2, true>;
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = FftGeom<N, P>::T;
+    const int tid = threadIdx.x, step = blockIdx.y, ab = blockIdx.x;
+    const int g = wave_uniform<true>(tid / T), u = tid % T;
+    if (TwGeom<N, P>::IN_LDS) stage_tables<TwGeom<N, P>::TOTAL, G::NTHREADS>(lds, A.TW, tid);
+    const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
+    cf* set0 = lds + G::TW_LDS;
+    P2StateHS<P> st;
+    cf x[P];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int f = p2_hs_field(k);
+        __syncthreads();  // k = 0: twiddle tables staged; later: the previous phase's LDS reads are done
+        p2_load<N, P, R2>(A, ab, step, tid, f, x, set0);
+        __syncthreads();
+#pragma unroll
+        for (int s = 1; s < FftGeom<N, P>::S; s++) {
+            p2_mid_load<N, P, R2>(tid, x, set0);
+            __syncthreads();
+            p2_mid_store<N, P, R2>(tw, tid, s, x, set0);
+            __syncthreads();
+        }
+        if (f == 2) {
+            p2_hs_finish_slopes<N, P, R2>(A, tw, ab, step, tid, x, st, set0);
+            break;
+        }
+        p2_hs_finish<N, P, R2>(tw, ab, tid, f, x, st, set0);
+        if (f != 1) continue;
+        // ---- displacement done: vertices, halo row, Jacobian ----
+        p2_vertices<N, P, R2>(A, ab, step, tid, st);
+        __syncthreads();  // every final-pass read of the displacement buffers is done
+        p2_publish_hds<N, P, R2>(tid, st, set0);  // every row into its own buffer, plain index b
+        __syncthreads();
+        const bool has_halo = (ab * R2 + R2 < N);  // block-uniform
+        // Rows 0..R2-2 have their (a+1) neighbour published already: they form 1 - J now.  Buffer 0 (row 0's copy) is
+        // then free for the halo row's transform; row R2-1 waits for it and works from its own published copy, so that
+        // nobody's d is live across the halo transform (P = 16: the transform alone takes ~100 VGPRs).
+        if (g != R2 - 1) p2_hs_jacobian<N, P, R2>(ab, tid, st, set0 + g * G::BUFSTRIDE, set0 + (g + 1) * G::BUFSTRIDE);
+        __syncthreads();  // group 0 no longer reads its own row
+        if (has_halo) {
+            if (g == 0) {
+                p2_hs_halo_fetch<N, P, R2>(A, ab, step, u, x);
+                stage0_store<N, P, +1>(x, u, set0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 1; s < FftGeom<N, P>::S; s++) {
+                if (g == 0) load_slots<N, P>(x, u, set0);
+                __syncthreads();
+                if (g == 0) stage_store<N, P, +1>(x, u, set0, tw, s);
+                __syncthreads();
+            }
+            if (g == 0) {
+                load_slots<N, P>(x, u, set0);
+                final_stage<N, P, +1>(x, u, tw.TF);
+            }
+            __syncthreads();
+            if (g == 0) p2_hs_halo_publish<N, P, R2>(ab, u, x, set0);
+            __syncthreads();
+        }
+        if (g == R2 - 1) p2_hs_jacobian_lds<N, P, R2>(ab, tid, st, set0 + (R2 - 1) * G::BUFSTRIDE, set0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------------
@@ -361,17 +432,23 @@ static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nstep
 template <int N>
 static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     constexpr int P = Plan<N>::P2, R2 = Plan<N>::R2;
+    constexpr bool HS = Plan<N>::HS;
+    constexpr int NT = P2Geom<N, P, R2, HS>::NTHREADS, LB = P2Geom<N, P, R2, HS>::LDS_BYTES;
     static bool attr_done[64] = {false};
     int dev = 0;
     hipGetDevice(&dev);
     if (!attr_done[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<N, P, R2>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, P2Geom<N, P, R2>::LDS_BYTES);
+        const void* fn;
+        if constexpr (HS) fn = reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2>);
+        else fn = reinterpret_cast<const void*>(&k_pass2<N, P, R2>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LB);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
-    constexpr int NT = P2Geom<N, P, R2>::NTHREADS, LB = P2Geom<N, P, R2>::LDS_BYTES;
-    k_pass2<N, P, R2><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
+    if constexpr (HS)
+        k_pass2_hs<N, P, R2><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
+    else
+        k_pass2<N, P, R2><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
     return hipGetLastError();
 }
 

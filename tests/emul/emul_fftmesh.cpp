@@ -82,6 +82,8 @@ void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
         }
 }
 
+static bool g_force_hs = false;  // emul_set_variant: run the sequential-halo pass 2 regardless of Plan<N>::HS
+
 template <int N, int P, int R2>
 void run_pass2(const P2Args& A, int nsteps) {
     constexpr int T = FftGeom<N, P>::T, NT = P2Geom<N, P, R2>::NTHREADS, BS = P2Geom<N, P, R2>::BUFSTRIDE;
@@ -113,10 +115,57 @@ void run_pass2(const P2Args& A, int nsteps) {
         }
 }
 
+// the sequential-halo variant (k_pass2_hs), phase by phase; runs at any N here so that small grids exercise it too
+template <int N, int P, int R2>
+void run_pass2_hs(const P2Args& A, int nsteps) {
+    constexpr int T = FftGeom<N, P>::T, NT = P2Geom<N, P, R2, true>::NTHREADS, BS = P2Buf<N, P>::BUFSTRIDE;
+    std::vector<cf> lds(R2 * BS);
+    const Twiddles tw = TwGeom<N, P>::view(A.TW);
+    struct St { P2StateHS<P> s; cf x[P]; };
+    std::vector<St> st(NT);
+    for (int step = 0; step < nsteps; step++)
+        for (int ab = 0; ab < N / R2; ab++)
+            for (int k = 0; k < 3; k++) {
+                const int f = p2_hs_field(k);
+                for (int tid = 0; tid < NT; tid++) p2_load<N, P, R2>(A, ab, step, tid, f, st[tid].x, lds.data());
+                for (int s = 1; s < FftGeom<N, P>::S; s++) {
+                    for (int tid = 0; tid < NT; tid++) p2_mid_load<N, P, R2>(tid, st[tid].x, lds.data());
+                    for (int tid = 0; tid < NT; tid++) p2_mid_store<N, P, R2>(tw, tid, s, st[tid].x, lds.data());
+                }
+                if (f == 2) {
+                    for (int tid = 0; tid < NT; tid++)
+                        p2_hs_finish_slopes<N, P, R2>(A, tw, ab, step, tid, st[tid].x, st[tid].s, lds.data());
+                    break;
+                }
+                for (int tid = 0; tid < NT; tid++) p2_hs_finish<N, P, R2>(tw, ab, tid, f, st[tid].x, st[tid].s, lds.data());
+                if (f != 1) continue;
+                for (int tid = 0; tid < NT; tid++) p2_vertices<N, P, R2>(A, ab, step, tid, st[tid].s);
+                for (int tid = 0; tid < NT; tid++) p2_publish_hds<N, P, R2>(tid, st[tid].s, lds.data());
+                for (int tid = 0; tid < NT; tid++)
+                    if (tid / T != R2 - 1)
+                        p2_hs_jacobian<N, P, R2>(ab, tid, st[tid].s, lds.data() + (tid / T) * BS, lds.data() + (tid / T + 1) * BS);
+                if (ab * R2 + R2 < N) {
+                    for (int u = 0; u < T; u++) {
+                        p2_hs_halo_fetch<N, P, R2>(A, ab, step, u, st[u].x);
+                        stage0_store<N, P, +1>(st[u].x, u, lds.data());
+                    }
+                    for (int s = 1; s < FftGeom<N, P>::S; s++) {
+                        for (int u = 0; u < T; u++) load_slots<N, P>(st[u].x, u, lds.data());
+                        for (int u = 0; u < T; u++) stage_store<N, P, +1>(st[u].x, u, lds.data(), tw, s);
+                    }
+                    for (int u = 0; u < T; u++) { load_slots<N, P>(st[u].x, u, lds.data()); final_stage<N, P, +1>(st[u].x, u, tw.TF); }
+                    for (int u = 0; u < T; u++) p2_hs_halo_publish<N, P, R2>(ab, u, st[u].x, lds.data());
+                }
+                for (int tid = (R2 - 1) * T; tid < NT; tid++)
+                    p2_hs_jacobian_lds<N, P, R2>(ab, tid, st[tid].s, lds.data() + (R2 - 1) * BS, lds.data());
+            }
+}
+
 template <int N, int P>
 int evaluate_np(const OceanConsts& C, const cf* h0, const cf* h0c, const float* times, int nsteps, float* vertices,
                 float* normals, float* white, int white_stride) {
     constexpr int R2 = Plan<N>::R2;
+    const bool hs = g_force_hs || Plan<N>::HS;
     Tables tb(N, P);
     std::vector<f4> PQt((size_t)N * N), d_i0(N), d_j0(N);
     std::vector<float> Om((size_t)N * N);
@@ -133,7 +182,11 @@ int evaluate_np(const OceanConsts& C, const cf* h0, const cf* h0c, const float* 
     P2Args A2;
     A2.E = E.data(); A2.Cj0 = Cj0.data(); A2.TW = tb.TW.data(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
     A2.white_stride = white_stride; A2.c = C;
-    run_pass2<N, P, R2>(A2, nsteps);
+    if (hs) {
+        run_pass2_hs<N, P, 4>(A2, nsteps);
+    } else {
+        if constexpr (!Plan<N>::HS) run_pass2<N, P, R2>(A2, nsteps);
+    }
     return 0;
 }
 
@@ -335,6 +388,8 @@ void emul_gerstner(const float* pos, long nverts, const float* waves, int nwaves
         gerstner_vertex(wv, nwaves, amplitude, frequency, steepness, t, pos[3 * v], pos[3 * v + 1], pos[3 * v + 2], &out[3 * v],
                         &out[3 * v + 1], &out[3 * v + 2]);
 }
+
+void emul_set_variant(int force_hs) { g_force_hs = force_hs != 0; }
 
 // pond Displacement(): p is an mw_pond_params
 void emul_pond(const mw_pond_params* p, const float* pos, long nverts, float t, float* out, float* nrm) {

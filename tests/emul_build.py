@@ -27,6 +27,10 @@ class Emul:
     def __init__(self):
         self.L = C.CDLL(build())
 
+    def set_variant(self, force_hs=False):
+        """force_hs: run the sequential-halo pass 2 (the product's N >= 4096 kernel) at every grid size."""
+        self.L.emul_set_variant(1 if force_hs else 0)
+
     def evaluate(self, p, h0, h0c, times, white_stride=4, pts=0):
         """p: oracle.Params.  Returns (vertices, normals, white) with a leading step axis."""
         N, ns = p.N, len(times)

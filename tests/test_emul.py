@@ -72,6 +72,24 @@ def test_pipeline_vs_oracle_f64(emul, oracle, N, pts):
         workloads.assert_parity(v[k], n[k], w[k], vf, nf, cf, rest, np.abs(hds).max(), tag=f"N={N} t={t}")
 
 
+@pytest.mark.parametrize("N,pts", [(64, 8), (128, 16), (256, 8)])
+def test_sequential_halo_pass2_equals_halo_group_pass2(emul, oracle, N, pts):
+    """The N >= 4096 kernel (k_pass2_hs: no halo thread group, halo row transformed after the displacement field, whitecap
+    finished in the slope field's final pass) forced onto small grids: bit-identical to the halo-group kernel, and
+    within tolerance of the oracle."""
+    p = workloads.fftmesh_params(N)
+    h0, h0c = oracle.generate_spectrum(p, 11)
+    times = [0.4, 9.75]
+    try:
+        emul.set_variant(force_hs=False)
+        v0, n0, w0 = emul.evaluate(p, h0, h0c, times, pts=pts)
+        emul.set_variant(force_hs=True)
+        v1, n1, w1 = emul.evaluate(p, h0, h0c, times, pts=pts)
+    finally:
+        emul.set_variant(force_hs=False)
+    assert (v0 == v1).all() and (n0 == n1).all() and (w0 == w1).all()
+
+
 def test_pipeline_nyquist_lines_only(emul, oracle):
     """Spectrum supported ONLY on the Nyquist row i=0 and column j=0 (k index 0 mirrors onto itself with a
     sign flip): exercises the dPQ correction tables in isolation."""
