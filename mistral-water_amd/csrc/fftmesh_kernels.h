@@ -674,7 +674,10 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 template <int N> struct Plan {
     static constexpr int P = (N >= 2048) ? 16 : MW_PT;    // OceanRenderer passes
     static constexpr int P1 = (N >= 2048) ? 16 : MW_PT1;  // 5 x N/8 threads would exceed 1024 at N = 2048
-    static constexpr int P2 = (N >= 2048) ? 16 : MW_PT2;
+#ifndef MW_PT2_2048
+#define MW_PT2_2048 16
+#endif
+    static constexpr int P2 = (N >= 4096) ? 16 : (N == 2048 ? MW_PT2_2048 : MW_PT2);
 #ifndef MW_HS_MIN_N
 #define MW_HS_MIN_N 4096  // grids from this size up use the sequential-halo pass 2 (P2Geom<..., true>); measured:
                           // 4096^2 +9 % over 2 rows + halo group, 2048^2 -8 % against 4 rows + halo group

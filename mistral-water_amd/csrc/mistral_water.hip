@@ -239,7 +239,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
 // the vertices leave, every row publishes hds, rows 0..R2-2 form 1 - J, group 0 transforms the halo row in buffer 0, row R2-1 follows;
 // the slope field comes last and its final pass writes normals and whitecap together.
 template <int N, int P, int R2>
-__global__ __launch_bounds__((P2Geom<N, P, R2, true>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(4))) void k_pass2_hs(P2Args A) {
+__global__ __launch_bounds__((P2Geom<N, P, R2, true>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(P == 8 ? 8 : 4))) void k_pass2_hs(P2Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = P2Geom<N, P, R2, true>;
     cf* lds = reinterpret_cast<cf*>(smem);
@@ -348,7 +348,11 @@ static mw_status dmalloc(T** p, size_t count) {
 }
 
 // host-side geometry mirror of FftGeom<N,P> / Plan<N>
-static int plan_points(int N, int pass) { return N >= 2048 ? 16 : (pass == 1 ? MW_PT1 : MW_PT2); }
+static int plan_points(int N, int pass) {
+    if (N >= 4096) return 16;
+    if (N == 2048) return pass == 1 ? 16 : MW_PT2_2048;
+    return pass == 1 ? MW_PT1 : MW_PT2;
+}
 
 // concatenated twiddle table [TS1 | TS2 | TS3 | TF] in the layout of TwGeom<N,P>
 namespace mw {
