@@ -166,6 +166,7 @@ def main():
             ocean.evaluate_device([(kk + 1) / 60.0 for kk in range(k, k + nb)], dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
             k += nb
 
+    barrier()   # rank 0 may have spent seconds in the parity gate: line the ranks up BEFORE warming the clocks
     preheat_ms = preheat(lambda: run(B, 0), torch, a.preheat_ms)
     run(a.warmup, 0)
     barrier()
