@@ -25,7 +25,41 @@ def dump(name, p, seed, t):
                         vertices=v, normals=n, colors=c, vertices_f64=vd, normals_f64=nd, colors_f64=cd)
 
 
+def dump_pond(name):
+    """W/MistralWaterLib.cginc:154-180 in its three modes on a jittered 12x12 lattice (oracle/pond_oracle.c)."""
+    M = workloads.POND_MATERIAL
+    common = dict(amplitude=M["_Amplitude"], frequency=M["_Frequency"], speed=M["_Speed"], steepness=M["_Steepness"],
+                  wspeed=M["_WSpeed"], dir_ab=M["_WDirectionAB"], dir_cd=M["_WDirectionCD"])
+    pos = workloads.pond_lattice(12, y=0.25, seed=5)
+    out = {"pos": pos, "t": np.float32(3.25)}
+    for tag, mode, smoothing, amp in (("wave", 0, 0.35, M["_Amplitude"]), ("gerstner", 1, 1.0, M["_Amplitude"]),
+                                      ("level_one", 2, 1.0, 0.1)):
+        v, n = O.pond_displace_f64(O.pond_params(mode, smoothing=smoothing, **{**common, "amplitude": amp}), pos, 3.25)
+        out[tag + "_vertices"], out[tag + "_normals"] = v, n
+        out[tag + "_mode_smoothing_amplitude"] = np.array([mode, smoothing, amp], np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def dump_renderer(name):
+    """Two OceanRenderer frames at resolution 8 (64^2 textures) and the material's vertex stage on the 8x8 mesh."""
+    rp = O.RendererParams(resolution=8, length=434.48 * 64 / 1024.0, wind_x=14.45, wind_y=12.0, amplitude=0.41,
+                          choppiness=0.46, gravity=9.81, mult=1.5)
+    init4 = O.renderer_initial_spectrum(rp, 5)
+    ph = np.zeros((rp.M, rp.M), np.float32)
+    for dt in (0.016, 0.3):
+        H, D, Nn, W = O.renderer_textures_f64(rp, init4, ph, dt)
+    v, n, c = O.renderer_mesh_vertex_stage_f64(rp, 0.75, H[..., 0], D[..., [0, 2]], Nn[..., :3], W[..., 0])
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), init4=init4, dts=np.array([0.016, 0.3], np.float32), unit_width=0.75,
+                        params=np.array([rp.resolution, rp.length, rp.wind_x, rp.wind_y, rp.amplitude, rp.choppiness,
+                                         rp.gravity, rp.mult], np.float64),
+                        height_rgba=f32(H), disp_rgba=f32(D), normal_rgba=f32(Nn), white_rgba=f32(W), phase=ph,
+                        mesh_vertices=v, mesh_normals=n, mesh_colors=c)
+
+
 if __name__ == "__main__":
+    dump_pond("pond_modes_t3p25")
+    dump_renderer("renderer_res8_frame2")
     dump("fftmesh_n16_t1p5", workloads.fftmesh_params(16, choppiness=1.0), 42, 1.5)
     dump("fftmesh_shipped_n12_t2", workloads.shipped_fftmesh_scene(), 7, 2.0)
     print("ok")

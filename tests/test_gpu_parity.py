@@ -239,6 +239,32 @@ def test_golden_fixture_n16(mw):
     assert np.abs(n - z["normals_f64"]).max() < 1e-5
 
 
+def test_golden_pond_and_renderer_fixtures(mw):
+    """The committed fixtures of the pond modes and of two OceanRenderer frames + mesh vertex stage, through the C ABI."""
+    import os
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(G, "pond_modes_t3p25.npz"))
+    M = workloads.POND_MATERIAL
+    for tag in ("wave", "gerstner", "level_one"):
+        mode, smoothing, amp = z[tag + "_mode_smoothing_amplitude"]
+        mat = mw.PondMaterial(mode=int(mode), **{**M, "_Amplitude": float(amp), "_Smoothing": float(smoothing)})
+        v, n = mat.displace(z["pos"], float(z["t"]))
+        assert np.abs(v - z[tag + "_vertices"]).max() < 6e-6 and np.abs(n - z[tag + "_normals"]).max() < 6e-6, tag
+    z = np.load(os.path.join(G, "renderer_res8_frame2.npz"))
+    pr = z["params"]
+    with mw.Ocean(resolution=int(pr[0]), unit_width=float(z["unit_width"]), length=pr[1], wind=(pr[2], pr[3]), amplitude=pr[4],
+                  choppiness=pr[5], gravity=pr[6], mult=pr[7], seed=5, semantics=mw.MW_SEM_OCEANRENDERER) as o:
+        o.set_spectrum(z["init4"][..., :2], z["init4"][..., 2:])
+        for dt in z["dts"]:
+            H, D, Nn, W = o.generate_texture_rgba(float(dt))
+        v, n, c = o.displace_mesh()
+    for got, key in ((H, "height_rgba"), (D, "disp_rgba")):
+        assert np.abs(got - z[key]).max() < 3e-6 * np.abs(z[key]).max(), key
+    assert np.quantile(np.abs(Nn - z["normal_rgba"]), 0.999) < 1e-4 and np.quantile(np.abs(W - z["white_rgba"]), 0.999) < 1e-4
+    assert np.abs(v - z["mesh_vertices"]).max() < 1e-5
+    assert np.quantile(np.abs(n - z["mesh_normals"]), 0.98) < 1e-4 and np.quantile(np.abs(c - z["mesh_colors"]), 0.98) < 1e-4
+
+
 def test_gerstner_pond(mw, oracle):
     """BASELINE config 5 (1M vertices, 8 waves) and ragged sizes, vs the f64 oracle (oracle/gerstner_oracle.c)."""
     rng = np.random.default_rng(0)

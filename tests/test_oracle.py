@@ -167,3 +167,42 @@ def test_golden_fixtures(oracle, name):
     assert (v == z["vertices"]).all() and (n == z["normals"]).all() and (c == z["colors"]).all()
     vd, nd, cd = oracle.eval_f64(p, h0, h0c, float(z["t"]))
     assert np.abs(vd - z["vertices_f64"]).max() < 1e-12
+
+
+def _golden_pond_cases(z):
+    M = workloads.POND_MATERIAL
+    common = dict(frequency=M["_Frequency"], speed=M["_Speed"], steepness=M["_Steepness"], wspeed=M["_WSpeed"],
+                  dir_ab=M["_WDirectionAB"], dir_cd=M["_WDirectionCD"])
+    for tag in ("wave", "gerstner", "level_one"):
+        mode, smoothing, amp = z[tag + "_mode_smoothing_amplitude"]
+        yield tag, int(mode), float(smoothing), float(amp), common
+
+
+def test_golden_pond_modes(oracle, emul):
+    """tests/golden/pond_modes_t3p25.npz: the oracle re-derives it exactly; the kernel body (host-stepped) matches it."""
+    z = np.load(os.path.join(GOLDEN, "pond_modes_t3p25.npz"))
+    for tag, mode, smoothing, amp, common in _golden_pond_cases(z):
+        p = oracle.pond_params(mode, amplitude=amp, smoothing=smoothing, **common)
+        v, n = oracle.pond_displace_f64(p, z["pos"], float(z["t"]))
+        assert np.abs(v - z[tag + "_vertices"]).max() < 1e-12 and np.abs(n - z[tag + "_normals"]).max() < 1e-12
+        ev, en = emul.pond(p, z["pos"], float(z["t"]))
+        assert np.abs(ev - z[tag + "_vertices"]).max() < 6e-6 and np.abs(en - z[tag + "_normals"]).max() < 6e-6
+
+
+def test_golden_renderer_frame(oracle):
+    """tests/golden/renderer_res8_frame2.npz: two GenerateTexture() frames at 64^2 and the mesh vertex stage."""
+    z = np.load(os.path.join(GOLDEN, "renderer_res8_frame2.npz"))
+    pr = z["params"]
+    rp = oracle.RendererParams(resolution=int(pr[0]), length=pr[1], wind_x=pr[2], wind_y=pr[3], amplitude=pr[4],
+                               choppiness=pr[5], gravity=pr[6], mult=pr[7])
+    init4 = oracle.renderer_initial_spectrum(rp, 5)
+    assert (init4 == z["init4"]).all()
+    ph = np.zeros((rp.M, rp.M), np.float32)
+    for dt in z["dts"]:
+        H, D, Nn, W = oracle.renderer_textures_f64(rp, init4, ph, float(dt))
+    assert (ph == z["phase"]).all()          # the float32 phase state, bit for bit
+    for got, key in ((H, "height_rgba"), (D, "disp_rgba"), (Nn, "normal_rgba"), (W, "white_rgba")):
+        assert (got.astype(np.float32) == z[key]).all()
+    v, n, c = oracle.renderer_mesh_vertex_stage_f64(rp, float(z["unit_width"]), H[..., 0], D[..., [0, 2]], Nn[..., :3], W[..., 0])
+    assert np.abs(v - z["mesh_vertices"]).max() < 1e-12 and np.abs(n - z["mesh_normals"]).max() < 1e-12
+    assert np.abs(c - z["mesh_colors"]).max() < 1e-12
