@@ -126,6 +126,21 @@ public:
         check(mw_ocean_generate_texture(ocean_, deltaTime, heightTexture.data(), displacementTexture.data(),
                                         normalTexture.data(), whiteTexture.data()));
     }
+    // The same frame as the four ARGBFloat render targets in the shaders' channel layout (S/OceanRenderer.cs:143-146):
+    // what oceanMat.SetTexture("_Height"/"_Anim"/"_Bump"/"_White") binds (:310-313).  4 floats per texel each.
+    void GenerateTextureRGBA(float deltaTime, std::vector<float>& height, std::vector<float>& anim, std::vector<float>& bump,
+                             std::vector<float>& white) {
+        const size_t mm = (size_t)M_ * M_ * 4;
+        height.resize(mm); anim.resize(mm); bump.resize(mm); white.resize(mm);
+        check(mw_ocean_generate_texture_rgba(ocean_, deltaTime, height.data(), anim.data(), bump.data(), white.data()));
+    }
+    // The ocean material's vertex stage (W/TestOcean.shader:61-79) applied to `mesh` from the latest frame's textures:
+    // displaced vertices, per-vertex normals and foam factor, for a consumer that does not bind textures.
+    void DisplaceMesh(std::vector<Vector3>& vertices, std::vector<Vector3>& normals, std::vector<float>& foam) {
+        const size_t nn = (size_t)resolution * resolution;
+        vertices.resize(nn); normals.resize(nn); foam.resize(nn);
+        check(mw_ocean_displace_mesh(ocean_, &vertices[0].x, &normals[0].x, foam.data()));
+    }
 
 private:
     void Create() {
@@ -144,6 +159,30 @@ private:
     int M_ = 0;
     float oldLength_ = 0.f, oldAmplitude_ = 0.f;
     Vector2 oldWind_;
+};
+
+// The pond material's displacement properties (W/MistralWaterLib.cginc:53-66) and its vertex-stage Displacement()
+// (:154-180) in the three modes of the shader library.
+class PondMaterial {
+public:
+    int mode = MW_POND_GERSTNER;   // _DISPLACEMENTMODE_*: MW_POND_WAVE / MW_POND_GERSTNER / MW_POND_GERSTNER_LEVEL_ONE
+    float _Amplitude = 10.f, _Frequency = 2.58f, _Speed = 0.f, _Steepness = 0.99f, _Smoothing = 1.f;  // M/Pond Water Mat.mat
+    float _WSpeed[4] = {1.2f, 0.71f, 1.1f, 0.73f};
+    float _WDirectionAB[4] = {0.3f, 0.73f, 0.85f, 0.25f};
+    float _WDirectionCD[4] = {-0.25f, 1.11f, 0.5f, 0.5f};
+    int device = 0;
+
+    // time = _Time.y; normals may be null
+    void Displacement(const std::vector<Vector3>& in, float time, std::vector<Vector3>& out, std::vector<Vector3>* normals) const {
+        mw_pond_params p;
+        p.mode = mode; p.amplitude = _Amplitude; p.frequency = _Frequency; p.speed = _Speed; p.steepness = _Steepness;
+        p.smoothing = _Smoothing;
+        for (int i = 0; i < 4; i++) { p.wspeed[i] = _WSpeed[i]; p.dir_ab[i] = _WDirectionAB[i]; p.dir_cd[i] = _WDirectionCD[i]; }
+        out.resize(in.size());
+        if (normals) normals->resize(in.size());
+        if (in.empty()) return;
+        check(mw_pond_displace(&p, &in[0].x, (int64_t)in.size(), time, &out[0].x, normals ? &(*normals)[0].x : nullptr, device));
+    }
 };
 
 }  // namespace mistral_water
