@@ -163,6 +163,8 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
 mw_status mw_debug_omega_t(mw_ocean* o, float t, float* out_host);
 mw_status mw_debug_get_omega(mw_ocean* o, float* out_host);
 mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host);
+/* the pond kernels' hardware-sine variant (v_sin_f32 / v_cos_f32 after an exact revolution count) */
+mw_status mw_debug_sincos_fast(const float* x_host, int32_t n, float* s_host, float* c_host);
 /* streams `bytes` of device memory through `width`-byte per-lane loads (4, 8 or 16): FETCH_SIZE calibration */
 mw_status mw_debug_stream_read(int64_t bytes, int32_t width, int32_t iters);
 
@@ -176,6 +178,14 @@ mw_status mw_gerstner_displace(const float* pos_xyz, int64_t nverts, const float
 mw_status mw_gerstner_displace_device(const void* d_pos_xyz, int64_t nverts, const float* waves, int32_t nwaves,
                                       float amplitude, float frequency, float steepness, float t, void* d_out_xyz,
                                       void* hip_stream);
+
+/* many time values of one lattice in ONE launch (the positions are read once, the time part of every wave's phase is
+ * joined by angle addition): t[nsteps] is a HOST array, d_out_xyz is [nsteps][nverts*3].  nwaves must be 4 or 8 and
+ * nsteps * nwaves <= 256 (mw_gerstner_max_steps); otherwise MW_EINVAL.  Asynchronous on hip_stream.               */
+mw_status mw_gerstner_displace_steps_device(const void* d_pos_xyz, int64_t nverts, const float* waves, int32_t nwaves,
+                                            float amplitude, float frequency, float steepness, const float* t,
+                                            int32_t nsteps, void* d_out_xyz, void* hip_stream);
+int32_t mw_gerstner_max_steps(int32_t nwaves); /* 0 when this wave count has no batched kernel */
 
 /* ---- pond: the material's whole vertex-stage Displacement()  (W/MistralWaterLib.cginc:154-180) with every
  * displacement mode of the shader library.  Fields are the material properties of W/MistralWaterProperty.cginc /

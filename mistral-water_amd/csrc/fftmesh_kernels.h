@@ -28,6 +28,8 @@ struct StepTimes {
 };
 
 MW_HD void mw_sincos(float x, float* s, float* c) { sincos_f32(x, s, c); }
+// hardware sine/cosine after an exact reduction (1.8e-7 absolute on the device): the VALU-bound pond kernels
+MW_HD void mw_sincos_fast(float x, float* s, float* c) { sincos_fast_f32(x, s, c); }
 // A value that is the same in every lane of a wave (e.g. tid / T when T is a multiple of 64): telling the compiler
 // lets it keep the value -- and every pointer derived from it -- in SGPRs, so global accesses use the
 // `saddr + 32-bit voffset` form instead of one 64-bit VGPR address pair per access.

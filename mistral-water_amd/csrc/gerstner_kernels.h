@@ -20,7 +20,7 @@ MW_HD void gerstner_vertex(const GerstnerWaves& wv, int nwaves, float amplitude,
     for (int i = 0; i < nwaves; i++) {
         const float th = frequency * (wv.dx[i] * px + wv.dy[i] * pz) + t * wv.speed[i];  // :80-84 (sVertex.xz = world x,z)
         float s, c;
-        mw_sincos(th, &s, &c);
+        mw_sincos_fast(th, &s, &c);
         sx += c * (sa * wv.dx[i]);  // :86
         sz += c * (sa * wv.dy[i]);  // :87
         sy += s;                    // :88
@@ -60,6 +60,108 @@ __global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos,
     }
 }
 
+#endif
+
+// ---- many time-steps of one lattice in one launch ------------------------------------------------------------
+// theta_i(x, t) = frequency * dot(dir_i, x.xz) + t * speed_i splits into a position part (per vertex and wave, one
+// hardware sincos, kept in registers) and a time part (per wave and step, uniform: cos/sin(t_k * speed_i) come
+// from the host in the kernel arguments), joined by the angle-addition formulas: 7 FMAs per vertex, wave and step instead
+// of a sincos.  The positions are read once per launch; per step only the 12-B result leaves.
+#define MW_GERSTNER_PHASES 256  // nsteps * nwaves per launch (2 KiB of kernel arguments)
+struct GerstnerPhases {
+    float cb[MW_GERSTNER_PHASES], sb[MW_GERSTNER_PHASES];  // [step * nwaves + i]
+};
+template <int NW>
+MW_HD void gerstner_position_part(const GerstnerWaves& wv, float frequency, float px, float pz, float (&sa)[NW], float (&ca)[NW]) {
+#pragma unroll
+    for (int i = 0; i < NW; i++) mw_sincos_fast(frequency * (wv.dx[i] * px + wv.dy[i] * pz), &sa[i], &ca[i]);
+}
+template <int NW>
+MW_HD void gerstner_step_vertex(const GerstnerWaves& wv, const GerstnerPhases& ph, int step, float amplitude, float steepness,
+                                const float (&sa)[NW], const float (&ca)[NW], float px, float py, float pz, float* o) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    const float sam = steepness * amplitude;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        const float cb = ph.cb[step * NW + i], sb = ph.sb[step * NW + i];
+        const float c = ca[i] * cb - sa[i] * sb, s = sa[i] * cb + ca[i] * sb;  // cos/sin(theta_i)
+        sx += c * (sam * wv.dx[i]);
+        sz += c * (sam * wv.dy[i]);
+        sy += s;
+    }
+    o[0] = px + sx; o[1] = py + amplitude * sy; o[2] = pz + sz;
+}
+
+#if defined(__HIPCC__)
+template <int NW>
+__global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts,
+                                                        GerstnerWaves wv, GerstnerPhases ph, int nsteps, float amplitude,
+                                                        float frequency, float steepness) {
+    const int64_t nquads = nverts >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquads; qd += stride) {
+        const f4* p = reinterpret_cast<const f4*>(pos) + qd * 3;
+        f4 a = p[0], b = p[1], c = p[2];
+        const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+        float sa[4][NW], ca[4][NW];
+#pragma unroll
+        for (int k = 0; k < 4; k++) gerstner_position_part<NW>(wv, frequency, v[3 * k], v[3 * k + 2], sa[k], ca[k]);
+        for (int step = 0; step < nsteps; step++) {
+            float o[12];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                gerstner_step_vertex<NW>(wv, ph, step, amplitude, steepness, sa[k], ca[k], v[3 * k], v[3 * k + 1], v[3 * k + 2], &o[3 * k]);
+            f4* po = reinterpret_cast<f4*>(out + (size_t)step * nverts * 3) + qd * 3;
+            f4 r0 = {o[0], o[1], o[2], o[3]}, r1 = {o[4], o[5], o[6], o[7]}, r2 = {o[8], o[9], o[10], o[11]};
+            po[0] = r0; po[1] = r1; po[2] = r2;
+        }
+    }
+    const int64_t tail0 = nquads << 2;  // nverts % 4 by the first few threads of block 0
+    if (blockIdx.x == 0 && threadIdx.x < (nverts - tail0)) {
+        const int64_t vtx = tail0 + threadIdx.x;
+        float sa[NW], ca[NW];
+        gerstner_position_part<NW>(wv, frequency, pos[3 * vtx], pos[3 * vtx + 2], sa, ca);
+        for (int step = 0; step < nsteps; step++) {
+            float o[3];
+            gerstner_step_vertex<NW>(wv, ph, step, amplitude, steepness, sa, ca, pos[3 * vtx], pos[3 * vtx + 1], pos[3 * vtx + 2], o);
+            float* po = out + (size_t)step * nverts * 3 + 3 * vtx;
+            po[0] = o[0]; po[1] = o[1]; po[2] = o[2];
+        }
+    }
+}
+#endif
+
+#if defined(__HIPCC__)
+// nsteps time values in one launch; nwaves must be 4 or 8 and nsteps * nwaves <= MW_GERSTNER_PHASES (the caller checks)
+static inline hipError_t gerstner_launch_steps(const float* d_pos, int64_t nverts, const float* waves, int nwaves, float amplitude,
+                                               float frequency, float steepness, const float* t, int nsteps, float* d_out,
+                                               hipStream_t st) {
+    GerstnerWaves wv;
+    GerstnerPhases ph;
+    for (int i = 0; i < MW_GERSTNER_MAX_WAVES; i++) {
+        wv.dx[i] = i < nwaves ? waves[3 * i] : 0.f;
+        wv.dy[i] = i < nwaves ? waves[3 * i + 1] : 0.f;
+        wv.speed[i] = i < nwaves ? waves[3 * i + 2] : 0.f;
+    }
+    for (int k = 0; k < nsteps; k++)
+        for (int i = 0; i < nwaves; i++) {
+            const double b = (double)t[k] * (double)wv.speed[i];
+            ph.cb[k * nwaves + i] = (float)cos(b);
+            ph.sb[k * nwaves + i] = (float)sin(b);
+        }
+    int64_t nquads = nverts >> 2;
+    int64_t blocks = (nquads + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (nwaves == 4)
+        k_gerstner_steps<4><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness);
+    else
+        k_gerstner_steps<8><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness);
+    return hipGetLastError();
+}
+#endif
+
+#if defined(__HIPCC__)
 static inline hipError_t gerstner_launch(const float* d_pos, int64_t nverts, const float* waves, int nwaves, float amplitude,
                                          float frequency, float steepness, float t, float* d_out, hipStream_t st) {
     GerstnerWaves wv;

@@ -980,12 +980,24 @@ __global__ void k_dbg_sincos(const float* x, int n, float* sn, float* cs) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) sincos_f32(x[i], &sn[i], &cs[i]);
 }
+__global__ void k_dbg_sincos_fast(const float* x, int n, float* sn, float* cs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sincos_fast_f32(x[i], &sn[i], &cs[i]);
+}
+static mw_status debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host, bool fast);
 mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host) {
+    return debug_sincos(x_host, n, s_host, c_host, false);
+}
+mw_status mw_debug_sincos_fast(const float* x_host, int32_t n, float* s_host, float* c_host) {
+    return debug_sincos(x_host, n, s_host, c_host, true);
+}
+static mw_status debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host, bool fast) {
     float *dx = nullptr, *ds = nullptr, *dc = nullptr;
     if (hipMalloc((void**)&dx, 4 * n) != hipSuccess || hipMalloc((void**)&ds, 4 * n) != hipSuccess ||
         hipMalloc((void**)&dc, 4 * n) != hipSuccess) return fail(MW_ENOMEM, "hipMalloc");
     hipMemcpy(dx, x_host, 4 * n, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(k_dbg_sincos, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, ds, dc);
+    if (fast) hipLaunchKernelGGL(k_dbg_sincos_fast, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, ds, dc);
+    else hipLaunchKernelGGL(k_dbg_sincos, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, ds, dc);
     hipMemcpy(s_host, ds, 4 * n, hipMemcpyDeviceToHost);
     hipMemcpy(c_host, dc, 4 * n, hipMemcpyDeviceToHost);
     hipFree(dx); hipFree(ds); hipFree(dc);
@@ -1031,6 +1043,27 @@ mw_status mw_gerstner_displace_device(const void* d_pos_xyz, int64_t nverts, con
     if (nverts == 0) return MW_OK;
     hipError_t e = gerstner_launch((const float*)d_pos_xyz, nverts, waves, nwaves, amplitude, frequency, steepness, t,
                                    (float*)d_out_xyz, reinterpret_cast<hipStream_t>(hip_stream));
+    if (e != hipSuccess) return fail(MW_EDEVICE, std::string("gerstner launch: ") + hipGetErrorString(e));
+    return MW_OK;
+}
+
+int32_t mw_gerstner_max_steps(int32_t nwaves) {
+    if (nwaves != 4 && nwaves != 8) return 0;
+    const int m = MW_GERSTNER_PHASES / nwaves;
+    return m < 32 ? m : 32;
+}
+
+mw_status mw_gerstner_displace_steps_device(const void* d_pos_xyz, int64_t nverts, const float* waves, int32_t nwaves,
+                                            float amplitude, float frequency, float steepness, const float* t,
+                                            int32_t nsteps, void* d_out_xyz, void* hip_stream) {
+    if (!d_pos_xyz || !d_out_xyz || !waves || !t) return fail(MW_EINVAL, "mw_gerstner_displace_steps_device: NULL argument");
+    const int maxs = mw_gerstner_max_steps(nwaves);
+    if (maxs == 0) return fail(MW_EINVAL, "mw_gerstner_displace_steps_device: nwaves must be 4 or 8");
+    if (nsteps < 1 || nsteps > maxs) return fail(MW_EINVAL, "mw_gerstner_displace_steps_device: nsteps out of range");
+    if (nverts < 0) return fail(MW_EINVAL, "nverts < 0");
+    if (nverts == 0) return MW_OK;
+    hipError_t e = gerstner_launch_steps((const float*)d_pos_xyz, nverts, waves, nwaves, amplitude, frequency, steepness, t, nsteps,
+                                         (float*)d_out_xyz, reinterpret_cast<hipStream_t>(hip_stream));
     if (e != hipSuccess) return fail(MW_EDEVICE, std::string("gerstner launch: ") + hipGetErrorString(e));
     return MW_OK;
 }

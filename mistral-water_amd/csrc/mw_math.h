@@ -91,6 +91,28 @@ MW_HD void sincos_f32(float x, float* sn, float* cs) {
     *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// sin/cos through the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions, quarter-rate, ~1e-6 absolute) after a
+// two-constant reduction that keeps the revolution count exact: p = x/2pi rounded, e = the rounding error of that
+// product recovered by FMA plus the low part of 1/2pi, r = (p - rint(p)) + e in [-0.5, 0.5].  10 VALU issue slots
+// against ~25 for sincos_f32: used where a kernel is VALU-bound and 1e-6 is inside its stated tolerance (the pond: eight
+// sincos per vertex against 24 B).  The host (emulation) evaluates sin(2 pi r) in double: same r, correctly rounded
+// result -- host and device agree to the hardware's error, not bit for bit.
+MW_HD void sincos_fast_f32(float x, float* sn, float* cs) {
+    const float hi = 0.15915494f, lo = 6.4206382e-09f;  // 1/(2 pi) = hi + lo (hi = the f32 nearest, lo = the rest)
+    const float p = smul(x, hi);  // the ROUNDED product (a contracted x*hi - rint(p) would count its error twice)
+    float e = fmaf(x, hi, -p);
+    e = fmaf(x, lo, e);
+    const float r = sadd(ssub(p, rintf(p)), e);
+#if defined(__HIP_DEVICE_COMPILE__)
+    *sn = __builtin_amdgcn_sinf(r);
+    *cs = __builtin_amdgcn_cosf(r);
+#else
+    const double a = 6.283185307179586476925 * (double)r;
+    *sn = (float)sin(a);
+    *cs = (float)cos(a);
+#endif
+}
+
 // S/FFTMesh.cs:141-147 Dispersion(n,m) * t  (:183) -- bit-for-bit the reference's float sequence.
 MW_HD float omega_f32(int N, float length, float gravity, int n, int m) {
     float w = sdiv(smul(2.0f, MW_PI_F), length);

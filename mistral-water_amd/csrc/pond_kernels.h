@@ -45,11 +45,11 @@ MW_HD void pond_vertex(const PondParams& P, float t, float px, float py, float p
         const float a = sp + px * f, b = sp + pz * f;  // phases of v0 (:136,:140)
         const float hd = 0.5f * (0.05f * f);           // half the phase step of the +0.05 neighbours v1, v2 (:130-131)
         float s0, c0, sb, cb, sa2, ca2, sb2, cb2, sh, ch;
-        mw_sincos(a, &s0, &c0);
-        mw_sincos(b, &sb, &cb);
-        mw_sincos(a + hd, &sa2, &ca2);
-        mw_sincos(b + hd, &sb2, &cb2);
-        mw_sincos(hd, &sh, &ch);
+        mw_sincos_fast(a, &s0, &c0);
+        mw_sincos_fast(b, &sb, &cb);
+        mw_sincos_fast(a + hd, &sa2, &ca2);
+        mw_sincos_fast(b + hd, &sb2, &cb2);
+        mw_sincos_fast(hd, &sh, &ch);
         const float y0 = py + s0 * A - cb * A;
         // v1.y - v0.y = (sin(a + 2hd) - sin a) A = 2 cos(a + hd) sin(hd) A and v2.y - v0.y = -(cos(b + 2hd) - cos b) A =
         // 2 sin(b + hd) sin(hd) A, then scaled by _Smoothing (:144-145).  The product form has no cancellation (the
@@ -73,7 +73,7 @@ MW_HD void pond_vertex(const PondParams& P, float t, float px, float py, float p
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             float s, c;
-            mw_sincos(P.frequency * (dx[i] * px + dy[i] * pz) + t * P.wspeed[i], &s, &c);  // :80-84
+            mw_sincos_fast(P.frequency * (dx[i] * px + dy[i] * pz) + t * P.wspeed[i], &s, &c);  // :80-84
             sx += c * (sa * dx[i]);  // :86
             sz += c * (sa * dy[i]);  // :87
             sy += s * A;             // :88
@@ -84,7 +84,7 @@ MW_HD void pond_vertex(const PondParams& P, float t, float px, float py, float p
             float amp, steep, speed, dx, dy, fs;
             level_one_wave(i, &amp, &steep, &speed, &dx, &dy, &fs);
             float s, c;
-            mw_sincos(P.frequency * fs * (px * dx + pz * dy) + speed * P.frequency * fs * t, &s, &c);
+            mw_sincos_fast(P.frequency * fs * (px * dx + pz * dy) + speed * P.frequency * fs * t, &s, &c);
             sx += P.steepness * P.amplitude * steep * amp * dx * c;
             sz += P.steepness * P.amplitude * steep * amp * dy * c;
             sy += P.amplitude * amp * s;

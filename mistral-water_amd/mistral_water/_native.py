@@ -110,11 +110,15 @@ def lib():
                                            f32p, C.c_int32]),
         "mw_gerstner_displace_device": (C.c_int, [vp, C.c_int64, f32p, C.c_int32, C.c_float, C.c_float, C.c_float,
                                                   C.c_float, vp, vp]),
+        "mw_gerstner_displace_steps_device": (C.c_int, [vp, C.c_int64, f32p, C.c_int32, C.c_float, C.c_float, C.c_float, f32p,
+                                                        C.c_int32, vp, vp]),
+        "mw_gerstner_max_steps": (C.c_int32, [C.c_int32]),
         "mw_pond_displace": (C.c_int, [C.POINTER(MwPondParams), f32p, C.c_int64, C.c_float, f32p, f32p, C.c_int32]),
         "mw_pond_displace_device": (C.c_int, [C.POINTER(MwPondParams), vp, C.c_int64, C.c_float, vp, vp, vp]),
         "mw_debug_omega_t": (C.c_int, [vp, C.c_float, f32p]),
         "mw_debug_get_omega": (C.c_int, [vp, f32p]),
         "mw_debug_sincos": (C.c_int, [f32p, C.c_int32, f32p, f32p]),
+        "mw_debug_sincos_fast": (C.c_int, [f32p, C.c_int32, f32p, f32p]),
         "mw_debug_stream_read": (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
     }
     for name, (res, args) in sig.items():
@@ -134,7 +138,7 @@ ABI_SYMBOLS = [
     "mw_ocean_evaluate_device", "mw_ocean_max_batch", "mw_ocean_generate_texture",
     "mw_ocean_generate_texture_device", "mw_ocean_generate_texture_rgba", "mw_ocean_generate_texture_rgba_device",
     "mw_ocean_displace_mesh", "mw_ocean_displace_mesh_device", "mw_ocean_profile_kernels", "mw_gerstner_displace",
-    "mw_gerstner_displace_device", "mw_pond_displace", "mw_pond_displace_device", "mw_debug_omega_t", "mw_debug_get_omega", "mw_debug_sincos", "mw_debug_stream_read",
+    "mw_gerstner_displace_device", "mw_gerstner_displace_steps_device", "mw_gerstner_max_steps", "mw_pond_displace", "mw_pond_displace_device", "mw_debug_omega_t", "mw_debug_get_omega", "mw_debug_sincos", "mw_debug_sincos_fast", "mw_debug_stream_read",
 ]
 
 

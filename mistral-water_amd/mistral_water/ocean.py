@@ -282,6 +282,16 @@ def gerstner_displace(pos_xyz, waves, amplitude: float, frequency: float, steepn
     return out
 
 
+def gerstner_displace_steps_device(d_pos: int, nverts: int, waves, amplitude: float, frequency: float, steepness: float,
+                                   times, d_out: int, stream: int = 0):
+    """len(times) displaced copies of one device-resident lattice in one launch: d_out is [len(times)][nverts*3]."""
+    wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)
+    tt = np.ascontiguousarray(times, np.float32)
+    nat.check(nat.lib().mw_gerstner_displace_steps_device(C.c_void_p(d_pos), nverts, _p(wv), wv.shape[0], C.c_float(amplitude),
+                                                          C.c_float(frequency), C.c_float(steepness), _p(tt), tt.size,
+                                                          C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
+
+
 class PondMaterial:
     """Displacement properties of the pond material (W/MistralWaterProperty.cginc, W/MistralWaterLib.cginc:53-66), under
     the material's own property names, and its vertex-stage ``Displacement()`` (:154-180) on host or device arrays.

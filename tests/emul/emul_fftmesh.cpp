@@ -391,6 +391,39 @@ void emul_gerstner(const float* pos, long nverts, const float* waves, int nwaves
 
 void emul_set_variant(int force_hs) { g_force_hs = force_hs != 0; }
 
+// the time-batched Gerstner path: position part once, angle addition per step (cb/sb as the launcher forms them)
+void emul_gerstner_steps(const float* pos, long nverts, const float* waves, int nwaves, float amplitude, float frequency,
+                         float steepness, const float* t, int nsteps, float* out) {
+    GerstnerWaves wv;
+    GerstnerPhases ph;
+    for (int i = 0; i < MW_GERSTNER_MAX_WAVES; i++) {
+        wv.dx[i] = i < nwaves ? waves[3 * i] : 0.f;
+        wv.dy[i] = i < nwaves ? waves[3 * i + 1] : 0.f;
+        wv.speed[i] = i < nwaves ? waves[3 * i + 2] : 0.f;
+    }
+    for (int k = 0; k < nsteps; k++)
+        for (int i = 0; i < nwaves; i++) {
+            const double b = (double)t[k] * (double)wv.speed[i];
+            ph.cb[k * nwaves + i] = (float)cos(b);
+            ph.sb[k * nwaves + i] = (float)sin(b);
+        }
+    for (long v = 0; v < nverts; v++) {
+        if (nwaves == 4) {
+            float sa[4], ca[4];
+            gerstner_position_part<4>(wv, frequency, pos[3 * v], pos[3 * v + 2], sa, ca);
+            for (int k = 0; k < nsteps; k++)
+                gerstner_step_vertex<4>(wv, ph, k, amplitude, steepness, sa, ca, pos[3 * v], pos[3 * v + 1], pos[3 * v + 2],
+                                        out + ((size_t)k * nverts + v) * 3);
+        } else {
+            float sa[8], ca[8];
+            gerstner_position_part<8>(wv, frequency, pos[3 * v], pos[3 * v + 2], sa, ca);
+            for (int k = 0; k < nsteps; k++)
+                gerstner_step_vertex<8>(wv, ph, k, amplitude, steepness, sa, ca, pos[3 * v], pos[3 * v + 1], pos[3 * v + 2],
+                                        out + ((size_t)k * nverts + v) * 3);
+        }
+    }
+}
+
 // pond Displacement(): p is an mw_pond_params
 void emul_pond(const mw_pond_params* p, const float* pos, long nverts, float t, float* out, float* nrm) {
     PondParams P;

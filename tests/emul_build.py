@@ -107,6 +107,15 @@ class Emul:
         self.L.emul_or_displace_mesh(M, res, C.c_float(unit_width), _p(h), _p(d), _p(n), _p(w), _p(v), _p(nr), _p(c))
         return v, nr, c
 
+    def gerstner_steps(self, pos, waves, amplitude, frequency, steepness, times):
+        pos = np.ascontiguousarray(pos, np.float32)
+        wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)
+        tt = np.ascontiguousarray(times, np.float32)
+        out = np.empty((tt.size,) + pos.shape, np.float32)
+        self.L.emul_gerstner_steps(_p(pos), C.c_long(pos.size // 3), _p(wv), wv.shape[0], C.c_float(amplitude),
+                                   C.c_float(frequency), C.c_float(steepness), _p(tt), tt.size, _p(out))
+        return out
+
     def pond(self, params, pos, t):
         """params: a ctypes struct with the mw_pond_params layout (oracle.PondParams) -> (positions, normals) f32."""
         pos = np.ascontiguousarray(pos, np.float32)

@@ -188,3 +188,16 @@ def test_pond_displacement_modes_vs_oracle(emul, oracle):
     a = emul.gerstner(pos, P["waves"], P["amplitude"], P["frequency"], P["steepness"], 3.25)
     b, _ = emul.pond(_pond_cases(oracle)[2][1], pos, 3.25)
     assert np.abs(a - b).max() < 4e-6
+
+
+@pytest.mark.parametrize("nwaves", [4, 8])
+def test_gerstner_time_batched_path_vs_oracle(emul, oracle, nwaves):
+    """mw_gerstner_displace_steps_device's arithmetic (position part once, time part by angle addition), host-stepped."""
+    P = workloads.POND
+    W = workloads.pond_waves8()[:nwaves]
+    pos = workloads.pond_lattice(40, y=0.1, seed=9)
+    times = [0.0, 1.0 / 60, 3.25, 61.7, 600.0]
+    out = emul.gerstner_steps(pos, W, P["amplitude"], P["frequency"], P["steepness"], times)
+    for k, t in enumerate(times):
+        want = oracle.gerstner_f64(pos, W, P["amplitude"], P["frequency"], P["steepness"], t)
+        assert np.abs(out[k] - want).max() < 8e-6, (nwaves, t)    # 1 ulp of a coordinate near 50 = 3.8e-6

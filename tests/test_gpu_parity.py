@@ -281,6 +281,29 @@ def test_gerstner_pond(mw, oracle):
     assert np.abs(out - oracle.gerstner_f64(pos, P["waves"], P["amplitude"], P["frequency"], P["steepness"], 0.7)).max() < 3e-6
 
 
+def test_gerstner_time_batched(mw, oracle):
+    """BASELINE config 5 through the batched entry point: 1M vertices x 8 waves x 32 time values in one launch."""
+    import torch
+    P, W = workloads.POND, workloads.pond_waves8()
+    assert mw.lib().mw_gerstner_max_steps(8) == 32 and mw.lib().mw_gerstner_max_steps(4) == 32
+    assert mw.lib().mw_gerstner_max_steps(5) == 0
+    for nv, nw in ((1000 * 1000, 8), (1003, 4), (3, 8)):
+        pos = workloads.pond_lattice(1000, seed=2)[:nv]
+        times = [(k + 1) / 60.0 for k in range(32)] if nv > 5000 else [0.0, 3.25, 600.0]
+        dp = torch.from_numpy(pos).cuda()
+        do = torch.empty((len(times), nv, 3), dtype=torch.float32, device="cuda")
+        mw.gerstner_displace_steps_device(dp.data_ptr(), nv, W[:nw], P["amplitude"], P["frequency"], P["steepness"], times,
+                                          do.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = do.cpu().numpy()
+        for k in (0, len(times) // 2, len(times) - 1):
+            want = oracle.gerstner_f64(pos, W[:nw], P["amplitude"], P["frequency"], P["steepness"], times[k])
+            assert np.abs(got[k] - want).max() < 8e-6, (nv, nw, k)
+    with pytest.raises(mw.MistralWaterError) as e:     # 33 steps of 8 waves exceed the phase table
+        mw.gerstner_displace_steps_device(dp.data_ptr(), 3, W, 0.1, 2.58, 0.99, [0.0] * 33, do.data_ptr())
+    assert e.value.status == mw.MW_EINVAL
+
+
 def test_pond_material_displacement_modes(mw, oracle):
     """W/MistralWaterLib.cginc:154-180 Displacement() in its three modes (Wave with its finite-difference normal, Gerstner,
     GerstnerLevelOne) through mw_pond_displace, vs the f64 oracle (oracle/pond_oracle.c); 1M-vertex and ragged sizes."""
