@@ -27,7 +27,12 @@ struct StepTimes {
     float t[MW_MAX_BATCH];
 };
 
-MW_HD void mw_sincos(float x, float* s, float* c) { sincos_f32(x, s, c); }
+#ifndef MW_FAST_SINCOS
+#define MW_FAST_SINCOS 1  // hardware v_sin/v_cos after an exact reduction (1.8e-7 abs; +1 % at 1024^2, -4 % OceanRenderer frame time)
+#endif
+MW_HD void mw_sincos(float x, float* s, float* c) {
+    if (MW_FAST_SINCOS) sincos_fast_f32(x, s, c); else sincos_f32(x, s, c);
+}
 // hardware sine/cosine after an exact reduction (1.8e-7 absolute on the device): the VALU-bound pond kernels
 MW_HD void mw_sincos_fast(float x, float* s, float* c) { sincos_fast_f32(x, s, c); }
 // A value that is the same in every lane of a wave (e.g. tid / T when T is a multiple of 64): telling the compiler
