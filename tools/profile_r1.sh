@@ -12,3 +12,7 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_IN
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$tag -o pmc -- python bench.py --steps 64 --warmup 32 --preheat-ms 0 --no-cpu-baseline --no-parity > /dev/null 2>&1
 done
 find $OUT -name "*.csv" | head -40
+# other workloads: per-kernel durations only
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_renderer -o renderer -- python bench.py --workload renderer1024 --steps 2000 > $OUT/renderer_stdout.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pond -o pond -- python bench.py --workload pond --steps 3200 > $OUT/pond_stdout.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_4096 -o o4096 -- python bench.py --workload ocean4096 --batch 4 --steps 200 --warmup 4 --no-cpu-baseline > $OUT/o4096_stdout.txt 2>&1
