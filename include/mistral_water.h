@@ -20,6 +20,7 @@
 #ifndef MISTRAL_WATER_H
 #define MISTRAL_WATER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -128,6 +129,15 @@ mw_status mw_ocean_generate_texture(mw_ocean* o, float delta_time, float* height
                                     float* white);
 mw_status mw_ocean_generate_texture_device(mw_ocean* o, float delta_time, void* d_height, void* d_disp_xz,
                                            void* d_normal_xyz, void* d_white);
+
+/* ---- optional: page-lock caller arrays --------------------------------------------------------------------
+ * The host-pointer entry points copy results into caller memory; into ordinary (pageable) arrays that copy runs at
+ * ~9 GB/s and dominates the call.  A host that keeps its output arrays for many frames -- the
+ * reference does: vertMeow/normals are allocated once (S/FFTMesh.cs:90-99) -- can register them once (in C#: after
+ * GCHandle.Alloc(array, GCHandleType.Pinned)) and every later copy into them goes at PCIe rate.  Unregister before
+ * the memory is freed or unpinned.                                                                               */
+mw_status mw_host_register(void* ptr, size_t bytes);
+mw_status mw_host_unregister(void* ptr);
 
 /* ---- OceanRenderer semantics, consumer-side packing ---------------------------------------------------------
  * One GenerateTexture() delivered as the reference's four ARGBFloat render targets (S/OceanRenderer.cs:143-146,

@@ -844,6 +844,17 @@ mw_status mw_ocean_generate_texture(mw_ocean* o, float delta_time, float* height
     return MW_OK;
 }
 
+mw_status mw_host_register(void* ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return fail(MW_EINVAL, "mw_host_register: NULL pointer or zero size");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return MW_OK;
+}
+mw_status mw_host_unregister(void* ptr) {
+    if (!ptr) return fail(MW_EINVAL, "mw_host_unregister: NULL pointer");
+    HIP_TRY(hipHostUnregister(ptr));
+    return MW_OK;
+}
+
 mw_status mw_ocean_generate_texture_rgba_device(mw_ocean* o, float delta_time, void* d_height_rgba, void* d_disp_rgba,
                                                 void* d_normal_rgba, void* d_white_rgba) {
     if (!o) return fail(MW_EINVAL, "NULL handle");

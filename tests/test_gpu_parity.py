@@ -375,6 +375,24 @@ def test_batch_limits_and_empty_inputs(mw, oracle):
         mw.gerstner_displace(np.zeros((4, 3), np.float32), [(1, 0, 1)] * 17, 0.1, 1.0, 0.5, 0.0)   # > 16 waves
 
 
+def test_registered_host_arrays(mw, oracle):
+    """mw_host_register: results copied into page-locked caller arrays equal the pageable path bit for bit."""
+    p = workloads.fftmesh_params(128)
+    NN = 128 * 128
+    with make(mw, p) as o:
+        v0, n0, c0 = o.evaluate(2.5)
+        v, n, c = np.empty((NN, 3), np.float32), np.empty((NN, 3), np.float32), np.empty((NN, 4), np.float32)
+        for a in (v, n, c):
+            mw.host_register(a)
+        try:
+            o.evaluate_into(2.5, v, n, c)
+            assert (v == v0).all() and (n == n0).all() and (c == c0).all()
+        finally:
+            for a in (v, n, c):
+                mw.host_unregister(a)
+    assert mw.lib().mw_host_register(None, 16) == mw.MW_EINVAL
+
+
 def test_errors_on_gpu(mw):
     with pytest.raises(mw.MistralWaterError) as e:
         mw.Ocean(resolution=8192, length=8192.0)
