@@ -169,9 +169,10 @@ def test_gpu_rgba_textures_and_mesh_vertex_stage(mw, oracle, resolution):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("resolution", [8, 32, 128])
+@pytest.mark.parametrize("resolution", [8, 32, 128, 256, 512])
 def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
-    """BASELINE's shipped OceanRenderer configuration (1024^2 textures at resolution 128) and smaller."""
+    """BASELINE's shipped OceanRenderer configuration (1024^2 textures at resolution 128), smaller ones, the Inspector
+    default resolution 256 (2048^2) and the largest supported texture (4096^2, P = 16 kernels)."""
     rp = shipped(resolution)
     M = rp.M
     o = mw.Ocean(resolution=resolution, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude,
@@ -193,8 +194,11 @@ def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
         # nearly cancel: at those isolated texels 1/|n| amplifies float32 rounding.  Bound the bulk tightly and the
         # ill-conditioned tail loosely.
         en, ew = np.abs(n - Nn).max(-1).ravel(), np.abs(w - W).ravel()
-        assert np.quantile(en, 0.999) < 1e-4 and np.median(en) < 3e-6 and en.max() < 1e-2, (float(np.quantile(en, 0.999)), float(en.max()))
-        assert np.quantile(ew, 0.999) < 1e-4 and ew.max() < 1e-2, (float(np.quantile(ew, 0.999)), float(ew.max()))
+        # (the worst texel of 4M-16M is worse conditioned than the worst of 1M: the max bound grows with the texture)
+        # and the swell grows with the patch (length ~ M here) while the texel stays 0.42 m, so the differences cancel more
+        mx, q = 1e-2 * max(1.0, (M / 1024.0) ** 2), 1e-4 * max(1.0, M / 2048.0)
+        assert np.quantile(en, 0.999) < q and np.median(en) < 3e-6 * max(1.0, M / 2048.0) and en.max() < mx, (float(np.quantile(en, 0.999)), float(en.max()))
+        assert np.quantile(ew, 0.999) < q and ew.max() < mx, (float(np.quantile(ew, 0.999)), float(ew.max()))
     o.close()
 
 
