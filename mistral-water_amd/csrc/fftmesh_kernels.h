@@ -690,7 +690,10 @@ template <int N> struct Plan {
                           // 4096^2 +9 % over 2 rows + halo group, 2048^2 -8 % against 4 rows + halo group
 #endif
     static constexpr bool HS = (N >= MW_HS_MIN_N);
-    static constexpr int R2 = HS ? 4 : ((N >= 4096) ? 2 : 4);
+#ifndef MW_R2_SMALL_N
+#define MW_R2_SMALL_N 256  // grids up to this size use 8 rows + halo per pass-2 workgroup (256^2: +3.5 %; 512^2: -3 %)
+#endif
+    static constexpr int R2 = HS ? 4 : ((N >= 4096) ? 2 : ((N <= MW_R2_SMALL_N) ? 8 : 4));
 };
 
 }  // namespace mw
