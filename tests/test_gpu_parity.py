@@ -169,6 +169,21 @@ def test_batched_device_steps_equal_single_steps(mw, oracle):
             v, n, c = o.evaluate(t)
             assert (dv[k].cpu().numpy() == v).all() and (dn[k].cpu().numpy() == n).all()
             assert (dw[k].cpu().numpy() == c[:, 0]).all()
+        # every pass-1 time-group size (p1_block_map): 24 -> groups of 8, 12 -> 4, 6 -> 2, 7 -> plain 2-D grid
+        dv = torch.empty((24, NN, 3), dtype=torch.float32, device="cuda")
+        dn = torch.empty((24, NN, 3), dtype=torch.float32, device="cuda")
+        dw = torch.empty((24, NN), dtype=torch.float32, device="cuda")
+        singles = {}
+        for ns in (24, 12, 6, 7):
+            tt = [0.25 + 0.37 * k for k in range(ns)]
+            dv.zero_(); dn.zero_(); dw.zero_()
+            o.evaluate_device(tt, dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+            o.synchronize()
+            hv, hw = dv.cpu().numpy(), dw.cpu().numpy()
+            for k in (0, 1, ns // 2, ns - 1):
+                if k not in singles:
+                    singles[k] = o.evaluate(tt[k])
+                assert (hv[k] == singles[k][0]).all() and (hw[k] == singles[k][2][:, 0]).all(), (ns, k)
 
 
 def test_update_lifecycle_matches_fftmesh_update(mw, oracle):
