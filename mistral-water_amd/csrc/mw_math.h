@@ -366,8 +366,20 @@ MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
     const int p = 1 << (LogP<P>::v * s);
     const int k = u & (p - 1);
     const cf* __restrict__ row = tw.TS[s] + k * (P + 1);
+#ifdef MW_TW_POWERS
+    {   // experiment: one table read per thread and pass, the other P-2 twiddles as its powers (binary tree: <= log2 P
+        // multiplications deep)
+        cf w[P];
+        w[1] = row[1];
+#pragma unroll
+        for (int r = 2; r < P; r++) w[r] = cmul(w[r / 2], w[r - r / 2]);
+#pragma unroll
+        for (int r = 1; r < P; r++) x[r] = cmul(x[r], w[r]);
+    }
+#else
 #pragma unroll
     for (int r = 1; r < P; r++) x[r] = cmul(x[r], row[r]);
+#endif
     DftP<P, SGN>::run(x);
     const int j = ((u - k) << LogP<P>::v) + k;
 #ifdef MW_ABLATE_LDS
