@@ -96,6 +96,18 @@ def cpu_baseline(p, h0, h0c, budget_s=12.0):
     t1 = time.perf_counter()
     O.eval_fft_f64(p, h0, h0c, 1.0)
     el_fft = time.perf_counter() - t1
+    # a float32 radix-2 Stockham port in C (oracle/cpu_fft_baseline.c), 1 thread and all host cores
+    def time_c(nthreads, reps):
+        O.cpu_fft_step_f32(p, h0, h0c, 1.0, nthreads)
+        t2 = time.perf_counter()
+        for r in range(reps):
+            O.cpu_fft_step_f32(p, h0, h0c, 1.0 + r / 60.0, nthreads)
+        return (time.perf_counter() - t2) / reps
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    el_c1 = time_c(1, 2)
+    # more threads than the memory system can feed only add barrier cost: report the best thread count, name it
+    cands = sorted({c for c in (cores, cores // 2, cores // 4, cores // 8, 32, 16, 8) if 1 <= c <= cores})
+    el_call, best_threads = min((time_c(c, 3), c) for c in cands)
     return {
         "value": count / el, "unit": "grid-points/s", "cores": 1, "kind": "port",
         "sample": f"{count} of {N * N} vertices of one {N}x{N} step through the literal O(N^4) "
@@ -103,6 +115,10 @@ def cpu_baseline(p, h0, h0c, budget_s=12.0):
                   f"host has {os.cpu_count()} cores",
         "fft_port": {"value": N * N / el_fft, "unit": "grid-points/s", "cores": 1,
                      "what": "same model via numpy ifft2 in f64 (oracle.eval_fft_f64), one full step"},
+        "fft_port_c": {"value": N * N / el_c1, "unit": "grid-points/s", "cores": 1,
+                       "what": "float32 radix-2 Stockham port, 5 unpacked fields (oracle/cpu_fft_baseline.c), full steps"},
+        "fft_port_c_all_cores": {"value": N * N / el_call, "unit": "grid-points/s", "cores": best_threads,
+                                 "what": f"the same over pthreads; best of {cands} threads on the {cores}-core host"},
     }
 
 

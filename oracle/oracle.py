@@ -321,3 +321,18 @@ def pond_displace_f64(p, pos_xyz, t):
     if rc:
         raise ValueError("unknown pond displacement mode")
     return out, nrm
+
+
+def cpu_fft_step_f32(p: Params, h0, h0c, t: float, nthreads: int = 1):
+    """The CPU_FFT baseline of SURVEY.md 8d (oracle/cpu_fft_baseline.c): float32 radix-2 Stockham 2-D transform over
+    `nthreads` pthreads -> (vertices, normals, colors) float32.  Commensurate power-of-two grids only."""
+    N = p.N
+    h0 = np.ascontiguousarray(h0, np.float32)
+    h0c = np.ascontiguousarray(h0c, np.float32)
+    v = np.empty((N * N, 3), np.float32)
+    n = np.empty((N * N, 3), np.float32)
+    c = np.empty((N * N, 4), np.float32)
+    rc = lib().orc_cpu_fft_step_f32(C.byref(p.c()), _fp(h0), _fp(h0c), C.c_float(t), C.c_int(nthreads), _fp(v), _fp(n), _fp(c))
+    if rc:
+        raise ValueError({1: "N must be a power of two >= 8", 2: "grid is not commensurate", 3: "out of memory"}[rc])
+    return v, n, c

@@ -206,3 +206,20 @@ def test_golden_renderer_frame(oracle):
     v, n, c = oracle.renderer_mesh_vertex_stage_f64(rp, float(z["unit_width"]), H[..., 0], D[..., [0, 2]], Nn[..., :3], W[..., 0])
     assert np.abs(v - z["mesh_vertices"]).max() < 1e-12 and np.abs(n - z["mesh_normals"]).max() < 1e-12
     assert np.abs(c - z["mesh_colors"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("N,threads", [(64, 1), (256, 3), (512, 8)])
+def test_cpu_fft_baseline_matches_oracle(oracle, N, threads):
+    """oracle/cpu_fft_baseline.c (bench.py's all-cores CPU baseline) against the f64 oracle; thread count is immaterial."""
+    p = workloads.fftmesh_params(N)
+    h0, h0c = oracle.generate_spectrum(p, 4)
+    v, n, c = oracle.cpu_fft_step_f32(p, h0, h0c, 2.5, threads)
+    vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, 2.5, return_hds=True)
+    rest = oracle.rest_mesh(p)[0]
+    sc = max(np.abs(hds).max(), np.abs(vf[:, 1]).max())
+    assert np.abs(v - vf).max() < 2e-5 * sc + 2.0 ** -22 * np.abs(rest).max()      # f32 radix-2, log2 N stages
+    assert np.abs(n - nf).max() < 2e-5 and np.abs(c - cf).max() < 2e-4
+    v1, n1, c1 = oracle.cpu_fft_step_f32(p, h0, h0c, 2.5, 1)
+    assert (v1 == v).all() and (n1 == n).all() and (c1 == c).all()
+    with pytest.raises(ValueError):
+        oracle.cpu_fft_step_f32(workloads.shipped_fftmesh_scene(), *oracle.generate_spectrum(workloads.shipped_fftmesh_scene(), 1), 1.0)
