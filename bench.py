@@ -138,9 +138,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # test hooks for a 1-GPU box (never set by the driver): MW_BENCH_BACKEND=gloo + MW_BENCH_SAME_DEVICE=1 run the
+        # N > 1 control flow (barriers, max-over-ranks, rank-0 reporting) with every rank on cuda:0
+        backend = os.environ.get("MW_BENCH_BACKEND", "nccl")
+        if os.environ.get("MW_BENCH_SAME_DEVICE") == "1":
+            local_rank = 0
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
     stream = torch.cuda.current_stream()
 
     def barrier():
@@ -194,7 +203,7 @@ def main():
     el = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        tt = torch.tensor([el], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
