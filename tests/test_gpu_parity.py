@@ -57,6 +57,20 @@ def test_fftmesh_256_vs_literal_f32_sample(mw, oracle):
     assert np.abs(n[idx] - nor).max() < 3e-4
 
 
+def test_fftmesh_parity_after_an_hour(mw, oracle):
+    """timer = 3600 s: omega*t reaches ~2.5e4 rad in float32 (the reference's own product, reproduced bit for bit); the
+    kernels' sine/cosine must still be accurate there."""
+    p = workloads.fftmesh_params(256)
+    h0, h0c = oracle.generate_spectrum(p, 2)
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        for t in (3600.0, 86400.0):
+            v, n, c = o.evaluate(t)
+            vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, t, return_hds=True)
+            workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"t={t}")
+
+
 @pytest.mark.parametrize("N", [2048, 4096])
 def test_fftmesh_large_grids(mw, oracle, N):
     """BASELINE config 4 (4096^2): parity at full size against the numpy-FFT f64 oracle."""

@@ -4,7 +4,7 @@ import torch, numpy as np, ctypes as C
 import mistral_water as mw
 L = mw.lib()
 rng = np.random.default_rng(0)
-for scale in (3.0, 100.0, 500.0, 5000.0):
+for scale in (3.0, 100.0, 500.0, 5000.0, 1e5, 1e6):
     x = rng.uniform(-scale, scale, 1 << 20).astype(np.float32)
     for name in ("mw_debug_sincos", "mw_debug_sincos_fast"):
         s = np.empty_like(x); c = np.empty_like(x)
