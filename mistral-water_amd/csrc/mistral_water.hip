@@ -160,7 +160,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
     // the same XCD's L2 instead of a second 128-B line fill across the fabric.
     constexpr int NBLK = N / R2;
 #ifndef MW_XCD_GROUP
-#define MW_XCD_GROUP 1  // adjacent row blocks kept on one XCD (1 = plain round-robin)
+#define MW_XCD_GROUP 8  // adjacent row blocks kept on one XCD (1 = plain round-robin); 8-32: pass 2 -3 % at steady clocks
 #endif
     constexpr int XG = MW_XCD_GROUP;
     const int xcd = blockIdx.x % 8, cidx = blockIdx.x / 8;
