@@ -201,3 +201,12 @@ def test_gerstner_time_batched_path_vs_oracle(emul, oracle, nwaves):
     for k, t in enumerate(times):
         want = oracle.gerstner_f64(pos, W, P["amplitude"], P["frequency"], P["steepness"], t)
         assert np.abs(out[k] - want).max() < 8e-6, (nwaves, t)    # 1 ulp of a coordinate near 50 = 3.8e-6
+
+
+def test_pipeline_random_inspector_settings(emul, oracle):
+    """Seeded random parameter sets through the host-stepped kernels (the GPU tier runs 16 of these on the device)."""
+    for p, seed, t in workloads.random_fftmesh_cases(5, seed=7, sizes=(64, 128)):
+        h0, h0c = oracle.generate_spectrum(p, seed)
+        v, n, w = emul.evaluate(p, h0, h0c, [t])
+        vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, t, return_hds=True)
+        workloads.assert_parity(v[0], n[0], w[0], vf, nf, cf, oracle.rest_mesh(p)[0], np.abs(hds).max(), tag=f"{p} t={t}")

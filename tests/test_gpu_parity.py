@@ -57,6 +57,22 @@ def test_fftmesh_256_vs_literal_f32_sample(mw, oracle):
     assert np.abs(n[idx] - nor).max() < 3e-4
 
 
+def test_fftmesh_random_inspector_settings(mw, oracle):
+    """16 seeded random parameter sets (size, unit width, wind direction and speed, amplitude, choppiness, gravity, time,
+    seed) with the library's OWN spectrum generation on both sides: device spectrum == oracle spectrum, then parity."""
+    for p, seed, t in workloads.random_fftmesh_cases(16, seed=2024):
+        h0, h0c = oracle.generate_spectrum(p, seed)
+        rest = oracle.rest_mesh(p)[0]
+        with make(mw, p, seed=seed) as o:
+            g0, g0c = o.get_spectrum()
+            sc = max(np.abs(h0).max(), 1e-30)
+            assert np.abs(g0 - h0).max() < 4e-6 * sc and np.abs(g0c - h0c).max() < 4e-6 * sc, p
+            o.set_spectrum(h0, h0c)
+            v, n, c = o.evaluate(t)
+        vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, t, return_hds=True)
+        workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"{p} t={t}")
+
+
 def test_fftmesh_parity_after_an_hour(mw, oracle):
     """timer = 3600 s: omega*t reaches ~2.5e4 rad in float32 (the reference's own product, reproduced bit for bit); the
     kernels' sine/cosine must still be accurate there."""

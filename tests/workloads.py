@@ -10,6 +10,23 @@ def fftmesh_params(N: int, choppiness: float = 0.46) -> Params:
                   amplitude=1.5e-8 * (1024.0 / N) ** 2, choppiness=choppiness, gravity=9.81)
 
 
+def random_fftmesh_cases(count: int, seed: int, sizes=(64, 128, 256)):
+    """Seeded random Inspector settings on commensurate grids: size, unit width, wind, amplitude, choppiness, gravity, time.
+    The amplitude is chosen so that wave heights stay O(unit width), i.e. the choppy mesh folds here and there."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        N = int(rng.choice(sizes))
+        uw = float(rng.choice([0.25, 0.5, 1.0, 2.0, 3.5]))
+        ang, speed = rng.uniform(0, 2 * np.pi), rng.uniform(3.0, 30.0)
+        p = Params(N=N, unit_width=uw, length=float(np.float32(uw) * np.float32(N)), wind_x=float(speed * np.cos(ang)),
+                   wind_y=float(speed * np.sin(ang)), amplitude=float(1.5e-8 * (1024.0 / N) ** 2 * uw ** 2 * rng.uniform(0.3, 3.0)),
+                   choppiness=float(rng.uniform(0.0, 1.5)), gravity=float(rng.choice([9.81, 3.71, 24.8])))
+        out.append((p, int(rng.integers(1, 1 << 30)), float(rng.choice([0.0, 0.016, 1.0, 37.5, 1234.5, -2.0]))))
+    return out
+
+
 def shipped_fftmesh_scene() -> Params:
     """The scene the reference ships (D/FFT Mesh.unity:145-152): NOT commensurate, N = 12."""
     return Params(N=12, unit_width=1.0, length=12.39, wind_x=5.0, wind_y=3.0, amplitude=0.01, choppiness=1.0)
