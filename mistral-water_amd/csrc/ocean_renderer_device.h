@@ -124,7 +124,11 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
 // that produced the normal goes straight on to the whitecap (its own global write is visible to itself).
 __global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float* height, const cf* disp, const float* disp_g,
                                                          float* normal, float* white) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware: block b runs on XCD b % 8; give each XCD one contiguous band of texel rows, so that the +-1 and +-8 row
+    // neighbours are hits in ITS L2 (round-robin rows made every XCD fetch its own copy: 29.5 B/texel for 16 needed)
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    const unsigned blk = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+    int idx = blk * blockDim.x + threadIdx.x;
     if (idx >= c.M * c.M) return;
     or_normal_element(c, idx % c.M, idx / c.M, height, disp, disp_g, normal);
     or_white_element(c, idx % c.M, idx / c.M, disp, normal, white);

@@ -16,3 +16,9 @@ find $OUT -name "*.csv" | head -40
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_renderer -o renderer -- python bench.py --workload renderer1024 --steps 2000 > $OUT/renderer_stdout.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pond -o pond -- python bench.py --workload pond --steps 3200 > $OUT/pond_stdout.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_4096 -o o4096 -- python bench.py --workload ocean4096 --batch 4 --steps 200 --warmup 4 --no-cpu-baseline > $OUT/o4096_stdout.txt 2>&1
+# HBM-side traffic of the other workloads' kernels (FETCH_SIZE / WRITE_SIZE in separate passes)
+for w in renderer1024 pond; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${w}_$c -o pmc -- python bench.py --workload $w --steps 64 --warmup 8 --preheat-ms 0 --no-parity > /dev/null 2>&1
+  done
+done
