@@ -35,9 +35,64 @@ MW_HD void mw_sincos(float x, float* s, float* c) {
 }
 // hardware sine/cosine after an exact reduction (1.8e-7 absolute on the device): the VALU-bound pond kernels
 MW_HD void mw_sincos_fast(float x, float* s, float* c) { sincos_fast_f32(x, s, c); }
+// streaming (write-once) stores: MW_NT_STORES marks them non-temporal so that they do not displace reusable lines
+#ifndef MW_NT_STORES
+#define MW_NT_STORES 1  // measured: pass 1 -10 % (exchange-buffer stores), pass 2 -3 % (results)
+#endif
+// Results (vertices, normals, whitecap): non-temporal only where measured faster -- 512^2 (+5 % step) and 1024^2 (+2 % on
+// top of the exchange-buffer stores); slower at 256^2 (everything is cache-resident: -8 % pass 2) and in the 4096^2
+// sequential-halo kernel (-3 %), neutral at 2048^2.  
+MW_HD constexpr bool mw_nt_results(int N) { return N == 512 || N == 1024; }
+// exchange buffer: non-temporal from 512^2 up (pass 1 -10 %); at 256^2 the whole batch's buffer is cache-resident and
+// pass 2 reads it back 12 % slower if it was streamed out
+MW_HD constexpr bool mw_nt_exchange(int N) { return N >= 512; }
+template <bool NT = true>
+MW_HD void mw_store_stream(float* p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (MW_NT_STORES && NT) { __builtin_nontemporal_store(v, p); return; }
+#endif
+    *p = v;
+}
+template <bool NT = true>
+MW_HD void mw_store_stream(cf* p, cf v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (MW_NT_STORES && NT) {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        f2v t; t.x = v.x; t.y = v.y;
+        __builtin_nontemporal_store(t, reinterpret_cast<f2v*>(p));
+        return;
+    }
+#endif
+    *p = v;
+}
 // A value that is the same in every lane of a wave (e.g. tid / T when T is a multiple of 64): telling the compiler
 // lets it keep the value -- and every pointer derived from it -- in SGPRs, so global accesses use the
 // `saddr + 32-bit voffset` form instead of one 64-bit VGPR address pair per access.
+template <bool NT = true>
+MW_HD void mw_store_stream(f4* p, f4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (MW_NT_STORES && NT) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p));
+        return;
+    }
+#endif
+    *p = v;
+}
+#ifndef MW_NT_LOADS
+#define MW_NT_LOADS 0
+#endif
+MW_HD cf mw_load_stream(const cf* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (MW_NT_LOADS) {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(p));
+        return mk(t.x, t.y);
+    }
+#endif
+    return *p;
+}
 template <bool WAVE_UNIFORM>
 MW_HD int wave_uniform(int v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -317,7 +372,7 @@ MW_HD void p1_finish(const P1Args& A, const Twiddles& tw, int jb, int step, int 
     cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)jb * N * 4;  // block-uniform
     const unsigned voff = (unsigned)(u2 * 4 + w2);
 #pragma unroll
-    for (int q = 0; q < P; q++) (Ef + (size_t)T * q * 4)[voff] = x[q];
+    for (int q = 0; q < P; q++) mw_store_stream<mw_nt_exchange(N)>(&(Ef + (size_t)T * q * 4)[voff], x[q]);
 }
 
 // =============================== pass 2: transform along j + epilogue ========================
@@ -403,9 +458,9 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
         const int j = u1 + T * q;
         if (f == 0 && j > N / 2) {  // height: stored for j <= N/2 only; T(a, j) = conj T(a, N - j)
             const int m = N - j;
-            x[q] = cconj(Ef[(unsigned)(((m >> 2) * N + r1) * 4 + (m & 3))]);
+            x[q] = cconj(mw_load_stream(&Ef[(unsigned)(((m >> 2) * N + r1) * 4 + (m & 3))]));
         } else if (T % 4 == 0) {
-            x[q] = (Ef + (size_t)(T / 4) * q * N * 4)[voff];
+            x[q] = mw_load_stream(&(Ef + (size_t)(T / 4) * q * N * 4)[voff]);
         } else {
             x[q] = Ef[(unsigned)(((j >> 2) * N + r1) * 4 + (j & 3))];
         }
@@ -458,9 +513,9 @@ MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int 
             // Vector3.Normalize(up - n): |(sx,1,sz)| >= 1, so Unity's 1e-5 zero-guard never fires
             const float inv = mw_rsqrt(sx * sx + 1.0f + sz * sz);
             const float nx = sx * inv, ny = inv, nz = sz * inv;
-            nq[noff + 0] = nx;
-            nq[noff + 1] = ny;
-            nq[noff + 2] = nz;
+            mw_store_stream<mw_nt_results(N)>(&nq[noff + 0], nx);
+            mw_store_stream<mw_nt_results(N)>(&nq[noff + 1], ny);
+            mw_store_stream<mw_nt_results(N)>(&nq[noff + 2], nz);
             const float n0 = smul(fabsf(nx), 0.3f), n1 = smul(fabsf(nz), 0.3f);
             const float nz_ = ssqrt(sadd(smul(n0, n0), smul(n1, n1)));
             if (!ST::NOISE_REG) noise_lds[g * N + b] = nz_; else st.noise[ST::NOISE_REG ? q : 0] = nz_;
@@ -500,9 +555,9 @@ MW_HD void p2_vertices(const P2Args& A, int ab, int step, int tid, const ST& st)
         const int b = u + T * q;
         const cf d = st.d[q];
         float* vq = vblk + (size_t)T * q * 3;                                              // uniform
-        vq[voff + 0] = ssub(rx, smul(d.x, A.c.choppiness));                                // :245
-        vq[voff + 1] = st.h[q];                                                            // :243
-        vq[voff + 2] = ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness));  // :244
+        mw_store_stream<mw_nt_results(N)>(&vq[voff + 0], ssub(rx, smul(d.x, A.c.choppiness)));                                // :245
+        mw_store_stream<mw_nt_results(N)>(&vq[voff + 1], st.h[q]);                                                            // :243
+        mw_store_stream<mw_nt_results(N)>(&vq[voff + 2], ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness)));  // :244
     }
 }
 
@@ -529,13 +584,15 @@ MW_HD float p2_one_minus_jacobian(int a, int b, int q, const ST& st, const cf* n
     return ssub(1.f, jac);
 }
 // S/FFTMesh.cs:269-274: turbulence = max(1 - J + |0.3 n.xz|, 0) -> smoothstep -> Color
+template <bool NT>
 MW_HD void p2_store_white(float* wq, unsigned woff, int white_stride, float one_minus_jac, float noise) {
     const float turb = fmaxf(sadd(one_minus_jac, noise), 0.f);  // :270
     const float xx = smoothstep01(turb);                        // :273
     if (white_stride == 1) {
-        wq[woff] = xx;
+        mw_store_stream<NT>(&wq[woff], xx);
     } else {
-        wq[woff + 0] = xx; wq[woff + 1] = xx; wq[woff + 2] = xx; wq[woff + 3] = xx;  // :274
+        mw_store_stream<NT>(&wq[woff + 0], xx); mw_store_stream<NT>(&wq[woff + 1], xx);  // :274
+        mw_store_stream<NT>(&wq[woff + 2], xx); mw_store_stream<NT>(&wq[woff + 3], xx);
     }
 }
 // halo-group variant: vertex + whitecap of one thread's slots from the rows published in LDS, slot by slot (measured
@@ -556,12 +613,12 @@ MW_HD void p2_epilogue(const P2Args& A, int ab, int step, int tid, const ST& st,
         const int b = u + T * q;
         const cf d = st.d[q];
         float* vq = vblk + (size_t)T * q * 3;                                              // uniform
-        vq[voff + 0] = ssub(rx, smul(d.x, A.c.choppiness));                                // :245
-        vq[voff + 1] = st.h[q];                                                            // :243
-        vq[voff + 2] = ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness));  // :244
+        mw_store_stream<mw_nt_results(N)>(&vq[voff + 0], ssub(rx, smul(d.x, A.c.choppiness)));                                // :245
+        mw_store_stream<mw_nt_results(N)>(&vq[voff + 1], st.h[q]);                                                            // :243
+        mw_store_stream<mw_nt_results(N)>(&vq[voff + 2], ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness)));  // :244
         const float omj = p2_one_minus_jacobian<N, P, R2>(a, b, q, st, nxt, nb);
         const float nz_ = !ST::NOISE_REG ? noise_lds[g * N + b] : st.noise[ST::NOISE_REG ? q : 0];
-        p2_store_white(wblk + (size_t)T * q * A.white_stride, woff, A.white_stride, omj, nz_);
+        p2_store_white<mw_nt_results(N)>(wblk + (size_t)T * q * A.white_stride, woff, A.white_stride, omj, nz_);
     }
 }
 
@@ -636,12 +693,12 @@ MW_HD void p2_hs_finish_slopes(const P2Args& A, const Twiddles& tw, int ab, int 
         const float sx = sg * x[q].x, sz = sg * x[q].y;
         const float inv = mw_rsqrt(sx * sx + 1.0f + sz * sz);
         const float nx = sx * inv, ny = inv, nz = sz * inv;
-        nq[noff + 0] = nx;
-        nq[noff + 1] = ny;
-        nq[noff + 2] = nz;
+        mw_store_stream<mw_nt_results(N)>(&nq[noff + 0], nx);
+        mw_store_stream<mw_nt_results(N)>(&nq[noff + 1], ny);
+        mw_store_stream<mw_nt_results(N)>(&nq[noff + 2], nz);
         const float n0 = smul(fabsf(nx), 0.3f), n1 = smul(fabsf(nz), 0.3f);
         const float nz_ = ssqrt(sadd(smul(n0, n0), smul(n1, n1)));  // :269
-        p2_store_white(wblk + (size_t)T * q * A.white_stride, woff, A.white_stride, st.omj[q], nz_);
+        p2_store_white<mw_nt_results(N)>(wblk + (size_t)T * q * A.white_stride, woff, A.white_stride, st.omj[q], nz_);
     }
 }
 
