@@ -130,8 +130,9 @@ __global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float
     const unsigned blk = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
     int idx = blk * blockDim.x + threadIdx.x;
     if (idx >= c.M * c.M) return;
-    or_normal_element(c, idx % c.M, idx / c.M, height, disp, disp_g, normal);
-    or_white_element(c, idx % c.M, idx / c.M, disp, normal, white);
+    float nxz[2];
+    or_normal_element(c, idx % c.M, idx / c.M, height, disp, disp_g, normal, nxz);
+    or_white_element(c, idx % c.M, idx / c.M, disp, normal, white, nxz);
 }
 
 __global__ void k_or_pack_rgba(int M, const float* height, const float* height_g, const cf* disp, const float* disp_g,

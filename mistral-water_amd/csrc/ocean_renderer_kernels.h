@@ -199,8 +199,13 @@ MW_HD void or_p2_finish(const OrP2Args& A, const Twiddles& tw, int ab, int tid, 
 
 // F/OceanNormal.shader:39-56 and F/WhiteCap.shader:33-45 for one texel; clamp addressing
 MW_HD int or_clamp(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+#ifndef MW_OR_NT_STORES
+#define MW_OR_NT_STORES 0  // non-temporal normal/whitecap stores: -2 % frame time, but the textures are consumed right
+                           // away (renderer, mw_ocean_displace_mesh, RGBA packing) and should stay cache-resident: off
+#endif
+// normal_xz (optional): the normal's x and z as stored, for the whitecap of the same texel (F/WhiteCap.shader:38)
 MW_HD void or_normal_element(const OrConsts& c, int px, int py, const float* height, const cf* disp, const float* disp_g,
-                             float* normal) {
+                             float* normal, float* normal_xz = nullptr) {
     const int M = c.M;
     const float ts = c.length / (float)M;
     const size_t idx = (size_t)py * M + px;
@@ -216,9 +221,15 @@ MW_HD void or_normal_element(const OrConsts& c, int px, int py, const float* hei
     float ny = (r2 * t0 - r0 * t2) + (t2 * l0 - t0 * l2) + (l2 * b0 - l0 * b2) + (b2 * r0 - b0 * r2);
     float nz = (r0 * t1 - r1 * t0) + (t0 * l1 - t1 * l0) + (l0 * b1 - l1 * b0) + (b0 * r1 - b1 * r0);
     const float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
-    normal[3 * idx] = nx * inv; normal[3 * idx + 1] = ny * inv; normal[3 * idx + 2] = nz * inv;  // :55
+    const float ox = nx * inv, oy = ny * inv, oz = nz * inv;  // :55
+    mw_store_stream<MW_OR_NT_STORES != 0>(&normal[3 * idx], ox);
+    mw_store_stream<MW_OR_NT_STORES != 0>(&normal[3 * idx + 1], oy);
+    mw_store_stream<MW_OR_NT_STORES != 0>(&normal[3 * idx + 2], oz);
+    if (normal_xz) { normal_xz[0] = ox; normal_xz[1] = oz; }
 }
-MW_HD void or_white_element(const OrConsts& c, int px, int py, const cf* disp, const float* normal, float* white) {
+// normal_xz: (n.x, n.z) of this texel when the caller has just computed it, else read from `normal`
+MW_HD void or_white_element(const OrConsts& c, int px, int py, const cf* disp, const float* normal, float* white,
+                            const float* normal_xz = nullptr) {
     const int M = c.M;
     const size_t idx = (size_t)py * M + px;  // reads the normal of its own texel only, so one thread can do both passes
     // texelSize = 1/_Length with _Length = resolution = M/8 (S/OceanRenderer.cs:306): +-8 texels
@@ -226,11 +237,12 @@ MW_HD void or_white_element(const OrConsts& c, int px, int py, const cf* disp, c
     const cf xm = disp[(size_t)py * M + or_clamp(px - 8, M - 1)], xp = disp[(size_t)py * M + or_clamp(px + 8, M - 1)];
     const float dDdy_x = -0.5f * (ym.x - yp.x) / 8.f, dDdy_y = -0.5f * (ym.y - yp.y) / 8.f;  // :36
     const float dDdx_x = -0.5f * (xm.x - xp.x) / 8.f, dDdx_y = -0.5f * (xm.y - xp.y) / 8.f;  // :37
-    const float n0 = 0.3f * normal[3 * idx], n1 = 0.3f * normal[3 * idx + 2];                 // :38
+    const float n0 = 0.3f * (normal_xz ? normal_xz[0] : normal[3 * idx]);                     // :38
+    const float n1 = 0.3f * (normal_xz ? normal_xz[1] : normal[3 * idx + 2]);
     const float jac = (1.f + dDdx_x) * (1.f + dDdy_y) - dDdx_y * dDdy_x;                     // :39
     const float turb = fmaxf(0.f, 1.f - jac + sqrtf(n0 * n0 + n1 * n1));                    // :40
     const float t = turb > 1.f ? 1.f : turb;
-    white[idx] = t * t * (3.f - 2.f * t);                                                    // smoothstep(0,1,turb), :43
+    mw_store_stream<MW_OR_NT_STORES != 0>(&white[idx], t * t * (3.f - 2.f * t));             // smoothstep(0,1,turb), :43
 }
 
 
