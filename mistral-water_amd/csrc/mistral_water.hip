@@ -317,14 +317,8 @@ struct mw_ocean {
     bool use_fft = false;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
-    // two-stream pipeline: pass 1 of enqueue k+1 (aux stream, exchange region r^1) overlaps pass 2 of enqueue k
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_full[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_inputs = nullptr;
-    int region = 0;
     int p1_tgroup = 8;  // time-steps of one pass-1 column job grouped on one XCD (p1_block_map): -25 % pass-1 time;
                         // env MW_P1_TGROUP overrides (0 = plain 2-D grid)
-    bool pipeline = false;  // MW_PIPELINE=1: +1.5-2 % at 1024^2 (hides the inter-kernel tail/ramp); off by default so
-                            // that per-kernel durations in a profile are not stretched by the overlap
     float timer = 0.f;
     // FFTMesh state
     cf *h0 = nullptr, *h0c = nullptr;
@@ -468,13 +462,10 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
         default: return fail(MW_EINVAL, "unsupported FFT size"); \
     }
 
-static cf* region_E(mw_ocean* o, int r) { return o->E + (size_t)r * o->e_cap * 3 * o->N * o->N; }
-static cf* region_C(mw_ocean* o, int r) { return o->Cj0 + (size_t)r * o->e_cap * 3 * o->N; }
-
-static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipStream_t st, int r) {
+static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipStream_t st) {
     P1Args A;
     A.PQt = o->PQt; A.dPQ_i0 = o->dPQ_i0; A.dPQ_j0 = o->dPQ_j0; A.Om = o->Om; A.TW = o->TW;
-    A.E = region_E(o, r); A.Cj0 = region_C(o, r);
+    A.E = o->E; A.Cj0 = o->Cj0;
     A.c = consts_of(o);
     A.nsteps = nsteps;
     A.tgroup = 0;
@@ -485,9 +476,9 @@ static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipS
     if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pass1 launch: ") + hipGetErrorString(e));
     return MW_OK;
 }
-static mw_status launch_pass2(mw_ocean* o, int nsteps, float* dv, float* dn, float* dw, int white_stride, int r) {
+static mw_status launch_pass2(mw_ocean* o, int nsteps, float* dv, float* dn, float* dw, int white_stride) {
     P2Args A;
-    A.E = region_E(o, r); A.Cj0 = region_C(o, r); A.TW = o->TW2; A.vertices = dv; A.normals = dn; A.white = dw; A.white_stride = white_stride;
+    A.E = o->E; A.Cj0 = o->Cj0; A.TW = o->TW2; A.vertices = dv; A.normals = dn; A.white = dw; A.white_stride = white_stride;
     A.c = consts_of(o);
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass2_n<NN>(A, nsteps, o->stream));
@@ -499,29 +490,25 @@ static mw_status ensure_exchange(mw_ocean* o, int nsteps) {
     if (o->e_cap >= nsteps) return MW_OK;
     if (o->E) {
         HIP_TRY(hipStreamSynchronize(o->stream));
-        HIP_TRY(hipStreamSynchronize(o->aux_stream));
         HIP_TRY(hipFree(o->E));
         HIP_TRY(hipFree(o->Cj0));
         o->E = o->Cj0 = nullptr;
         o->e_cap = 0;
     }
-    const size_t regions = o->pipeline ? 2 : 1;
-    mw_status s = dmalloc(&o->E, regions * nsteps * 3 * o->N * o->N);
+    mw_status s = dmalloc(&o->E, (size_t)nsteps * 3 * o->N * o->N);
     if (s != MW_OK) return s;
-    if ((s = dmalloc(&o->Cj0, regions * nsteps * 3 * o->N)) != MW_OK) return s;
+    if ((s = dmalloc(&o->Cj0, (size_t)nsteps * 3 * o->N)) != MW_OK) return s;
     o->e_cap = nsteps;
     return MW_OK;
 }
 
 static mw_status run_prep(mw_ocean* o) {
     const int N = o->N;
-    if (o->aux_stream) HIP_TRY(hipStreamSynchronize(o->aux_stream));  // nobody may still read the old tables
     if (o->use_fft) {
         hipLaunchKernelGGL(k_prep, dim3((N * N + 255) / 256), dim3(256), 0, o->stream, N, o->p.length, o->p.gravity,
                            o->h0, o->h0c, o->Wpre, o->PQt, o->dPQ_i0, o->dPQ_j0, o->Om);
         HIP_TRY(hipGetLastError());
     }
-    if (o->ev_inputs) HIP_TRY(hipEventRecord(o->ev_inputs, o->stream));
     return MW_OK;
 }
 
@@ -574,9 +561,6 @@ void mw_ocean_destroy(mw_ocean* o) {
     hipFree(o->TW); hipFree(o->TW2); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white);
     direct_free(o->direct);
     or_free(o->orr);
-    if (o->aux_stream) { hipStreamSynchronize(o->aux_stream); hipStreamDestroy(o->aux_stream); }
-    for (int i = 0; i < 2; i++) { if (o->ev_full[i]) hipEventDestroy(o->ev_full[i]); if (o->ev_free[i]) hipEventDestroy(o->ev_free[i]); }
-    if (o->ev_inputs) hipEventDestroy(o->ev_inputs);
     if (o->own_stream) hipStreamDestroy(o->own_stream);
     delete o;
 }
@@ -609,13 +593,6 @@ mw_status mw_ocean_create(const mw_params* params, mw_ocean** out) {
     hipError_t he = hipStreamCreateWithFlags(&o->own_stream, hipStreamNonBlocking);
     if (he != hipSuccess) { delete o; return fail(MW_EDEVICE, "hipStreamCreate failed"); }
     o->stream = o->own_stream;
-    if (hipStreamCreateWithFlags(&o->aux_stream, hipStreamNonBlocking) != hipSuccess) { mw_ocean_destroy(o); return fail(MW_EDEVICE, "hipStreamCreate failed"); }
-    for (int i = 0; i < 2; i++) {
-        hipEventCreateWithFlags(&o->ev_full[i], hipEventDisableTiming);
-        hipEventCreateWithFlags(&o->ev_free[i], hipEventDisableTiming);
-    }
-    hipEventCreateWithFlags(&o->ev_inputs, hipEventDisableTiming);
-    if (const char* e = std::getenv("MW_PIPELINE")) o->pipeline = (e[0] != '0');
     if (const char* e = std::getenv("MW_P1_TGROUP")) o->p1_tgroup = std::atoi(e);
 
     if (o->sem == MW_SEM_FFTMESH) {
@@ -662,7 +639,6 @@ mw_status mw_ocean_set_stream(mw_ocean* o, void* hip_stream) {
     if (!o) return fail(MW_EINVAL, "NULL handle");
     HIP_TRY(hipSetDevice(o->device));
     HIP_TRY(hipStreamSynchronize(o->stream));
-    if (o->aux_stream) HIP_TRY(hipStreamSynchronize(o->aux_stream));
     o->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : o->own_stream;
     return MW_OK;
 }
@@ -780,22 +756,8 @@ mw_status mw_ocean_evaluate_device(mw_ocean* o, const float* t, int32_t nsteps, 
     if (s != MW_OK) return s;
     StepTimes tm;
     for (int k = 0; k < nsteps; k++) tm.t[k] = t[k];
-    if (!o->pipeline) {
-        if ((s = launch_pass1(o, tm, nsteps, o->stream, 0)) != MW_OK) return s;
-        return launch_pass2(o, nsteps, (float*)d_vertices, (float*)d_normals, (float*)d_white, white_stride, 0);
-    }
-    // pass 1 on the aux stream into region r, pass 2 on the caller's stream: consecutive enqueues overlap
-    // (pass 1 of this call runs beside pass 2 of the previous one, which reads the other region)
-    const int r = o->region;
-    o->region ^= 1;
-    HIP_TRY(hipStreamWaitEvent(o->aux_stream, o->ev_inputs, 0));
-    HIP_TRY(hipStreamWaitEvent(o->aux_stream, o->ev_free[r], 0));
-    if ((s = launch_pass1(o, tm, nsteps, o->aux_stream, r)) != MW_OK) return s;
-    HIP_TRY(hipEventRecord(o->ev_full[r], o->aux_stream));
-    HIP_TRY(hipStreamWaitEvent(o->stream, o->ev_full[r], 0));
-    if ((s = launch_pass2(o, nsteps, (float*)d_vertices, (float*)d_normals, (float*)d_white, white_stride, r)) != MW_OK) return s;
-    HIP_TRY(hipEventRecord(o->ev_free[r], o->stream));
-    return MW_OK;
+    if ((s = launch_pass1(o, tm, nsteps, o->stream)) != MW_OK) return s;
+    return launch_pass2(o, nsteps, (float*)d_vertices, (float*)d_normals, (float*)d_white, white_stride);
 }
 
 mw_status mw_ocean_evaluate(mw_ocean* o, float t, float* vertices_xyz, float* normals_xyz, float* colors_rgba) {
@@ -923,7 +885,6 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
     if (o->sem != MW_SEM_FFTMESH || !o->use_fft) return fail(MW_ESTATE, "mw_ocean_profile_kernels: FFT path only");
     if (nsteps < 1 || nsteps > MW_MAX_BATCH) return fail(MW_EINVAL, "nsteps out of range");
     HIP_TRY(hipSetDevice(o->device));
-    HIP_TRY(hipStreamSynchronize(o->aux_stream));
     HIP_TRY(hipStreamSynchronize(o->stream));
     mw_status s = ensure_exchange(o, nsteps);
     if (s != MW_OK) return s;
@@ -942,14 +903,14 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
     std::vector<hipEvent_t> ev(2 * iters + 1);
     for (auto& e : ev) hipEventCreate(&e);
     for (int w = 0; w < 2 && s == MW_OK; w++) {  // warm-up
-        s = launch_pass1(o, tm, nsteps, o->stream, 0);
-        if (s == MW_OK) s = launch_pass2(o, nsteps, dv, dn, dw, 1, 0);
+        s = launch_pass1(o, tm, nsteps, o->stream);
+        if (s == MW_OK) s = launch_pass2(o, nsteps, dv, dn, dw, 1);
     }
     hipEventRecord(ev[0], o->stream);
     for (int it = 0; it < iters && s == MW_OK; it++) {
-        s = launch_pass1(o, tm, nsteps, o->stream, 0);
+        s = launch_pass1(o, tm, nsteps, o->stream);
         hipEventRecord(ev[2 * it + 1], o->stream);
-        if (s == MW_OK) s = launch_pass2(o, nsteps, dv, dn, dw, 1, 0);
+        if (s == MW_OK) s = launch_pass2(o, nsteps, dv, dn, dw, 1);
         hipEventRecord(ev[2 * it + 2], o->stream);
     }
     hipEventSynchronize(ev[2 * iters]);
