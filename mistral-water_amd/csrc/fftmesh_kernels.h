@@ -45,7 +45,10 @@ MW_HD void mw_sincos_fast(float x, float* s, float* c) { sincos_fast_f32(x, s, c
 MW_HD constexpr bool mw_nt_results(int N) { return N == 512 || N == 1024; }
 // exchange buffer: non-temporal from 512^2 up (pass 1 -10 %); at 256^2 the whole batch's buffer is cache-resident and
 // pass 2 reads it back 12 % slower if it was streamed out
-MW_HD constexpr bool mw_nt_exchange(int N) { return N >= 512; }
+#ifndef MW_NT_EXCHANGE_MIN_N
+#define MW_NT_EXCHANGE_MIN_N 512
+#endif
+MW_HD constexpr bool mw_nt_exchange(int N) { return N >= MW_NT_EXCHANGE_MIN_N; }
 template <bool NT = true>
 MW_HD void mw_store_stream(float* p, float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
