@@ -104,6 +104,13 @@ MW_HD int wave_uniform(int v) {
     return v;
 #endif
 }
+// scheduling fence: keeps the compiler from hoisting every LDS read of an unrolled loop above the arithmetic of its
+// first iterations (all reads in flight at once = all their destination registers live at once)
+MW_HD void mw_sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 MW_HD float mw_rsqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __frsqrt_rn(x);
@@ -265,7 +272,7 @@ struct P1Geom {
     static constexpr int T = FftGeom<N, P>::T;
     static constexpr int NTHREADS = 4 * T;
     static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4;
-    static constexpr int TW_LDS = TwGeom<N, P>::IN_LDS ? ((TwGeom<N, P>::TOTAL + 1) & ~1) : 0;  // cf units, 16-B aligned
+    static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;  // cf units, 16-B aligned
     static constexpr int SETSTRIDE = 4 * BUFSTRIDE;
     // 2: ping-pong exchange buffers, one barrier per exchange (when both sets fit a 100 KiB budget)
     static constexpr int NBUF = (MW_DBUF && (TW_LDS + 2 * SETSTRIDE) * 8 <= 100 * 1024) ? 2 : 1;
@@ -405,7 +412,7 @@ struct P2Geom {
     static constexpr int NGROUPS = HS ? R2 : R2 + 1;
     static constexpr int NTHREADS = NGROUPS * T;
     static constexpr int BUFSTRIDE = P2Buf<N, P>::BUFSTRIDE;
-    static constexpr int TW_LDS = TwGeom<N, P>::IN_LDS ? ((TwGeom<N, P>::TOTAL + 1) & ~1) : 0;
+    static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;
     static constexpr int SETSTRIDE = NGROUPS * BUFSTRIDE;
     static constexpr int NBUF = (!HS && MW_DBUF && (TW_LDS + 2 * SETSTRIDE) * 8 <= 100 * 1024) ? 2 : 1;
     // the whitecap noise term |0.3 n.xz| waits in LDS (R2*N floats) from the slope field to the epilogue instead of
@@ -456,6 +463,14 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
     const cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * 4;  // block-uniform base (first row of the block)
     // per-lane 32-bit offset of element j = u1 (slot q adds the uniform T*q/4 chunks of N*4)
     const unsigned voff = (unsigned)(((u1 >> 2) * N + r1) * 4 + (u1 & 3));
+#ifdef MW_ABLATE_SEQ_READ  // timing experiment (wrong results): the same bytes from ONE contiguous block per workgroup
+    {
+        const cf* Es = A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * N;
+#pragma unroll
+        for (int q = 0; q < P; q++) x[q] = mw_load_stream(&(Es + (size_t)R2 * T * q)[(unsigned)(tid % (R2 * T))]);
+        return;
+    }
+#endif
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int j = u1 + T * q;
@@ -658,15 +673,19 @@ MW_HD void p2_hs_jacobian(int ab, int tid, P2StateHS<P>& st, const cf* own, cons
     NbRow nb;
     nb.row = own;
 #pragma unroll
-    for (int q = 0; q < P; q++) st.omj[q] = p2_one_minus_jacobian<N, P, R2>(a, u + T * q, q, st, nxt, nb);
+    for (int q = 0; q < P; q++) {
+        st.omj[q] = p2_one_minus_jacobian<N, P, R2>(a, u + T * q, q, st, nxt, nb);
+        if (q % 4 == 3) mw_sched_fence();
+    }
 }
-// the same for the block's last row, entirely from LDS: own = its published hds row, nxt = the halo row
+// the same entirely from LDS (own = the row's published hds copy, nxt = row a+1 or the halo row): the block's last row
+// after the halo transform, and -- with P = 16, where d[] alone is 32 VGPRs -- every row (HS_JAC_FROM_LDS)
 template <int P>
 struct P2RowView { cf d[P]; };
 template <int N, int P, int R2>
 MW_HD void p2_hs_jacobian_lds(int ab, int tid, P2StateHS<P>& st, const cf* own, const cf* nxt) {
     constexpr int T = FftGeom<N, P>::T;
-    const int u = tid % T, a = ab * R2 + R2 - 1;
+    const int g = tid / T, u = tid % T, a = ab * R2 + g;
     NbRow nb;
     nb.row = own;
 #pragma unroll
@@ -675,6 +694,7 @@ MW_HD void p2_hs_jacobian_lds(int ab, int tid, P2StateHS<P>& st, const cf* own, 
         P2RowView<P> v;
         v.d[q] = own[b];
         st.omj[q] = p2_one_minus_jacobian<N, P, R2>(a, b, q, v, nxt, nb);
+        if (q % 4 == 3) mw_sched_fence();
     }
 }
 // final pass of the slope field: unit normal (S/FFTMesh.cs:218) and, with the waiting 1 - J, the whitecap
@@ -738,22 +758,51 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 #ifndef MW_PT2
 #define MW_PT2 MW_PT  // pass 2 (the exchange-buffer layout does not depend on P, so the passes may differ)
 #endif
-template <int N> struct Plan {
-    static constexpr int P = (N >= 2048) ? 16 : MW_PT;    // OceanRenderer passes
-    static constexpr int P1 = (N >= 2048) ? 16 : MW_PT1;  // 5 x N/8 threads would exceed 1024 at N = 2048
+// Pass-2 plans of the large grids (A/B-measured): points per thread, rows per workgroup and whether
+// the sequential-halo kernel is used.  The aim from 2048^2 up is TWO resident workgroups per CU (<= 80 KiB of LDS and
+// <= 64 VGPRs at 1024 threads), which only 8 points per thread allows.
 #ifndef MW_PT2_2048
 #define MW_PT2_2048 16
 #endif
-    static constexpr int P2 = (N >= 4096) ? 16 : (N == 2048 ? MW_PT2_2048 : MW_PT2);
-#ifndef MW_HS_MIN_N
-#define MW_HS_MIN_N 4096  // grids from this size up use the sequential-halo pass 2 (P2Geom<..., true>); measured:
-                          // 4096^2 +9 % over 2 rows + halo group, 2048^2 -8 % against 4 rows + halo group
+#ifndef MW_PT2_4096
+#define MW_PT2_4096 16
 #endif
-    static constexpr bool HS = (N >= MW_HS_MIN_N);
+#ifndef MW_HS_2048
+#define MW_HS_2048 1  // 2048^2: sequential halo, 4 rows, 2 virtual threads per lane, two 4-wave workgroups per CU: +10 % over 4 rows + halo group
+#endif
+#ifndef MW_HS_4096
+#define MW_HS_4096 1  // sequential-halo pass 2 (P2Geom<..., true>): 4096^2 +9 % over 2 rows + halo group
+#endif
+#ifndef MW_R2_2048
+#define MW_R2_2048 4
+#endif
+#ifndef MW_R2_4096
+#define MW_R2_4096 4
+#endif
+#ifndef MW_VT_4096
+#define MW_VT_4096 2
+#endif
+#ifndef MW_VT_2048
+#define MW_VT_2048 2
+#endif
+#ifndef MW_VT1_4096
+#define MW_VT1_4096 1
+#endif
+#ifndef MW_VT1_2048
+#define MW_VT1_2048 1
+#endif
 #ifndef MW_R2_SMALL_N
 #define MW_R2_SMALL_N 256  // grids up to this size use 8 rows + halo per pass-2 workgroup (256^2: +3.5 %; 512^2: -3 %)
 #endif
-    static constexpr int R2 = HS ? 4 : ((N >= 4096) ? 2 : ((N <= MW_R2_SMALL_N) ? 8 : 4));
+template <int N> struct Plan {
+    static constexpr int P = (N >= 2048) ? 16 : MW_PT;    // OceanRenderer passes
+    static constexpr int P1 = (N >= 2048) ? 16 : MW_PT1;  // 5 x N/8 threads would exceed 1024 at N = 2048
+    static constexpr int P2 = (N >= 4096) ? MW_PT2_4096 : (N == 2048 ? MW_PT2_2048 : MW_PT2);
+    static constexpr bool HS = (N >= 4096) ? (MW_HS_4096 != 0) : (N == 2048 ? (MW_HS_2048 != 0) : false);
+    static constexpr int R2 = (N >= 4096) ? MW_R2_4096 : (N == 2048 ? MW_R2_2048 : ((N <= MW_R2_SMALL_N) ? 8 : 4));
+    // virtual threads per lane of the sequential-halo kernel (k_pass2_hs): 2 = 8 fat waves with a 256-VGPR budget
+    static constexpr int VT = (N >= 4096) ? MW_VT_4096 : MW_VT_2048;
+    static constexpr int VT1 = (N >= 4096) ? MW_VT1_4096 : (N == 2048 ? MW_VT1_2048 : 1);  // the same for pass 1
 };
 
 }  // namespace mw

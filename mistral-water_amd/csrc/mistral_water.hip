@@ -74,10 +74,13 @@ __global__ void k_omega_t(int N, float length, float gravity, float t, float* ou
 }
 
 #ifdef MW_TIMING
+#ifndef MW_STAMP_STEP
+#define MW_STAMP_STEP 3
+#endif
 __device__ long long g_stamps[2][64][8][32];  // [kernel][block slot][wave][stamp]
 #define MW_STAMP(K, id)                                                                               \
     do {                                                                                              \
-        if ((blockIdx.x % 37) == 5 && blockIdx.x / 37 < 64 && blockIdx.y == 3 && (threadIdx.x & 63) == 0) \
+        if ((blockIdx.x % 37) == 5 && blockIdx.x / 37 < 64 && step == MW_STAMP_STEP && (threadIdx.x & 63) == 0 && threadIdx.x < 512) \
             g_stamps[K][blockIdx.x / 37][threadIdx.x >> 6][id] = __builtin_readcyclecounter();        \
     } while (0)
 #elif defined(MW_SCHED_FENCE)
@@ -94,57 +97,83 @@ __device__ __forceinline__ void stage_tables(cf* dst, const cf* __restrict__ src
     for (int i = tid; i < TOTAL; i += NT) dst[i] = src[i];
 }
 
-template <int N, int P>
-__global__ __launch_bounds__((P1Geom<N, P>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(P == 8 ? MW_WAVES_P1 : 4))) void k_pass1(
-    P1Args A, StepTimes times) {
+// VT = virtual threads per lane (see k_pass2_hs): the phase functions are written for 4*T virtual threads (4 spectrum
+// columns x T); a workgroup of 4*T/VT lanes runs virtual threads tid, tid + NT, ... of every phase back to back.
+template <int N, int P, int VT>
+__global__ __launch_bounds__((P1Geom<N, P>::NTHREADS / VT))
+__attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : (P == 8 ? MW_WAVES_P1 : 4)))) void k_pass1(P1Args A, StepTimes times) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = P1Geom<N, P>;
     cf* lds = reinterpret_cast<cf*>(smem);
-    constexpr int T = FftGeom<N, P>::T;
+    constexpr int T = FftGeom<N, P>::T, NT = G::NTHREADS / VT;
+    static_assert(G::NTHREADS % VT == 0 && (VT == 1 || NT % T == 0), "a lane's virtual threads must belong to whole columns");
     const int tid = threadIdx.x;
     int jb = blockIdx.x, step = blockIdx.y;
     if (A.tgroup > 0 && !p1_block_map((int)blockIdx.x, G::GRID_X, A.nsteps, A.tgroup, &jb, &step)) return;
     const float t = times.t[step];
-    const int w = tid / T, u = tid % T;
-    if (TwGeom<N, P>::IN_LDS) stage_tables<TwGeom<N, P>::TOTAL, G::NTHREADS>(lds, A.TW, tid);  // visible after the first barrier
-    const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
+    if (TwGeom<N, P>::LDS_CF) stage_tables<TwGeom<N, P>::LDS_CF, NT>(lds, A.TW, tid);  // visible after the first barrier
+    const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     int cur = 0;  // set the next store goes to
-    P1State<P> st;
-    cf x[P];
+    P1State<P> st[VT];
+    cf x[VT][P];
+#define MW_VT(h) for (int h = 0; h < VT; h++)
+#define MW_BUF(h) (set0 + cur * G::SETSTRIDE + ((tid + (h) * NT) / T) * G::BUFSTRIDE)
+#define MW_U(h) ((tid + (h) * NT) % T)
     MW_STAMP(0, 0);
-    p1_animate<N, P>(A, jb, tid, t, st);
+#pragma unroll
+    MW_VT(h) p1_animate<N, P>(A, jb, tid + h * NT, t, st[h]);
     MW_STAMP(0, 1);
 #pragma unroll
     for (int f = 0; f < 3; f++) {
         if (!p1_field_active(N, jb, f)) continue;  // block-uniform: height needs columns j <= N/2 only
-        p1_build<N, P>(A, jb, tid, f, st, x);
+#pragma unroll
+        MW_VT(h) p1_build<N, P>(A, jb, tid + h * NT, f, st[h], x[h]);
         if (G::NBUF == 1 && f) __syncthreads();
         MW_STAMP(0, 2 + 8 * f);
 #ifdef MW_ABLATE_FFT
         {
             cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)(jb % (N / 4)) * N * 4;
 #pragma unroll
-            for (int q = 0; q < P; q++) Ef[(size_t)((tid >> 2) + T * q) * 4 + (tid & 3)] = x[q];
+            MW_VT(h)
+#pragma unroll
+            for (int q = 0; q < P; q++) Ef[(size_t)(((tid + h * NT) >> 2) + T * q) * 4 + (tid & 3)] = x[h][q];
             continue;
         }
 #endif
-        stage0_store<N, P, +1>(x, u, set0 + cur * G::SETSTRIDE + w * G::BUFSTRIDE);
+#pragma unroll
+        MW_VT(h) stage0_store<N, P, +1>(x[h], MW_U(h), MW_BUF(h));
         MW_STAMP(0, 3 + 8 * f);
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
-            load_slots<N, P>(x, u, set0 + cur * G::SETSTRIDE + w * G::BUFSTRIDE);
+#pragma unroll
+            MW_VT(h) load_slots<N, P>(x[h], MW_U(h), MW_BUF(h));
             if (G::NBUF == 1) __syncthreads(); else cur ^= 1;
-            stage_store<N, P, +1>(x, u, set0 + cur * G::SETSTRIDE + w * G::BUFSTRIDE, tw, s);
+#pragma unroll
+            MW_VT(h) stage_store<N, P, +1>(x[h], MW_U(h), MW_BUF(h), tw, s);
             __syncthreads();
         }
         MW_STAMP(0, 7 + 8 * f);
-        p1_finish<N, P>(A, tw, jb, step, tid, f, x, set0 + cur * G::SETSTRIDE);
+#pragma unroll
+        MW_VT(h) p1_finish<N, P>(A, tw, jb, step, tid + h * NT, f, x[h], set0 + cur * G::SETSTRIDE);
         if (G::NBUF == 2) cur ^= 1;
         MW_STAMP(0, 8 + 8 * f);
     }
     MW_STAMP(0, 26);
+#undef MW_VT
+#undef MW_BUF
+#undef MW_U
+}
+
+#ifndef MW_XCD_GROUP
+#define MW_XCD_GROUP 8  // adjacent row blocks kept on one XCD (1 = plain round-robin); 8-32: pass 2 -3 % at steady clocks
+#endif
+template <int NBLK>
+__device__ __forceinline__ int p2_row_block(int b) {
+    constexpr int XG = MW_XCD_GROUP;
+    const int xcd = b % 8, cidx = b / 8;
+    return (XG > 1 && NBLK % (8 * XG) == 0) ? (cidx / XG) * (8 * XG) + xcd * XG + (cidx % XG) : b;
 }
 
 template <int N, int P, int R2>
@@ -158,16 +187,10 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
     // XCD-aware row-block mapping: the dispatcher places block b on XCD b % 8 (speed only, never correctness); giving
     // each XCD a contiguous range of row blocks makes a block's halo row (the first row of the NEXT block) a hit in
     // the same XCD's L2 instead of a second 128-B line fill across the fabric.
-    constexpr int NBLK = N / R2;
-#ifndef MW_XCD_GROUP
-#define MW_XCD_GROUP 8  // adjacent row blocks kept on one XCD (1 = plain round-robin); 8-32: pass 2 -3 % at steady clocks
-#endif
-    constexpr int XG = MW_XCD_GROUP;
-    const int xcd = blockIdx.x % 8, cidx = blockIdx.x / 8;
-    const int ab = (XG > 1 && NBLK % (8 * XG) == 0) ? (cidx / XG) * (8 * XG) + xcd * XG + (cidx % XG) : (int)blockIdx.x;
+    const int ab = p2_row_block<N / R2>((int)blockIdx.x);
     const int g = tid / T;
-    if (TwGeom<N, P>::IN_LDS) stage_tables<TwGeom<N, P>::TOTAL, G::NTHREADS>(lds, A.TW, tid);
-    const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
+    if (TwGeom<N, P>::LDS_CF) stage_tables<TwGeom<N, P>::LDS_CF, G::NTHREADS>(lds, A.TW, tid);
+    const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     float* noise_lds = reinterpret_cast<float*>(lds + G::NOISE_OFF);
     int cur = 0;
@@ -238,72 +261,151 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
 // Pass 2, sequential-halo variant (large N): R2 row groups, no halo group.  Height and displacement fields first; then
 // the vertices leave, every row publishes hds, rows 0..R2-2 form 1 - J, group 0 transforms the halo row in buffer 0, row R2-1 follows;
 // the slope field comes last and its final pass writes normals and whitecap together.
-template <int N, int P, int R2>
-__global__ __launch_bounds__((P2Geom<N, P, R2, true>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(P == 8 ? 8 : 4))) void k_pass2_hs(P2Args A) {
+//
+// VT = "virtual threads" per lane: the phase functions are written for R2*T virtual threads; a workgroup of R2*T/VT
+// lanes runs virtual threads tid, tid + NT, ... of every phase back to back.  With VT = 2 a 4096-point, 4-row block is 8
+// waves instead of 16: each lane owns 2 x 16 points, the register budget doubles to 256 (the 16-wave form spilled 29
+// dwords = 14 B of scratch traffic per grid point at its 128), the two independent rows of a lane give the scheduler two
+// instruction streams to interleave, and every barrier joins half as many waves.
+//
+// mw_fresh (opt-in, -DMW_FRESH): every phase derives its lane indices from an opaque copy of the thread index, so that the
+// compiler cannot hoist the index arithmetic of all phases to the top of the kernel; it removes the spills of the 16-wave
+// form but the asm statements are scheduling barriers and the kernel gets 10-15 % slower: off.
+__device__ __forceinline__ int mw_fresh(int v) {
+#ifdef MW_FRESH
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+#ifndef MW_HS_JAC_FROM_LDS
+#define MW_HS_JAC_FROM_LDS 99  // points per thread from which the Jacobian re-reads its own row from LDS (d[] dead): off
+#endif
+// minimum waves per SIMD the register allocator must leave room for: as many workgroups per CU as the LDS admits (at most 2)
+constexpr int hs_min_waves(int nthreads, int lds_bytes) {
+    const int wgs = (2 * lds_bytes <= 160 * 1024) ? 2 : 1;
+    const int w = nthreads / 64 * wgs / 4;
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+template <int N, int P, int R2, int VT>
+__global__ __launch_bounds__((P2Geom<N, P, R2, true>::NTHREADS / VT))
+__attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS / VT, P2Geom<N, P, R2, true>::LDS_BYTES)))) void k_pass2_hs(P2Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = P2Geom<N, P, R2, true>;
     cf* lds = reinterpret_cast<cf*>(smem);
-    constexpr int T = FftGeom<N, P>::T;
-    const int tid = threadIdx.x, step = blockIdx.y, ab = blockIdx.x;
-    const int g = wave_uniform<true>(tid / T), u = tid % T;
-    if (TwGeom<N, P>::IN_LDS) stage_tables<TwGeom<N, P>::TOTAL, G::NTHREADS>(lds, A.TW, tid);
-    const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
+    constexpr int T = FftGeom<N, P>::T, NT = G::NTHREADS / VT;  // NT lanes, each running VT virtual threads
+    static_assert(G::NTHREADS % VT == 0 && NT % T == 0, "a lane's virtual threads must belong to distinct whole row groups");
+    const int tid0 = threadIdx.x, step = blockIdx.y;
+#ifdef MW_HS_NO_XCD_MAP
+    const int ab = blockIdx.x;
+#else
+    const int ab = p2_row_block<N / R2>((int)blockIdx.x);  // neighbouring row blocks (halo rows, shared 128-B lines) on one XCD
+#endif
+    const int g0 = wave_uniform<true>(tid0 / T);  // row group of virtual thread 0; virtual thread h is in group g0 + h * NT / T
+    if (TwGeom<N, P>::LDS_CF) stage_tables<TwGeom<N, P>::LDS_CF, NT>(lds, A.TW, tid0);
+    const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
-    P2StateHS<P> st;
-    cf x[P];
+    P2StateHS<P> st[VT];
+    cf x[VT][P];
+#ifndef MW_HS_HALO_EARLY
+#define MW_HS_HALO_EARLY 1
+#endif
+    constexpr bool HALO_EARLY = (MW_HS_HALO_EARLY != 0) && VT >= 2;
+    cf xh[HALO_EARLY ? P : 1];  // halo row data parked in registers across the displacement transform
+    const int tid = tid0;  // MW_STAMP
+    MW_STAMP(1, 0);
+#define MW_VT(h) for (int h = 0; h < VT; h++)
+#define MW_VTID(h) (mw_fresh(tid0) + (h) * NT)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int f = p2_hs_field(k);
         __syncthreads();  // k = 0: twiddle tables staged; later: the previous phase's LDS reads are done
-        p2_load<N, P, R2>(A, ab, step, tid, f, x, set0);
+        MW_STAMP(1, 1 + 8 * k);
+#pragma unroll
+        MW_VT(h) p2_load<N, P, R2>(A, ab, step, MW_VTID(h), f, x[h], set0);
+        // The halo row's lines are the next row block's own lines: fetched NOW, while that block (same XCD, same phase)
+        // loads them too, they are L2 hits; fetched two phases later they have left the L2 and cost a second 128-B fill
+        // per 32-B piece (measured +6 B per grid point).  Needs 2P spare VGPRs across the displacement transform: VT >= 2.
+        if (HALO_EARLY && f == 1 && g0 == 0 && ab * R2 + R2 < N) p2_hs_halo_fetch<N, P, R2>(A, ab, step, mw_fresh(tid0) % T, xh);
+        MW_STAMP(1, 2 + 8 * k);
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
-            p2_mid_load<N, P, R2>(tid, x, set0);
+#pragma unroll
+            MW_VT(h) p2_mid_load<N, P, R2>(MW_VTID(h), x[h], set0);
             __syncthreads();
-            p2_mid_store<N, P, R2>(tw, tid, s, x, set0);
+#pragma unroll
+            MW_VT(h) p2_mid_store<N, P, R2>(tw, MW_VTID(h), s, x[h], set0);
             __syncthreads();
         }
+        MW_STAMP(1, 6 + 8 * k);
         if (f == 2) {
-            p2_hs_finish_slopes<N, P, R2>(A, tw, ab, step, tid, x, st, set0);
+#pragma unroll
+            MW_VT(h) p2_hs_finish_slopes<N, P, R2>(A, tw, ab, step, MW_VTID(h), x[h], st[h], set0);
+            MW_STAMP(1, 7 + 8 * k);
             break;
         }
-        p2_hs_finish<N, P, R2>(tw, ab, tid, f, x, st, set0);
+#pragma unroll
+        MW_VT(h) p2_hs_finish<N, P, R2>(tw, ab, MW_VTID(h), f, x[h], st[h], set0);
+        MW_STAMP(1, 7 + 8 * k);
         if (f != 1) continue;
         // ---- displacement done: vertices, halo row, Jacobian ----
-        p2_vertices<N, P, R2>(A, ab, step, tid, st);
+#pragma unroll
+        MW_VT(h) p2_vertices<N, P, R2>(A, ab, step, MW_VTID(h), st[h]);
+        MW_STAMP(1, 24);
         __syncthreads();  // every final-pass read of the displacement buffers is done
-        p2_publish_hds<N, P, R2>(tid, st, set0);  // every row into its own buffer, plain index b
+#pragma unroll
+        MW_VT(h) p2_publish_hds<N, P, R2>(MW_VTID(h), st[h], set0);  // every row into its own buffer, plain index b
         __syncthreads();
         const bool has_halo = (ab * R2 + R2 < N);  // block-uniform
         // Rows 0..R2-2 have their (a+1) neighbour published already: they form 1 - J now.  Buffer 0 (row 0's copy) is
         // then free for the halo row's transform; row R2-1 waits for it and works from its own published copy, so that
         // nobody's d is live across the halo transform (P = 16: the transform alone takes ~100 VGPRs).
-        if (g != R2 - 1) p2_hs_jacobian<N, P, R2>(ab, tid, st, set0 + g * G::BUFSTRIDE, set0 + (g + 1) * G::BUFSTRIDE);
+#pragma unroll
+        MW_VT(h) {
+            const int g = g0 + h * (NT / T);
+            if (g != R2 - 1) {
+                if (P >= MW_HS_JAC_FROM_LDS)
+                    p2_hs_jacobian_lds<N, P, R2>(ab, MW_VTID(h), st[h], set0 + g * G::BUFSTRIDE, set0 + (g + 1) * G::BUFSTRIDE);
+                else
+                    p2_hs_jacobian<N, P, R2>(ab, MW_VTID(h), st[h], set0 + g * G::BUFSTRIDE, set0 + (g + 1) * G::BUFSTRIDE);
+            }
+        }
         __syncthreads();  // group 0 no longer reads its own row
-        if (has_halo) {
-            if (g == 0) {
-                p2_hs_halo_fetch<N, P, R2>(A, ab, step, u, x);
-                stage0_store<N, P, +1>(x, u, set0);
+        MW_STAMP(1, 25);
+        if (has_halo) {  // group 0 = virtual thread 0 of the lanes below T
+            const int u = mw_fresh(tid0) % T;
+            if (g0 == 0) {
+                if (HALO_EARLY) {
+#pragma unroll
+                    for (int q = 0; q < P; q++) x[0][q] = xh[q];
+                } else {
+                    p2_hs_halo_fetch<N, P, R2>(A, ab, step, u, x[0]);
+                }
+                stage0_store<N, P, +1>(x[0], u, set0);
             }
             __syncthreads();
 #pragma unroll
             for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                if (g == 0) load_slots<N, P>(x, u, set0);
+                if (g0 == 0) load_slots<N, P>(x[0], u, set0);
                 __syncthreads();
-                if (g == 0) stage_store<N, P, +1>(x, u, set0, tw, s);
+                if (g0 == 0) stage_store<N, P, +1>(x[0], u, set0, tw, s);
                 __syncthreads();
             }
-            if (g == 0) {
-                load_slots<N, P>(x, u, set0);
-                final_stage<N, P, +1>(x, u, tw.TF);
+            if (g0 == 0) {
+                load_slots<N, P>(x[0], u, set0);
+                final_stage<N, P, +1>(x[0], u, tw.TF);
             }
             __syncthreads();
-            if (g == 0) p2_hs_halo_publish<N, P, R2>(ab, u, x, set0);
+            if (g0 == 0) p2_hs_halo_publish<N, P, R2>(ab, u, x[0], set0);
             __syncthreads();
         }
-        if (g == R2 - 1) p2_hs_jacobian_lds<N, P, R2>(ab, tid, st, set0 + (R2 - 1) * G::BUFSTRIDE, set0);
+        MW_STAMP(1, 26);
+        if (g0 + (VT - 1) * (NT / T) == R2 - 1)  // the lane whose LAST virtual thread owns the block's last row
+            p2_hs_jacobian_lds<N, P, R2>(ab, MW_VTID(VT - 1), st[VT - 1], set0 + (R2 - 1) * G::BUFSTRIDE, set0);
+        MW_STAMP(1, 27);
     }
+#undef MW_VT
+#undef MW_VTID
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -343,7 +445,7 @@ static mw_status dmalloc(T** p, size_t count) {
 
 // host-side geometry mirror of FftGeom<N,P> / Plan<N>
 static int plan_points(int N, int pass) {
-    if (N >= 4096) return 16;
+    if (N >= 4096) return pass == 1 ? 16 : MW_PT2_4096;
     if (N == 2048) return pass == 1 ? 16 : MW_PT2_2048;
     return pass == 1 ? MW_PT1 : MW_PT2;
 }
@@ -410,41 +512,42 @@ static OceanConsts consts_of(const mw_ocean* o) {
 // ---- kernel dispatch over N ----------------------------------------------------------------------
 template <int N>
 static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nsteps, hipStream_t st) {
-    constexpr int P = Plan<N>::P1;
+    constexpr int P = Plan<N>::P1, VT = Plan<N>::VT1;
     static bool attr_done[64] = {false};  // per device: the attribute belongs to the function on the current device
     int dev = 0;
     hipGetDevice(&dev);
     if (!attr_done[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<N, P>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<N, P, VT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, P1Geom<N, P>::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
-    constexpr int NT = P1Geom<N, P>::NTHREADS, LB = P1Geom<N, P>::LDS_BYTES, GX = P1Geom<N, P>::GRID_X;
+    constexpr int NT = P1Geom<N, P>::NTHREADS / VT, LB = P1Geom<N, P>::LDS_BYTES, GX = P1Geom<N, P>::GRID_X;
     if (A.tgroup > 0)
-        k_pass1<N, P><<<dim3(p1_grid_blocks(GX, nsteps, A.tgroup)), dim3(NT), LB, st>>>(A, tm);
+        k_pass1<N, P, VT><<<dim3(p1_grid_blocks(GX, nsteps, A.tgroup)), dim3(NT), LB, st>>>(A, tm);
     else
-        k_pass1<N, P><<<dim3(GX, nsteps), dim3(NT), LB, st>>>(A, tm);
+        k_pass1<N, P, VT><<<dim3(GX, nsteps), dim3(NT), LB, st>>>(A, tm);
     return hipGetLastError();
 }
 template <int N>
 static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     constexpr int P = Plan<N>::P2, R2 = Plan<N>::R2;
     constexpr bool HS = Plan<N>::HS;
-    constexpr int NT = P2Geom<N, P, R2, HS>::NTHREADS, LB = P2Geom<N, P, R2, HS>::LDS_BYTES;
+    constexpr int VT = HS ? Plan<N>::VT : 1;
+    constexpr int NT = P2Geom<N, P, R2, HS>::NTHREADS / VT, LB = P2Geom<N, P, R2, HS>::LDS_BYTES;
     static bool attr_done[64] = {false};
     int dev = 0;
     hipGetDevice(&dev);
     if (!attr_done[dev & 63]) {
         const void* fn;
-        if constexpr (HS) fn = reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2>);
+        if constexpr (HS) fn = reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, VT>);
         else fn = reinterpret_cast<const void*>(&k_pass2<N, P, R2>);
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LB);
         if (e != hipSuccess) return e;
         attr_done[dev & 63] = true;
     }
     if constexpr (HS)
-        k_pass2_hs<N, P, R2><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
+        k_pass2_hs<N, P, R2, VT><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
     else
         k_pass2<N, P, R2><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
     return hipGetLastError();

@@ -308,7 +308,12 @@ struct Twiddles {
     const cf* TS[4];
     const cf* TF;
 };
-// one concatenated table [TS1 | TS2 | TS3 | TF] (device global memory; copied to LDS when it is small)
+// one concatenated table [TS1 | TS2 | TS3 | TF] (device global memory).  Its leading sub-tables are copied to LDS up to an
+// 8-KiB budget (`LDS_CF` entries: the whole table when it fits -- every N <= 1024 plan -- else the longest prefix of whole
+// sub-tables); the rest is read from global memory (L1/L2 hits).  Exception, `POW_STAGE`: the last radix-8 pass of a large
+// transform (N = 4096 with P = 8: 512 rows of 7 twiddles, 36 KiB) reads ONE twiddle per thread, w = e^{SGN 2 pi i k/P^(s+1)},
+// and forms w^2..w^7 by a product tree three multiplications deep: 2 VGPRs of loads in flight instead of 14, which is what
+// lets that kernel fit the 64-VGPR budget of two resident 1024-thread workgroups per CU.
 template <int N, int P>
 struct TwGeom {
     static constexpr int S = FftGeom<N, P>::S;
@@ -319,16 +324,31 @@ struct TwGeom {
     static constexpr int OFFF = OFF3 + size_ts(3);
     static constexpr int SIZE_TF = (FftGeom<N, P>::RL > 1) ? FftGeom<N, P>::T * FftGeom<N, P>::RL : 0;
     static constexpr int TOTAL = OFFF + SIZE_TF;
-    static constexpr bool IN_LDS = (TOTAL * 8 <= 8192);  // <= 8 KiB: staged in LDS, off the global-latency path
-    static MW_HD Twiddles view(const cf* base) {
+    static constexpr int LDS_BUDGET_CF = 1024;  // 8 KiB
+    static constexpr int LDS_CF = TOTAL <= LDS_BUDGET_CF ? TOTAL
+                                  : (OFFF <= LDS_BUDGET_CF ? OFFF : (OFF3 <= LDS_BUDGET_CF ? OFF3 : (OFF2 <= LDS_BUDGET_CF ? OFF2 : 0)));
+    static constexpr bool IN_LDS = (LDS_CF == TOTAL);  // the whole table is staged
+    static constexpr int off_ts(int s) { return s == 1 ? OFF1 : (s == 2 ? OFF2 : OFF3); }
+#ifndef MW_POW_MIN_P
+#define MW_POW_MIN_P 8
+#endif
+#ifndef MW_POW_MAX_P
+#define MW_POW_MAX_P 16
+#endif
+    static constexpr int POW_STAGE =
+        (P >= MW_POW_MIN_P && P <= MW_POW_MAX_P && S >= 2 && off_ts(S - 1) >= LDS_CF && size_ts(S - 1) > LDS_BUDGET_CF) ? S - 1 : 0;
+    // sub-table at offset `off`: the LDS copy when it was staged, else global memory
+    static MW_HD const cf* pick(const cf* glob, const cf* lds, int off) { return off < LDS_CF ? lds + off : glob + off; }
+    static MW_HD Twiddles view(const cf* glob, const cf* lds) {
         Twiddles t;
         t.TS[0] = nullptr;
-        t.TS[1] = base + OFF1;
-        t.TS[2] = base + OFF2;
-        t.TS[3] = base + OFF3;
-        t.TF = base + OFFF;
+        t.TS[1] = pick(glob, lds, OFF1);
+        t.TS[2] = pick(glob, lds, OFF2);
+        t.TS[3] = pick(glob, lds, OFF3);
+        t.TF = pick(glob, lds, OFFF);
         return t;
     }
+    static MW_HD Twiddles view(const cf* base) { return view(base, base); }  // host emulation: one flat table
 };
 
 // LDS indices are written as (per-thread base) + (compile-time constant) so that every ds_read / ds_write
@@ -361,25 +381,29 @@ MW_HD void load_slots(cf (&x)[P], int u, const cf* buf) {
     }
 }
 // radix-P pass s (1 <= s < S): p = P^s
-template <int N, int P, int SGN>
+// ALLOW_POW = false keeps the table in every pass (the OceanRenderer kernels: their finite-difference normal amplifies
+// transform rounding at ill-conditioned texels, and a frame is latency- not throughput-bound anyway)
+template <int N, int P, int SGN, bool ALLOW_POW = true>
 MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
     const int p = 1 << (LogP<P>::v * s);
     const int k = u & (p - 1);
     const cf* __restrict__ row = tw.TS[s] + k * (P + 1);
 #ifdef MW_TW_POWERS
-    {   // experiment: one table read per thread and pass, the other P-2 twiddles as its powers (binary tree: <= log2 P
-        // multiplications deep)
+    constexpr bool POWERS = true;  // experiment: every pass by powers (+1 % step time at 1024^2: 24 VALU for 6 saved reads)
+#else
+    const bool POWERS = (ALLOW_POW && TwGeom<N, P>::POW_STAGE != 0 && s == TwGeom<N, P>::POW_STAGE);  // folds: s is unrolled
+#endif
+    if (POWERS) {  // one table read per thread, the other P-2 twiddles as its powers (product tree <= log2 P deep)
         cf w[P];
         w[1] = row[1];
 #pragma unroll
         for (int r = 2; r < P; r++) w[r] = cmul(w[r / 2], w[r - r / 2]);
 #pragma unroll
         for (int r = 1; r < P; r++) x[r] = cmul(x[r], w[r]);
-    }
-#else
+    } else {
 #pragma unroll
-    for (int r = 1; r < P; r++) x[r] = cmul(x[r], row[r]);
-#endif
+        for (int r = 1; r < P; r++) x[r] = cmul(x[r], row[r]);
+    }
     DftP<P, SGN>::run(x);
     const int j = ((u - k) << LogP<P>::v) + k;
 #ifdef MW_ABLATE_LDS

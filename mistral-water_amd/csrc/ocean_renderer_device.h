@@ -68,9 +68,8 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Arg
     constexpr int T = FftGeom<N, P>::T;
     const int tid = threadIdx.x, jb = blockIdx.x, f = blockIdx.y;  // one field per block
     const int w = tid / T, u = tid % T;
-    if (TwGeom<N, P>::IN_LDS)
-        for (int i = tid; i < TwGeom<N, P>::TOTAL; i += G::NTHREADS) lds[i] = A.TW[i];
-    const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
+    for (int i = tid; i < TwGeom<N, P>::LDS_CF; i += G::NTHREADS) lds[i] = A.TW[i];
+    const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     cf h[P], x[P];
     or_p1_animate<N, P>(A, jb, tid, f == 0, h);
@@ -82,7 +81,7 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Arg
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
             load_slots<N, P>(x, u, set0 + w * G::BUFSTRIDE);
             __syncthreads();
-            stage_store<N, P, -1>(x, u, set0 + w * G::BUFSTRIDE, tw, s);
+            stage_store<N, P, -1, false>(x, u, set0 + w * G::BUFSTRIDE, tw, s);
             __syncthreads();
         }
         or_p1_finish<N, P>(A, tw, jb, tid, f, x, set0);
@@ -96,9 +95,8 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = FftGeom<N, P>::T;
     const int tid = threadIdx.x, ab = blockIdx.x;
-    if (TwGeom<N, P>::IN_LDS)
-        for (int i = tid; i < TwGeom<N, P>::TOTAL; i += G::NTHREADS) lds[i] = A.TW[i];
-    const Twiddles tw = TwGeom<N, P>::view(TwGeom<N, P>::IN_LDS ? lds : A.TW);
+    for (int i = tid; i < TwGeom<N, P>::LDS_CF; i += G::NTHREADS) lds[i] = A.TW[i];
+    const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     cf x[P];
     float dx[P];
@@ -113,7 +111,7 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
             load_slots<N, P>(x, tid >> 2, set0 + (tid & 3) * G::BUFSTRIDE);
             __syncthreads();
-            stage_store<N, P, -1>(x, tid >> 2, set0 + (tid & 3) * G::BUFSTRIDE, tw, s);
+            stage_store<N, P, -1, false>(x, tid >> 2, set0 + (tid & 3) * G::BUFSTRIDE, tw, s);
             __syncthreads();
         }
         or_p2_finish<N, P>(A, tw, ab, tid, f, x, dx, set0);

@@ -101,7 +101,7 @@ struct OrP1Geom {
     static constexpr int T = FftGeom<N, P>::T;
     static constexpr int NTHREADS = 4 * T;
     static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4;
-    static constexpr int TW_LDS = TwGeom<N, P>::IN_LDS ? ((TwGeom<N, P>::TOTAL + 1) & ~1) : 0;
+    static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;
     static constexpr int LDS_BYTES = (TW_LDS + 4 * BUFSTRIDE) * (int)sizeof(cf);
 };
 // Dispersion + h~ for the 4 texel columns px = 4 jb .. 4 jb + 3 (transform index = py = u + T q)
@@ -164,7 +164,7 @@ struct OrP2Geom {
     static constexpr int R2 = 4;
     static constexpr int NTHREADS = R2 * T;
     static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4;
-    static constexpr int TW_LDS = TwGeom<N, P>::IN_LDS ? ((TwGeom<N, P>::TOTAL + 1) & ~1) : 0;
+    static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;
     static constexpr int LDS_BYTES = (TW_LDS + R2 * BUFSTRIDE) * (int)sizeof(cf);
 };
 MW_HD int or_p2_field(int k) { return k == 0 ? 1 : (k == 1 ? 2 : 0); }  // hx, hz, h

@@ -251,7 +251,7 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
                 }
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
                     for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
-                    for (int tid = 0; tid < NT; tid++) stage_store<N, P, -1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, tw, s);
+                    for (int tid = 0; tid < NT; tid++) stage_store<N, P, -1, false>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, tw, s);
                 }
                 for (int tid = 0; tid < NT; tid++) or_p1_finish<N, P>(A, tw, jb, tid, f, st[tid].x, lds.data());
             }
@@ -271,7 +271,7 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
                 for (int tid = 0; tid < NT; tid++) or_p2_load<N, P>(A, ab, tid, f, st[tid].x, lds.data());
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
                     for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid >> 2, lds.data() + (tid & 3) * BS);
-                    for (int tid = 0; tid < NT; tid++) stage_store<N, P, -1>(st[tid].x, tid >> 2, lds.data() + (tid & 3) * BS, tw, s);
+                    for (int tid = 0; tid < NT; tid++) stage_store<N, P, -1, false>(st[tid].x, tid >> 2, lds.data() + (tid & 3) * BS, tw, s);
                 }
                 for (int tid = 0; tid < NT; tid++) or_p2_finish<N, P>(A, tw, ab, tid, f, st[tid].x, st[tid].dx, lds.data());
             }
