@@ -785,6 +785,21 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 #ifndef MW_VT_2048
 #define MW_VT_2048 2
 #endif
+#ifndef MW_R2_1024
+#define MW_R2_1024 4
+#endif
+// 1024^2 (A/B at steady clocks, pass 2 per 32 steps): 4 rows + halo group at 8 points per thread 336 us; sequential halo at
+// 16 points per thread, one wave per row, 325-327 us either as 4-wave workgroups or as 2-wave workgroups of 2 virtual
+// threads per lane (kept: with the early halo fetch it reads 21.3 instead of 24.2 B per grid point)
+#ifndef MW_PT2_1024
+#define MW_PT2_1024 16
+#endif
+#ifndef MW_HS_1024
+#define MW_HS_1024 1
+#endif
+#ifndef MW_VT_1024
+#define MW_VT_1024 2
+#endif
 #ifndef MW_VT1_4096
 #define MW_VT1_4096 1
 #endif
@@ -797,11 +812,11 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 template <int N> struct Plan {
     static constexpr int P = (N >= 2048) ? 16 : MW_PT;    // OceanRenderer passes
     static constexpr int P1 = (N >= 2048) ? 16 : MW_PT1;  // 5 x N/8 threads would exceed 1024 at N = 2048
-    static constexpr int P2 = (N >= 4096) ? MW_PT2_4096 : (N == 2048 ? MW_PT2_2048 : MW_PT2);
-    static constexpr bool HS = (N >= 4096) ? (MW_HS_4096 != 0) : (N == 2048 ? (MW_HS_2048 != 0) : false);
-    static constexpr int R2 = (N >= 4096) ? MW_R2_4096 : (N == 2048 ? MW_R2_2048 : ((N <= MW_R2_SMALL_N) ? 8 : 4));
+    static constexpr int P2 = (N >= 4096) ? MW_PT2_4096 : (N == 2048 ? MW_PT2_2048 : (N == 1024 ? MW_PT2_1024 : MW_PT2));
+    static constexpr bool HS = (N >= 4096) ? (MW_HS_4096 != 0) : (N == 2048 ? (MW_HS_2048 != 0) : (N == 1024 ? (MW_HS_1024 != 0) : false));
+    static constexpr int R2 = (N >= 4096) ? MW_R2_4096 : (N == 2048 ? MW_R2_2048 : (N == 1024 ? MW_R2_1024 : ((N <= MW_R2_SMALL_N) ? 8 : 4)));
     // virtual threads per lane of the sequential-halo kernel (k_pass2_hs): 2 = 8 fat waves with a 256-VGPR budget
-    static constexpr int VT = (N >= 4096) ? MW_VT_4096 : MW_VT_2048;
+    static constexpr int VT = (N >= 4096) ? MW_VT_4096 : (N == 2048 ? MW_VT_2048 : MW_VT_1024);
     static constexpr int VT1 = (N >= 4096) ? MW_VT1_4096 : (N == 2048 ? MW_VT1_2048 : 1);  // the same for pass 1
 };
 

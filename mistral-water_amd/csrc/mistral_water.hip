@@ -325,7 +325,8 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
         // The halo row's lines are the next row block's own lines: fetched NOW, while that block (same XCD, same phase)
         // loads them too, they are L2 hits; fetched two phases later they have left the L2 and cost a second 128-B fill
         // per 32-B piece (measured +6 B per grid point).  Needs 2P spare VGPRs across the displacement transform: VT >= 2.
-        if (HALO_EARLY && f == 1 && g0 == 0 && ab * R2 + R2 < N) p2_hs_halo_fetch<N, P, R2>(A, ab, step, mw_fresh(tid0) % T, xh);
+        if constexpr (HALO_EARLY)
+            if (f == 1 && g0 == 0 && ab * R2 + R2 < N) p2_hs_halo_fetch<N, P, R2>(A, ab, step, mw_fresh(tid0) % T, xh);
         MW_STAMP(1, 2 + 8 * k);
         __syncthreads();
 #pragma unroll
@@ -375,7 +376,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
         if (has_halo) {  // group 0 = virtual thread 0 of the lanes below T
             const int u = mw_fresh(tid0) % T;
             if (g0 == 0) {
-                if (HALO_EARLY) {
+                if constexpr (HALO_EARLY) {
 #pragma unroll
                     for (int q = 0; q < P; q++) x[0][q] = xh[q];
                 } else {
@@ -445,9 +446,12 @@ static mw_status dmalloc(T** p, size_t count) {
 
 // host-side geometry mirror of FftGeom<N,P> / Plan<N>
 static int plan_points(int N, int pass) {
-    if (N >= 4096) return pass == 1 ? 16 : MW_PT2_4096;
-    if (N == 2048) return pass == 1 ? 16 : MW_PT2_2048;
-    return pass == 1 ? MW_PT1 : MW_PT2;
+    switch (N) {
+#define MW_PLAN_CASE(NN) case NN: return pass == 1 ? Plan<NN>::P1 : Plan<NN>::P2;
+        MW_PLAN_CASE(64) MW_PLAN_CASE(128) MW_PLAN_CASE(256) MW_PLAN_CASE(512) MW_PLAN_CASE(1024) MW_PLAN_CASE(2048) MW_PLAN_CASE(4096)
+#undef MW_PLAN_CASE
+        default: return 16;
+    }
 }
 
 // concatenated twiddle table [TS1 | TS2 | TS3 | TF] in the layout of TwGeom<N,P>

@@ -161,12 +161,13 @@ void run_pass2_hs(const P2Args& A, int nsteps) {
             }
 }
 
-template <int N, int P>
+// PA / PB: points per thread of pass 1 / pass 2 (the exchange-buffer layout does not depend on them)
+template <int N, int PA, int PB>
 int evaluate_np(const OceanConsts& C, const cf* h0, const cf* h0c, const float* times, int nsteps, float* vertices,
                 float* normals, float* white, int white_stride) {
     constexpr int R2 = Plan<N>::R2;
     const bool hs = g_force_hs || Plan<N>::HS;
-    Tables tb(N, P);
+    Tables tb(N, PA), tb2(N, PB);
     std::vector<f4> PQt((size_t)N * N), d_i0(N), d_j0(N);
     std::vector<float> Om((size_t)N * N);
     for (int i = 0; i < N; i++)
@@ -178,26 +179,28 @@ int evaluate_np(const OceanConsts& C, const cf* h0, const cf* h0c, const float* 
     A1.Cj0 = Cj0.data(); A1.E = E.data(); A1.c = C;
     StepTimes tm;
     for (int k = 0; k < nsteps; k++) tm.t[k] = times[k];
-    run_pass1<N, P>(A1, tm, nsteps);
+    run_pass1<N, PA>(A1, tm, nsteps);
     P2Args A2;
-    A2.E = E.data(); A2.Cj0 = Cj0.data(); A2.TW = tb.TW.data(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
+    A2.E = E.data(); A2.Cj0 = Cj0.data(); A2.TW = tb2.TW.data(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
     A2.white_stride = white_stride; A2.c = C;
     if (hs) {
-        run_pass2_hs<N, P, 4>(A2, nsteps);
+        run_pass2_hs<N, PB, R2>(A2, nsteps);
     } else {
-        if constexpr (!Plan<N>::HS) run_pass2<N, P, R2>(A2, nsteps);
+        if constexpr ((R2 + 1) * (N / PB) <= 1024) run_pass2<N, PB, R2>(A2, nsteps);  // the halo-group kernel exists for this plan
+        else return 4;
     }
     return 0;
 }
 
-// pts = 0: the product's plan (Plan<N>::P); 8 / 16: force that variant where the geometry allows it
+// pts = 0: the product's plan (Plan<N>::P1 for pass 1, Plan<N>::P2 for pass 2); 8 / 16: both passes with that many points
+// per thread where the geometry allows it
 template <int N>
 int evaluate_n(int pts, const OceanConsts& C, const cf* h0, const cf* h0c, const float* times, int nsteps, float* vertices,
                float* normals, float* white, int white_stride) {
-    if (pts == 0) pts = Plan<N>::P;
-    if (pts == 16) return evaluate_np<N, 16>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
+    if (pts == 0) return evaluate_np<N, Plan<N>::P1, Plan<N>::P2>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
+    if (pts == 16) return evaluate_np<N, 16, 16>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
     if constexpr (N <= 1024) {
-        if (pts == 8) return evaluate_np<N, 8>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
+        if (pts == 8) return evaluate_np<N, 8, 8>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
     }
     return 3;
 }
