@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MW_ABI_VERSION 1
+#define MW_ABI_VERSION 2
 
 typedef struct mw_ocean mw_ocean; /* opaque; one per FFTMesh / OceanRenderer instance */
 
@@ -79,9 +79,12 @@ void mw_params_default(mw_params* p, int32_t semantics); /* Inspector defaults o
 mw_status mw_ocean_create(const mw_params* params, mw_ocean** out);
 void mw_ocean_destroy(mw_ocean* o);
 
-/* Run all subsequent work of this handle on an existing hipStream_t (e.g. torch's current stream).
- * NULL = the library's own stream (default).                                                       */
+/* Run all subsequent work of this handle on an existing hipStream_t (e.g. torch's current stream).  The argument means
+ * what it says: NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is by default), as in
+ * the pond entry points.  A fresh handle runs on its own private non-blocking stream; mw_ocean_use_own_stream returns to
+ * it.  Work already enqueued on the previous stream is waited for before the switch.                                */
 mw_status mw_ocean_set_stream(mw_ocean* o, void* hip_stream);
+mw_status mw_ocean_use_own_stream(mw_ocean* o);
 void* mw_ocean_get_stream(mw_ocean* o);
 mw_status mw_ocean_synchronize(mw_ocean* o);
 
@@ -96,6 +99,24 @@ mw_status mw_ocean_set_choppiness(mw_ocean* o, float choppiness);
  * each with texel (px,py) at index py*M + px; setting it restarts the phase at 0.                              */
 mw_status mw_ocean_set_spectrum(mw_ocean* o, const float* h0_xy, const float* h0conj_xy);
 mw_status mw_ocean_get_spectrum(mw_ocean* o, float* h0_xy, float* h0conj_xy);
+
+/* Regenerate the initial spectrum IN PLACE from new (length, wind, amplitude, seed); everything else of the handle stays.
+ *  OceanRenderer semantics = the parameter-change branch of Update (S/OceanRenderer.cs:98-109): RenderInitial() draws
+ *    initialTexture again (pass the handle's own seed: the reference keeps _RandomSeed1/2); the stateful phase textures are
+ *    NOT touched, so the animation continues; dispersion and spectrum passes use the new length from the next frame on
+ *    (:94-97), while the normal pass keeps the length it was created with -- the reference sets normalMat's _Length only in
+ *    SetParams (:163) and never again.
+ *  FFTMesh semantics = the spectrum fill of GenerateMesh (S/FFTMesh.cs:114-116) with a new seed (the `generate` tick
+ *    draws fresh UnityEngine.Random values, :62-68); the timer is not touched (mw_ocean_reset_timer does that).  The grid
+ *    must stay on the same evaluation path: MW_ESTATE if the new length flips unit_width == length / N.              */
+mw_status mw_ocean_reinit_spectrum(mw_ocean* o, float length, float wind_x, float wind_y, float amplitude, uint64_t seed);
+
+/* Save / restore the animation state.  OceanRenderer: the current phase texture (F/Dispersion.shader:32-41), M*M floats,
+ * texel (px,py) at py*M + px -- with initialTexture (mw_ocean_get_spectrum) this is everything a checkpoint needs.
+ * FFTMesh: the timer (mw_ocean_timer / mw_ocean_set_timer); get/set_phase return MW_ESTATE there.                    */
+mw_status mw_ocean_get_phase(mw_ocean* o, float* phase);
+mw_status mw_ocean_set_phase(mw_ocean* o, const float* phase);
+mw_status mw_ocean_set_timer(mw_ocean* o, float timer);
 
 /* GenerateMesh outputs (S/FFTMesh.cs:101-139, S/OceanRenderer.cs:172-207): rest vertices [N*N*3],
  * normals [N*N*3], uvs [N*N*2], triangle indices [(N-1)^2*6].  Any pointer may be NULL.            */
@@ -159,6 +180,37 @@ mw_status mw_ocean_generate_texture_rgba_device(mw_ocean* o, float delta_time, v
  * normals/colors may be NULL.  MW_ESTATE before the first GenerateTexture().                                      */
 mw_status mw_ocean_displace_mesh(mw_ocean* o, float* vertices_xyz, float* normals_xyz, float* colors);
 mw_status mw_ocean_displace_mesh_device(mw_ocean* o, void* d_vertices_xyz, void* d_normals_xyz, void* d_colors);
+
+/* ---- independent tiles on several devices (BASELINE configs[2]) ------------------------------------
+ * FFTMesh-semantics tiles are independent units: tile k is the ocean of `params` with seed params->seed + k on its own
+ * device, compute stream and output buffers; there is no data-path collective.  The only exchange is the optional gather
+ * of finished outputs to one root device over RCCL (xGMI), issued on per-device SIDE streams behind an event recorded on
+ * the compute streams -- once per batch, never per step (29.4 MB per 1024^2 tile ~ 190 us on one 153 GB/s link).
+ *   single process : mw_tiles_create -- one RCCL rank per distinct device (ncclCommInitAll, rccl.h:236); tiles that share
+ *                    a device share its rank.  devices == NULL places tile k on device k % mw_device_count().
+ *   one process per GPU (the torch.distributed.run launch of bench.py): rank 0 calls mw_comm_unique_id, the launcher
+ *                    broadcasts the 128 bytes, every rank calls mw_tiles_create_rank (ncclCommInitRank, rccl.h:220) and
+ *                    owns exactly one tile; mw_tiles_gather is then collective over the ranks.
+ * RCCL is loaded with dlopen on first use (no link-time dependency); MW_EDEVICE when it is absent.                     */
+typedef struct mw_tiles mw_tiles;
+#define MW_COMM_ID_BYTES 128
+mw_status mw_comm_unique_id(void* id_out); /* MW_COMM_ID_BYTES bytes (ncclGetUniqueId) */
+mw_status mw_tiles_create(const mw_params* params, int32_t ntiles, const int32_t* devices, int32_t max_steps, mw_tiles** out);
+mw_status mw_tiles_create_rank(const mw_params* params, int32_t device, int32_t max_steps, const void* comm_id, int32_t rank,
+                               int32_t nranks, mw_tiles** out);
+void mw_tiles_destroy(mw_tiles* t);
+int32_t mw_tiles_count(const mw_tiles* t);       /* tiles in the whole job (= nranks in the per-process form) */
+int32_t mw_tiles_local_count(const mw_tiles* t); /* tiles this process owns */
+mw_ocean* mw_tiles_ocean(mw_tiles* t, int32_t local_k); /* borrowed handle of a local tile (set_spectrum, set_choppiness, ...) */
+/* nsteps <= max_steps time-steps t[0..nsteps) on every local tile (mw_ocean_evaluate_device per tile, asynchronous) */
+mw_status mw_tiles_evaluate(mw_tiles* t, const float* times, int32_t nsteps, uint32_t flags);
+/* device pointers of local tile k's outputs: [max_steps][N*N*3], [max_steps][N*N*3], [max_steps][N*N*(1|4)] */
+mw_status mw_tiles_outputs(mw_tiles* t, int32_t local_k, void** d_vertices, void** d_normals, void** d_white);
+/* Collect step `step` of EVERY tile on the device of tile `root` (global tile index): asynchronous, on the side streams.
+ * mw_tiles_gathered: the root's buffer [ntiles][N*N*3 | N*N*3 | N*N*w] floats (NULL on processes that do not own root). */
+mw_status mw_tiles_gather(mw_tiles* t, int32_t step, int32_t root);
+mw_status mw_tiles_gathered(mw_tiles* t, void** d_gathered, int64_t* floats_per_tile);
+mw_status mw_tiles_synchronize(mw_tiles* t); /* compute and side streams of every local tile */
 
 /* ---- measurement hook (bench.py): times each kernel of one FFTMesh step with hipEvents on the
  * handle's stream.  ms_out[k] = mean duration of kernel k over iters launches of `nsteps` batched

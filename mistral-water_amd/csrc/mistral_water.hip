@@ -4,10 +4,14 @@
 // /oracle and is never linked here.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -149,9 +153,14 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
 #pragma unroll
             MW_VT(h) load_slots<N, P>(x[h], MW_U(h), MW_BUF(h));
+            if (s == 1) MW_STAMP(0, 4 + 8 * f);
+#ifndef MW_ABLATE_WAR  // timing experiment (wrong results): no write-after-read barrier (4096^2: pass 1 -2 %)
             if (G::NBUF == 1) __syncthreads(); else cur ^= 1;
+#endif
+            if (s == 1) MW_STAMP(0, 5 + 8 * f);
 #pragma unroll
             MW_VT(h) stage_store<N, P, +1>(x[h], MW_U(h), MW_BUF(h), tw, s);
+            if (s == 1) MW_STAMP(0, 6 + 8 * f);
             __syncthreads();
         }
         MW_STAMP(0, 7 + 8 * f);
@@ -431,6 +440,8 @@ struct mw_ocean {
     cf *E = nullptr, *Cj0 = nullptr;
     int e_cap = 0;  // steps the exchange buffer holds
     float *s_vert = nullptr, *s_norm = nullptr, *s_white = nullptr;  // 1-step scratch for the host API
+    void* scratch = nullptr;  // grow-only device staging of the host-pointer entry points (rest mesh, RGBA targets, ...):
+    size_t scratch_cap = 0;   // allocated once at the largest size asked for, not per call
     DirectState direct;
     // OceanRenderer state
     OrState orr;
@@ -443,6 +454,23 @@ static mw_status dmalloc(T** p, size_t count) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
     return MW_OK;
 }
+
+// device staging for the host-pointer entry points: one grow-only buffer per handle
+static mw_status scratch_reserve(mw_ocean* o, size_t bytes, void** out) {
+    if (o->scratch_cap < bytes) {
+        if (o->scratch) {
+            HIP_TRY(hipStreamSynchronize(o->stream));
+            HIP_TRY(hipFree(o->scratch));
+            o->scratch = nullptr;
+            o->scratch_cap = 0;
+        }
+        if (hipMalloc(&o->scratch, bytes) != hipSuccess) return fail(MW_ENOMEM, "hipMalloc of the host-API staging buffer failed");
+        o->scratch_cap = bytes;
+    }
+    *out = o->scratch;
+    return MW_OK;
+}
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // host-side geometry mirror of FftGeom<N,P> / Plan<N>
 static int plan_points(int N, int pass) {
@@ -517,14 +545,10 @@ static OceanConsts consts_of(const mw_ocean* o) {
 template <int N>
 static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nsteps, hipStream_t st) {
     constexpr int P = Plan<N>::P1, VT = Plan<N>::VT1;
-    static bool attr_done[64] = {false};  // per device: the attribute belongs to the function on the current device
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (!attr_done[dev & 63]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<N, P, VT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, P1Geom<N, P>::LDS_BYTES);
+    static AttrOnce attr;  // per device: the attribute belongs to the function on the current device
+    {
+        hipError_t e = attr.set(reinterpret_cast<const void*>(&k_pass1<N, P, VT>), P1Geom<N, P>::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_done[dev & 63] = true;
     }
     constexpr int NT = P1Geom<N, P>::NTHREADS / VT, LB = P1Geom<N, P>::LDS_BYTES, GX = P1Geom<N, P>::GRID_X;
     if (A.tgroup > 0)
@@ -539,16 +563,13 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     constexpr bool HS = Plan<N>::HS;
     constexpr int VT = HS ? Plan<N>::VT : 1;
     constexpr int NT = P2Geom<N, P, R2, HS>::NTHREADS / VT, LB = P2Geom<N, P, R2, HS>::LDS_BYTES;
-    static bool attr_done[64] = {false};
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (!attr_done[dev & 63]) {
+    static AttrOnce attr;
+    {
         const void* fn;
         if constexpr (HS) fn = reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, VT>);
         else fn = reinterpret_cast<const void*>(&k_pass2<N, P, R2>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LB);
+        hipError_t e = attr.set(fn, LB);
         if (e != hipSuccess) return e;
-        attr_done[dev & 63] = true;
     }
     if constexpr (HS)
         k_pass2_hs<N, P, R2, VT><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
@@ -663,9 +684,9 @@ void mw_params_default(mw_params* p, int32_t semantics) {
 void mw_ocean_destroy(mw_ocean* o) {
     if (!o) return;
     hipSetDevice(o->device);
-    if (o->stream) hipStreamSynchronize(o->stream);
+    hipStreamSynchronize(o->stream);
     hipFree(o->h0); hipFree(o->h0c); hipFree(o->PQt); hipFree(o->Om); hipFree(o->dPQ_i0); hipFree(o->dPQ_j0);
-    hipFree(o->TW); hipFree(o->TW2); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white);
+    hipFree(o->TW); hipFree(o->TW2); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white); hipFree(o->scratch);
     direct_free(o->direct);
     or_free(o->orr);
     if (o->own_stream) hipStreamDestroy(o->own_stream);
@@ -746,7 +767,14 @@ mw_status mw_ocean_set_stream(mw_ocean* o, void* hip_stream) {
     if (!o) return fail(MW_EINVAL, "NULL handle");
     HIP_TRY(hipSetDevice(o->device));
     HIP_TRY(hipStreamSynchronize(o->stream));
-    o->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : o->own_stream;
+    o->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = HIP's legacy default stream, like the pond entry points
+    return MW_OK;
+}
+mw_status mw_ocean_use_own_stream(mw_ocean* o) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    HIP_TRY(hipSetDevice(o->device));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    o->stream = o->own_stream;
     return MW_OK;
 }
 void* mw_ocean_get_stream(mw_ocean* o) { return o ? reinterpret_cast<void*>(o->stream) : nullptr; }
@@ -781,16 +809,17 @@ mw_status mw_ocean_set_spectrum(mw_ocean* o, const float* h0_xy, const float* h0
     HIP_TRY(hipSetDevice(o->device));
     const size_t bytes = sizeof(cf) * (size_t)o->N * o->N;
     if (o->sem == MW_SEM_OCEANRENDERER) {  // initialTexture.rg / .ba, texel (px,py) at py*M + px
-        cf *a = nullptr, *b = nullptr;
-        HIP_TRY(hipMalloc((void**)&a, bytes));
-        if (hipMalloc((void**)&b, bytes) != hipSuccess) { hipFree(a); return fail(MW_ENOMEM, "hipMalloc failed"); }
-        hipMemcpyAsync(a, h0_xy, bytes, hipMemcpyHostToDevice, o->stream);
-        hipMemcpyAsync(b, h0conj_xy, bytes, hipMemcpyHostToDevice, o->stream);
+        void* buf = nullptr;
+        mw_status s = scratch_reserve(o, 2 * align256(bytes), &buf);
+        if (s != MW_OK) return s;
+        cf *a = static_cast<cf*>(buf), *b = reinterpret_cast<cf*>(static_cast<char*>(buf) + align256(bytes));
+        HIP_TRY(hipMemcpyAsync(a, h0_xy, bytes, hipMemcpyHostToDevice, o->stream));
+        HIP_TRY(hipMemcpyAsync(b, h0conj_xy, bytes, hipMemcpyHostToDevice, o->stream));
         k_or_set_init<<<dim3((unsigned)(((size_t)o->N * o->N + 255) / 256)), dim3(256), 0, o->stream>>>(o->N, a, b, o->orr.initT,
                                                                                                    o->orr.phaseT);
-        hipError_t e = hipStreamSynchronize(o->stream);
-        hipFree(a); hipFree(b);
-        return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, "set_spectrum (OceanRenderer) failed");
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(o->stream));
+        return MW_OK;
     }
     HIP_TRY(hipMemcpyAsync(o->h0, h0_xy, bytes, hipMemcpyHostToDevice, o->stream));
     HIP_TRY(hipMemcpyAsync(o->h0c, h0conj_xy, bytes, hipMemcpyHostToDevice, o->stream));
@@ -804,15 +833,16 @@ mw_status mw_ocean_get_spectrum(mw_ocean* o, float* h0_xy, float* h0conj_xy) {
     HIP_TRY(hipSetDevice(o->device));
     const size_t bytes = sizeof(cf) * (size_t)o->N * o->N;
     if (o->sem == MW_SEM_OCEANRENDERER) {
-        cf *a = nullptr, *b = nullptr;
-        HIP_TRY(hipMalloc((void**)&a, bytes));
-        if (hipMalloc((void**)&b, bytes) != hipSuccess) { hipFree(a); return fail(MW_ENOMEM, "hipMalloc failed"); }
+        void* buf = nullptr;
+        mw_status s = scratch_reserve(o, 2 * align256(bytes), &buf);
+        if (s != MW_OK) return s;
+        cf *a = static_cast<cf*>(buf), *b = reinterpret_cast<cf*>(static_cast<char*>(buf) + align256(bytes));
         k_or_get_init<<<dim3((unsigned)(((size_t)o->N * o->N + 255) / 256)), dim3(256), 0, o->stream>>>(o->N, o->orr.initT, a, b);
-        hipMemcpyAsync(h0_xy, a, bytes, hipMemcpyDeviceToHost, o->stream);
-        hipMemcpyAsync(h0conj_xy, b, bytes, hipMemcpyDeviceToHost, o->stream);
-        hipError_t e = hipStreamSynchronize(o->stream);
-        hipFree(a); hipFree(b);
-        return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, "get_spectrum (OceanRenderer) failed");
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h0_xy, a, bytes, hipMemcpyDeviceToHost, o->stream));
+        HIP_TRY(hipMemcpyAsync(h0conj_xy, b, bytes, hipMemcpyDeviceToHost, o->stream));
+        HIP_TRY(hipStreamSynchronize(o->stream));
+        return MW_OK;
     }
     HIP_TRY(hipMemcpyAsync(h0_xy, o->h0, bytes, hipMemcpyDeviceToHost, o->stream));
     HIP_TRY(hipMemcpyAsync(h0conj_xy, o->h0c, bytes, hipMemcpyDeviceToHost, o->stream));
@@ -820,30 +850,86 @@ mw_status mw_ocean_get_spectrum(mw_ocean* o, float* h0_xy, float* h0conj_xy) {
     return MW_OK;
 }
 
+mw_status mw_ocean_reinit_spectrum(mw_ocean* o, float length, float wind_x, float wind_y, float amplitude, uint64_t seed) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    if (!(length > 0.f)) return fail(MW_EINVAL, "mw_ocean_reinit_spectrum: length must be positive");
+    HIP_TRY(hipSetDevice(o->device));
+    if (o->sem == MW_SEM_OCEANRENDERER) {  // S/OceanRenderer.cs:98-109: RenderInitial() again, phase textures untouched
+        mw_status s = or_reinit(o->orr, length, wind_x, wind_y, amplitude, seed, o->stream);
+        if (s != MW_OK) return fail(s, or_last_error());
+    } else {
+        const int N = o->N;
+        const bool fft = is_pow2(N) && N >= 64 && (o->p.unit_width * (float)N == length);
+        if (fft != o->use_fft)
+            return fail(MW_ESTATE, "mw_ocean_reinit_spectrum: the new length moves the grid between the FFT and the direct-sum path; "
+                                   "create a new handle");
+        const size_t NN = (size_t)N * N;
+        hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, o->stream, N, length, wind_x, wind_y,
+                           amplitude, o->p.gravity, seed, o->h0, o->h0c);
+        HIP_TRY(hipGetLastError());
+        const float old_length = o->p.length;
+        o->p.length = length;  // run_prep reads it (omega table, S/FFTMesh.cs:141-147)
+        mw_status s = run_prep(o);
+        if (s != MW_OK) { o->p.length = old_length; return s; }
+    }
+    o->p.length = length; o->p.wind_x = wind_x; o->p.wind_y = wind_y; o->p.amplitude = amplitude; o->p.seed = seed;
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
+}
+
+static mw_status phase_copy(mw_ocean* o, float* host_out, const float* host_in, const char* who) {
+    if (!o || (!host_out && !host_in)) return fail(MW_EINVAL, std::string(who) + ": NULL argument");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, std::string(who) + ": OceanRenderer semantics only (FFTMesh state is the timer)");
+    HIP_TRY(hipSetDevice(o->device));
+    const size_t MM = (size_t)o->N * o->N, bytes = MM * sizeof(float);
+    void* buf = nullptr;
+    mw_status s = scratch_reserve(o, bytes, &buf);
+    if (s != MW_OK) return s;
+    float* tmp = static_cast<float*>(buf);
+    const dim3 grid((unsigned)((MM + 255) / 256)), block(256);
+    if (host_out) {  // device [px][py] -> host texel order py*M + px
+        k_or_phase_transpose<<<grid, block, 0, o->stream>>>(o->N, o->orr.phaseT, tmp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host_out, tmp, bytes, hipMemcpyDeviceToHost, o->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(tmp, host_in, bytes, hipMemcpyHostToDevice, o->stream));
+        k_or_phase_transpose<<<grid, block, 0, o->stream>>>(o->N, tmp, o->orr.phaseT);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
+}
+mw_status mw_ocean_get_phase(mw_ocean* o, float* phase) { return phase_copy(o, phase, nullptr, "mw_ocean_get_phase"); }
+mw_status mw_ocean_set_phase(mw_ocean* o, const float* phase) { return phase_copy(o, nullptr, phase, "mw_ocean_set_phase"); }
+mw_status mw_ocean_set_timer(mw_ocean* o, float timer) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    o->timer = timer;
+    return MW_OK;
+}
+
 mw_status mw_ocean_rest_mesh(mw_ocean* o, float* vertices_xyz, float* normals_xyz, float* uvs_xy, int32_t* indices) {
     if (!o) return fail(MW_EINVAL, "NULL handle");
     HIP_TRY(hipSetDevice(o->device));
     const int N = o->p.resolution;  // mesh resolution (not the 8x texture size in OceanRenderer mode)
-    const size_t NN = (size_t)N * N;
-    float *dv = nullptr, *dn = nullptr, *du = nullptr;
-    int32_t* di = nullptr;
-    const size_t nidx = (size_t)(N - 1) * (N - 1) * 6;
-    mw_status s = MW_OK;
-    if (vertices_xyz && (s = dmalloc(&dv, NN * 3)) != MW_OK) goto done;
-    if (normals_xyz && (s = dmalloc(&dn, NN * 3)) != MW_OK) goto done;
-    if (uvs_xy && (s = dmalloc(&du, NN * 2)) != MW_OK) goto done;
-    if (indices && (s = dmalloc(&di, nidx)) != MW_OK) goto done;
+    const size_t NN = (size_t)N * N, nidx = (size_t)(N - 1) * (N - 1) * 6;
+    const size_t bv = align256(NN * 3 * sizeof(float)), bu = align256(NN * 2 * sizeof(float)), bi = align256(nidx * sizeof(int32_t));
+    void* buf = nullptr;
+    mw_status s = scratch_reserve(o, 2 * bv + bu + bi, &buf);
+    if (s != MW_OK) return s;
+    char* base = static_cast<char*>(buf);
+    float* dv = vertices_xyz ? reinterpret_cast<float*>(base) : nullptr;
+    float* dn = normals_xyz ? reinterpret_cast<float*>(base + bv) : nullptr;
+    float* du = uvs_xy ? reinterpret_cast<float*>(base + 2 * bv) : nullptr;
+    int32_t* di = indices ? reinterpret_cast<int32_t*>(base + 2 * bv + bu) : nullptr;
     hipLaunchKernelGGL(k_rest_mesh, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, o->stream, N, o->p.unit_width, dv,
                        dn, du, di);
-    if (hipGetLastError() != hipSuccess) { s = fail(MW_EDEVICE, "k_rest_mesh launch failed"); goto done; }
-    if (dv) hipMemcpyAsync(vertices_xyz, dv, NN * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream);
-    if (dn) hipMemcpyAsync(normals_xyz, dn, NN * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream);
-    if (du) hipMemcpyAsync(uvs_xy, du, NN * 2 * sizeof(float), hipMemcpyDeviceToHost, o->stream);
-    if (di) hipMemcpyAsync(indices, di, nidx * sizeof(int32_t), hipMemcpyDeviceToHost, o->stream);
-    if (hipStreamSynchronize(o->stream) != hipSuccess) s = fail(MW_EDEVICE, "rest_mesh sync failed");
-done:
-    hipFree(dv); hipFree(dn); hipFree(du); hipFree(di);
-    return s;
+    HIP_TRY(hipGetLastError());
+    if (dv) HIP_TRY(hipMemcpyAsync(vertices_xyz, dv, NN * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (dn) HIP_TRY(hipMemcpyAsync(normals_xyz, dn, NN * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (du) HIP_TRY(hipMemcpyAsync(uvs_xy, du, NN * 2 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (di) HIP_TRY(hipMemcpyAsync(indices, di, nidx * sizeof(int32_t), hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
 }
 
 mw_status mw_ocean_evaluate_device(mw_ocean* o, const float* t, int32_t nsteps, void* d_vertices, void* d_normals,
@@ -941,19 +1027,19 @@ mw_status mw_ocean_generate_texture_rgba(mw_ocean* o, float delta_time, float* h
     if (!o) return fail(MW_EINVAL, "NULL handle");
     if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_generate_texture_rgba: OceanRenderer semantics only");
     HIP_TRY(hipSetDevice(o->device));
-    const size_t bytes = (size_t)o->N * o->N * 4 * sizeof(float);
+    const size_t bytes = (size_t)o->N * o->N * 4 * sizeof(float), stride = align256(bytes);
     float* host[4] = {height_rgba, disp_rgba, normal_rgba, white_rgba};
     float* dev[4] = {nullptr, nullptr, nullptr, nullptr};
-    mw_status s = MW_OK;
-    for (int k = 0; k < 4 && s == MW_OK; k++)
-        if (host[k] && hipMalloc((void**)&dev[k], bytes) != hipSuccess) s = fail(MW_ENOMEM, "hipMalloc failed");
-    if (s == MW_OK) s = mw_ocean_generate_texture_rgba_device(o, delta_time, dev[0], dev[1], dev[2], dev[3]);
-    for (int k = 0; k < 4 && s == MW_OK; k++)
-        if (host[k] && hipMemcpyAsync(host[k], dev[k], bytes, hipMemcpyDeviceToHost, o->stream) != hipSuccess)
-            s = fail(MW_EDEVICE, "D2H failed");
-    if (hipStreamSynchronize(o->stream) != hipSuccess && s == MW_OK) s = fail(MW_EDEVICE, "stream sync failed");
-    for (int k = 0; k < 4; k++) hipFree(dev[k]);
-    return s;
+    void* buf = nullptr;
+    mw_status s = scratch_reserve(o, 4 * stride, &buf);
+    if (s != MW_OK) return s;
+    for (int k = 0; k < 4; k++)
+        if (host[k]) dev[k] = reinterpret_cast<float*>(static_cast<char*>(buf) + k * stride);
+    if ((s = mw_ocean_generate_texture_rgba_device(o, delta_time, dev[0], dev[1], dev[2], dev[3])) != MW_OK) return s;
+    for (int k = 0; k < 4; k++)
+        if (host[k]) HIP_TRY(hipMemcpyAsync(host[k], dev[k], bytes, hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
 }
 
 mw_status mw_ocean_displace_mesh_device(mw_ocean* o, void* d_vertices_xyz, void* d_normals_xyz, void* d_colors) {
@@ -970,20 +1056,20 @@ mw_status mw_ocean_displace_mesh(mw_ocean* o, float* vertices_xyz, float* normal
     if (!o || !vertices_xyz) return fail(MW_EINVAL, "mw_ocean_displace_mesh: NULL argument");
     if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_displace_mesh: OceanRenderer semantics only");
     HIP_TRY(hipSetDevice(o->device));
-    const size_t nv = (size_t)o->p.resolution * o->p.resolution;
-    float *dv = nullptr, *dn = nullptr, *dc = nullptr;
-    mw_status s = dmalloc(&dv, nv * 3);
-    if (s == MW_OK && normals_xyz) s = dmalloc(&dn, nv * 3);
-    if (s == MW_OK && colors) s = dmalloc(&dc, nv);
-    if (s == MW_OK) s = mw_ocean_displace_mesh_device(o, dv, dn, dc);
-    if (s == MW_OK) {
-        hipMemcpyAsync(vertices_xyz, dv, nv * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream);
-        if (dn) hipMemcpyAsync(normals_xyz, dn, nv * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream);
-        if (dc) hipMemcpyAsync(colors, dc, nv * sizeof(float), hipMemcpyDeviceToHost, o->stream);
-        if (hipStreamSynchronize(o->stream) != hipSuccess) s = fail(MW_EDEVICE, "displace_mesh sync failed");
-    }
-    hipFree(dv); hipFree(dn); hipFree(dc);
-    return s;
+    const size_t nv = (size_t)o->p.resolution * o->p.resolution, b3 = align256(nv * 3 * sizeof(float));
+    void* buf = nullptr;
+    mw_status s = scratch_reserve(o, 2 * b3 + align256(nv * sizeof(float)), &buf);
+    if (s != MW_OK) return s;
+    char* base = static_cast<char*>(buf);
+    float* dv = reinterpret_cast<float*>(base);
+    float* dn = normals_xyz ? reinterpret_cast<float*>(base + b3) : nullptr;
+    float* dc = colors ? reinterpret_cast<float*>(base + 2 * b3) : nullptr;
+    if ((s = mw_ocean_displace_mesh_device(o, dv, dn, dc)) != MW_OK) return s;
+    HIP_TRY(hipMemcpyAsync(vertices_xyz, dv, nv * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (dn) HIP_TRY(hipMemcpyAsync(normals_xyz, dn, nv * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (dc) HIP_TRY(hipMemcpyAsync(colors, dc, nv * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
 }
 
 mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, const char** names_out,
@@ -1111,6 +1197,8 @@ mw_status mw_debug_get_stamps(long long* out_host) {
     return MW_OK;
 }
 #endif
+
+#include "tiles.inc"
 
 // ---- pond -------------------------------------------------------------------------------------
 mw_status mw_gerstner_displace_device(const void* d_pos_xyz, int64_t nverts, const float* waves, int32_t nwaves,

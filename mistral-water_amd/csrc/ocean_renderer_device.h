@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -10,6 +11,20 @@
 #include "ocean_renderer_kernels.h"
 
 namespace mw {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device), safe from any number of host threads
+struct AttrOnce {
+    std::once_flag once[64];
+    hipError_t res[64];
+    hipError_t set(const void* fn, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const int d = dev & 63;
+        std::call_once(once[d], [&] { res[d] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+        return res[d];
+    }
+};
 
 struct OrState {
     int M = 0;
@@ -157,7 +172,7 @@ static inline void or_free(OrState& s) {
 
 static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStream_t st) {
     s.M = M;
-    s.c.M = M; s.c.length = p.length; s.c.gravity = p.gravity; s.c.choppiness = p.choppiness;
+    s.c.M = M; s.c.length = p.length; s.c.gravity = p.gravity; s.c.choppiness = p.choppiness; s.c.normal_length = p.length;
     s.mult = p.mult; s.choppiness = p.choppiness;
     const size_t MM = (size_t)M * M;
     std::vector<cf> tab = build_twiddle_table(M, plan_points_host(M), -1);
@@ -175,21 +190,33 @@ static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStre
     return MW_OK;
 }
 
+// RenderInitial() after a parameter change (S/OceanRenderer.cs:98-109): initialTexture again from the new length / wind /
+// amplitude, dispersion and spectrum passes on the new length (:94-97); the phase textures and the normal pass's length stay
+static inline mw_status or_reinit(OrState& s, float length, float wind_x, float wind_y, float amplitude, uint64_t seed, hipStream_t st) {
+    const size_t MM = (size_t)s.M * s.M;
+    s.c.length = length;
+    k_or_init<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(s.M, length, wind_x, wind_y, amplitude / 10000.f, s.c.gravity,
+                                                                       seed, s.initT, nullptr);
+    k_or_omega<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(s.c, s.omT);
+    if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_init launch failed"; return MW_EDEVICE; }
+    return MW_OK;
+}
+// phase texture <-> host order (texel (px,py) at py*M + px); the device keeps it transposed
+__global__ void k_or_phase_transpose(int M, const float* src, float* dst) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * M) return;
+    dst[idx] = src[(size_t)(idx % M) * M + idx / M];
+}
+
 template <int N>
 static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
     constexpr int P = Plan<N>::P;
-    static bool attr_done_dev[64] = {false};
-    int dev = 0;
-    hipGetDevice(&dev);
-    bool& attr_done = attr_done_dev[dev & 63];
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_or_pass1<N, P>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, OrP1Geom<N, P>::LDS_BYTES);
+    static AttrOnce attr1, attr2;
+    {
+        hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_or_pass1<N, P>), OrP1Geom<N, P>::LDS_BYTES);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_or_pass2<N, P>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                OrP2Geom<N, P>::LDS_BYTES);
+        e = attr2.set(reinterpret_cast<const void*>(&k_or_pass2<N, P>), OrP2Geom<N, P>::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     OrP1Args A1;
     A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.E = s.E; A1.c = s.c; A1.dt = dt;

@@ -21,6 +21,7 @@ namespace mw {
 struct OrConsts {
     int M;  // texture size = 8 * resolution (S/OceanRenderer.cs:136)
     float length, gravity, choppiness;
+    float normal_length;  // normalMat's _Length: set once in SetParams (S/OceanRenderer.cs:163), NOT updated when `length` changes
 };
 
 // F/FFTCommon.cginc:58-67 GetWave component for texel index p (n = p + 0.5 in the shader, minus 0.5 again)
@@ -62,7 +63,7 @@ MW_HD void or_init_element(int M, float length, float wind_x, float wind_y, floa
     f4 v;
     v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = -o[3];  // Conj (:51)
     initT[(size_t)px * M + py] = v;
-    phaseT[(size_t)px * M + py] = 0.f;  // the phase render targets start at 0
+    if (phaseT) phaseT[(size_t)px * M + py] = 0.f;  // the phase render targets start at 0; RenderInitial() alone (NULL) keeps them
 }
 // F/FFTCommon.cginc:101-114: phase <- fmod(phase + sqrt(G |k| (1 + |k|^2/370^2)) dt, 2 pi), strict float32.
 // The angular frequency does not depend on time: it is tabulated once (or_omega, 4 strict divisions + 2 square roots per
@@ -207,7 +208,7 @@ MW_HD int or_clamp(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 MW_HD void or_normal_element(const OrConsts& c, int px, int py, const float* height, const cf* disp, const float* disp_g,
                              float* normal, float* normal_xz = nullptr) {
     const int M = c.M;
-    const float ts = c.length / (float)M;
+    const float ts = c.normal_length / (float)M;  // F/OceanNormal.shader:42 with the length of SetParams
     const size_t idx = (size_t)py * M + px;
     const float cx = disp[idx].x, cy = disp_g[idx], cz = disp[idx].y;  // center = D.rgb (:44)
     const size_t ir = (size_t)py * M + or_clamp(px + 1, M - 1), il = (size_t)py * M + or_clamp(px - 1, M - 1);

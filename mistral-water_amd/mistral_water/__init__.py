@@ -9,6 +9,6 @@ shown in INTEGRATION.md.
 from ._native import (MW_EDEVICE, MW_EINVAL, MW_ENOTPOW2, MW_ESTATE, MW_OK, MW_OUT_COLOR_RGBA,  # noqa: F401
                       MW_OUT_WHITE_SCALAR, MW_SEM_FFTMESH, MW_SEM_OCEANRENDERER, MistralWaterError, MwParams,
                       build_native, check, lib)
-from .ocean import (FFTMesh, Ocean, OceanRenderer, PondMaterial, Vector2, gerstner_displace,  # noqa: F401
+from .ocean import (FFTMesh, Ocean, OceanRenderer, PondMaterial, Tiles, Vector2, gerstner_displace,  # noqa: F401
                     gerstner_displace_steps_device, host_register, host_unregister)
 from ._native import MW_POND_GERSTNER, MW_POND_GERSTNER_LEVEL_ONE, MW_POND_WAVE  # noqa: F401

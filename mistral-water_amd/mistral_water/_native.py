@@ -31,6 +31,7 @@ class MwParams(C.Structure):
 
 
 MW_POND_WAVE, MW_POND_GERSTNER, MW_POND_GERSTNER_LEVEL_ONE = 0, 1, 2
+MW_COMM_ID_BYTES = 128
 
 
 class MwPondParams(C.Structure):
@@ -85,6 +86,23 @@ def lib():
         "mw_ocean_create": (C.c_int, [C.POINTER(MwParams), C.POINTER(vp)]),
         "mw_ocean_destroy": (None, [vp]),
         "mw_ocean_set_stream": (C.c_int, [vp, vp]),
+        "mw_ocean_use_own_stream": (C.c_int, [vp]),
+        "mw_ocean_reinit_spectrum": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint64]),
+        "mw_ocean_get_phase": (C.c_int, [vp, f32p]),
+        "mw_ocean_set_phase": (C.c_int, [vp, f32p]),
+        "mw_ocean_set_timer": (C.c_int, [vp, C.c_float]),
+        "mw_comm_unique_id": (C.c_int, [vp]),
+        "mw_tiles_create": (C.c_int, [C.POINTER(MwParams), C.c_int32, i32p, C.c_int32, C.POINTER(vp)]),
+        "mw_tiles_create_rank": (C.c_int, [C.POINTER(MwParams), C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, C.POINTER(vp)]),
+        "mw_tiles_destroy": (None, [vp]),
+        "mw_tiles_count": (C.c_int32, [vp]),
+        "mw_tiles_local_count": (C.c_int32, [vp]),
+        "mw_tiles_ocean": (vp, [vp, C.c_int32]),
+        "mw_tiles_evaluate": (C.c_int, [vp, f32p, C.c_int32, C.c_uint32]),
+        "mw_tiles_outputs": (C.c_int, [vp, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "mw_tiles_gather": (C.c_int, [vp, C.c_int32, C.c_int32]),
+        "mw_tiles_gathered": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
+        "mw_tiles_synchronize": (C.c_int, [vp]),
         "mw_ocean_get_stream": (vp, [vp]),
         "mw_ocean_synchronize": (C.c_int, [vp]),
         "mw_ocean_set_choppiness": (C.c_int, [vp, C.c_float]),
@@ -134,8 +152,11 @@ def lib():
 #: every symbol include/mistral_water.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [
     "mw_abi_version", "mw_last_error", "mw_device_count", "mw_params_default", "mw_ocean_create", "mw_ocean_destroy",
-    "mw_ocean_set_stream", "mw_ocean_get_stream", "mw_ocean_synchronize", "mw_ocean_set_choppiness",
-    "mw_ocean_set_spectrum", "mw_ocean_get_spectrum", "mw_ocean_rest_mesh", "mw_ocean_index_count",
+    "mw_ocean_set_stream", "mw_ocean_use_own_stream", "mw_ocean_get_stream", "mw_ocean_synchronize", "mw_ocean_set_choppiness",
+    "mw_ocean_set_spectrum", "mw_ocean_get_spectrum", "mw_ocean_reinit_spectrum", "mw_ocean_get_phase", "mw_ocean_set_phase",
+    "mw_ocean_set_timer", "mw_comm_unique_id", "mw_tiles_create", "mw_tiles_create_rank", "mw_tiles_destroy", "mw_tiles_count",
+    "mw_tiles_local_count", "mw_tiles_ocean", "mw_tiles_evaluate", "mw_tiles_outputs", "mw_tiles_gather", "mw_tiles_gathered",
+    "mw_tiles_synchronize", "mw_ocean_rest_mesh", "mw_ocean_index_count",
     "mw_ocean_grid_size", "mw_ocean_evaluate", "mw_ocean_update", "mw_ocean_timer", "mw_ocean_reset_timer",
     "mw_ocean_evaluate_device", "mw_ocean_max_batch", "mw_ocean_generate_texture",
     "mw_ocean_generate_texture_device", "mw_host_register", "mw_host_unregister", "mw_ocean_generate_texture_rgba", "mw_ocean_generate_texture_rgba_device",

@@ -56,7 +56,13 @@ class Ocean:
         return self._h
 
     def set_stream(self, hip_stream: int | None):
-        nat.check(nat.lib().mw_ocean_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+        """Run the handle's work on `hip_stream` (a hipStream_t as int).  0 is HIP's legacy default stream -- what
+        ``torch.cuda.current_stream().cuda_stream`` is unless a side stream is current; ``None`` returns to the handle's
+        own private non-blocking stream (mw_ocean_use_own_stream)."""
+        if hip_stream is None:
+            nat.check(nat.lib().mw_ocean_use_own_stream(self._h))
+        else:
+            nat.check(nat.lib().mw_ocean_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
     def synchronize(self):
         nat.check(nat.lib().mw_ocean_synchronize(self._h))
@@ -76,6 +82,32 @@ class Ocean:
         h0c = np.empty((self.N, self.N, 2), np.float32)
         nat.check(nat.lib().mw_ocean_get_spectrum(self._h, _p(h0), _p(h0c)))
         return h0, h0c
+
+    def reinit_spectrum(self, length=None, wind=None, amplitude=None, seed=None):
+        """Regenerate the initial spectrum in place (mw_ocean_reinit_spectrum); None keeps the handle's current value.
+        OceanRenderer: RenderInitial() again, phase untouched (S/OceanRenderer.cs:98-109)."""
+        p = self.params
+        length = p.length if length is None else float(length)
+        wx, wy = (p.wind_x, p.wind_y) if wind is None else (float(wind[0]), float(wind[1]))
+        amplitude = p.amplitude if amplitude is None else float(amplitude)
+        seed = p.seed if seed is None else int(seed)
+        nat.check(nat.lib().mw_ocean_reinit_spectrum(self._h, C.c_float(length), C.c_float(wx), C.c_float(wy), C.c_float(amplitude),
+                                                     C.c_uint64(seed)))
+        p.length, p.wind_x, p.wind_y, p.amplitude, p.seed = length, wx, wy, amplitude, seed
+
+    def get_phase(self):
+        """OceanRenderer: the stateful phase texture [M, M] (texel (px,py) at [py, px])."""
+        ph = np.empty((self.N, self.N), np.float32)
+        nat.check(nat.lib().mw_ocean_get_phase(self._h, _p(ph)))
+        return ph
+
+    def set_phase(self, phase):
+        ph = np.ascontiguousarray(phase, np.float32)
+        assert ph.size == self.N * self.N
+        nat.check(nat.lib().mw_ocean_set_phase(self._h, _p(ph)))
+
+    def set_timer(self, t: float):
+        nat.check(nat.lib().mw_ocean_set_timer(self._h, C.c_float(t)))
 
     def rest_mesh(self):
         n = self.mesh_resolution
@@ -188,16 +220,21 @@ class FFTMesh:
         self.gravity = 9.81            # G, :52
         self.mesh = _Mesh()
         self._device, self._seed = device, seed
+        self.fixedSeed = False         # True: every regeneration reproduces the same sea (tests); the reference draws anew
+        self._generation = 0
         self._ocean = None
         self._timer = 0.0
 
-    # SetParams + GenerateMesh (:90-139)
+    # SetParams + GenerateMesh (:90-139).  GenerateMesh draws fresh UnityEngine.Random values every time it runs
+    # (:114-116), so each regeneration is a NEW sea state: the seed advances with a generation counter.
     def _regenerate(self):
         if self._ocean is not None:
             self._ocean.close()
+        seed = self._seed if self.fixedSeed else self._seed + self._generation
+        self._generation += 1
         self._ocean = Ocean(resolution=self.resolution, unit_width=self.unitWidth, length=self.length,
                             wind=(self.wind.x, self.wind.y), amplitude=self.amplitude, choppiness=self.choppiness,
-                            gravity=self.gravity, t_division=self.tDivision, seed=self._seed, device=self._device)
+                            gravity=self.gravity, t_division=self.tDivision, seed=seed, device=self._device)
         v, n, uv, idx = self._ocean.rest_mesh()
         self.mesh.vertices, self.mesh.normals, self.mesh.uv, self.mesh.indices = v, n, uv, idx
 
@@ -262,10 +299,11 @@ class OceanRenderer:
         self.mesh.vertices, self.mesh.normals, self.mesh.uv, self.mesh.indices = v, n, uv, idx
 
     def Update(self, deltaTime: float):  # :91-110
-        self._ocean.set_choppiness(self.choppiness)
-        self.GenerateTexture(deltaTime)
-        if self._old != self._key():  # :98-109 RenderInitial again with the same seeds
-            self._create()
+        self.GenerateTexture(deltaTime)                   # with the values the materials carried into this frame (:93)
+        self._ocean.set_choppiness(self.choppiness)       # spectrumMat._Choppiness for the NEXT frame (:96)
+        if self._old != self._key():  # :98-109 RenderInitial again with the same seeds; the phase textures keep running
+            self._ocean.reinit_spectrum(length=self.length, wind=(self.wind.x, self.wind.y), amplitude=self.amplitude)
+            self._old = self._key()
 
     def GenerateTexture(self, deltaTime: float):  # :216-316
         h, d, n, w = self._ocean.generate_texture(deltaTime)
@@ -274,6 +312,93 @@ class OceanRenderer:
     @property
     def ocean(self) -> Ocean:
         return self._ocean
+
+
+class Tiles:
+    """Independent FFTMesh-semantics tiles (seed = seed0 + k) on several devices with an RCCL gather of finished outputs
+    (include/mistral_water.h, mw_tiles_*).  ``devices`` lists one device ordinal per tile (single-process form); pass
+    ``comm_id``/``rank``/``nranks`` instead for the one-process-per-GPU form."""
+
+    def __init__(self, *, resolution, ntiles=1, devices=None, max_steps=1, unit_width=1.0, length=1.0, wind=(1.0, 1.0), amplitude=1.0,
+                 choppiness=1.0, gravity=9.81, seed=1, comm_id=None, rank=0, nranks=1, device=0):
+        self._h = C.c_void_p()
+        self.params = nat.MwParams(int(resolution), float(unit_width), float(length), float(wind[0]), float(wind[1]),
+                                   float(amplitude), float(choppiness), float(gravity), 1.0, 1.0, int(seed), nat.MW_SEM_FFTMESH, 0)
+        if comm_id is None:
+            dv = None if devices is None else (C.c_int32 * ntiles)(*[int(d) for d in devices])
+            nat.check(nat.lib().mw_tiles_create(C.byref(self.params), int(ntiles), dv, int(max_steps), C.byref(self._h)))
+        else:
+            buf = (C.c_ubyte * nat.MW_COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+            nat.check(nat.lib().mw_tiles_create_rank(C.byref(self.params), int(device), int(max_steps), buf, int(rank), int(nranks),
+                                                     C.byref(self._h)))
+        self.N = int(resolution)
+        self.max_steps = int(max_steps)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_ubyte * nat.MW_COMM_ID_BYTES)()
+        nat.check(nat.lib().mw_comm_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            nat.lib().mw_tiles_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def count(self):
+        return nat.lib().mw_tiles_count(self._h)
+
+    @property
+    def local_count(self):
+        return nat.lib().mw_tiles_local_count(self._h)
+
+    def set_spectrum(self, k, h0, h0conj):
+        o = nat.lib().mw_tiles_ocean(self._h, int(k))
+        h0 = np.ascontiguousarray(h0, np.float32)
+        h0conj = np.ascontiguousarray(h0conj, np.float32)
+        nat.check(nat.lib().mw_ocean_set_spectrum(C.c_void_p(o), _p(h0), _p(h0conj)))
+
+    def get_spectrum(self, k):
+        o = nat.lib().mw_tiles_ocean(self._h, int(k))
+        h0 = np.empty((self.N, self.N, 2), np.float32)
+        h0c = np.empty((self.N, self.N, 2), np.float32)
+        nat.check(nat.lib().mw_ocean_get_spectrum(C.c_void_p(o), _p(h0), _p(h0c)))
+        return h0, h0c
+
+    def evaluate(self, times, rgba: bool = False):
+        tt = np.ascontiguousarray(times, np.float32)
+        nat.check(nat.lib().mw_tiles_evaluate(self._h, _p(tt), tt.size, nat.MW_OUT_COLOR_RGBA if rgba else nat.MW_OUT_WHITE_SCALAR))
+
+    def outputs(self, k):
+        """Device pointers (ints) of local tile k: vertices, normals, white."""
+        v, n, w = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nat.check(nat.lib().mw_tiles_outputs(self._h, int(k), C.byref(v), C.byref(n), C.byref(w)))
+        return v.value, n.value, w.value
+
+    def gather(self, step: int, root: int = 0):
+        nat.check(nat.lib().mw_tiles_gather(self._h, int(step), int(root)))
+
+    def gathered(self):
+        """(device pointer of the root buffer or None, floats per tile)."""
+        ptr, fpt = C.c_void_p(), C.c_int64()
+        nat.check(nat.lib().mw_tiles_gathered(self._h, C.byref(ptr), C.byref(fpt)))
+        return ptr.value, fpt.value
+
+    def synchronize(self):
+        nat.check(nat.lib().mw_tiles_synchronize(self._h))
 
 
 def host_register(array):

@@ -222,10 +222,13 @@ def renderer_initial_spectrum(p: RendererParams, seed: int):
     return init4
 
 
-def renderer_step_f64(p: RendererParams, init4, phase, delta_time: float, literal_passes: bool = True):
+def renderer_step_f64(p: RendererParams, init4, phase, delta_time: float, literal_passes: bool = True, normal_params=None):
     """One OceanRenderer.GenerateTexture().  `phase` ([M,M] float32) is advanced in place.
     literal_passes=True runs the 2*log2(M) Stockham gather passes exactly as S/OceanRenderer.cs schedules them;
-    False swaps in numpy's fft2 (validated equal in tests) for large M."""
+    False swaps in numpy's fft2 (validated equal in tests) for large M.
+    normal_params: the parameters normalMat / whiteMat carry (S/OceanRenderer.cs sets normalMat's _Length only in SetParams,
+    :163, so after a length change the normal pass keeps the OLD length); needs literal_passes=False."""
+    assert normal_params is None or not literal_passes
     M = p.M
     init4 = np.ascontiguousarray(init4, np.float32)
     assert phase.dtype == np.float32 and phase.flags.c_contiguous
@@ -245,7 +248,7 @@ def renderer_step_f64(p: RendererParams, init4, phase, delta_time: float, litera
     hh = np.fft.fft2(sh[..., 0] + 1j * sh[..., 1])
     dtex = np.ascontiguousarray(np.stack([hx.real, hx.imag, hz.real, hz.imag], -1))
     hre = np.ascontiguousarray(hh.real)
-    lib().orr_normal_white_f64(C.byref(p.c()), _fp(dtex), _fp(hre), _fp(n), _fp(w))
+    lib().orr_normal_white_f64(C.byref((normal_params or p).c()), _fp(dtex), _fp(hre), _fp(n), _fp(w))
     return hre, np.ascontiguousarray(dtex[..., [0, 2]]), n, w, np.ascontiguousarray(dtex[..., 1])
 
 

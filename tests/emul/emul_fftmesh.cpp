@@ -334,7 +334,7 @@ void emul_or_init(int M, float length, float wind_x, float wind_y, float amplitu
 int emul_or_step(int M, float length, float gravity, float choppiness, float dt, const float* initT, float* phaseT,
                  float* height, float* disp, float* disp_g, float* normal, float* white, float* height_g, float* disp_a) {
     OrConsts C;
-    C.M = M; C.length = length; C.gravity = gravity; C.choppiness = choppiness;
+    C.M = M; C.length = length; C.gravity = gravity; C.choppiness = choppiness; C.normal_length = length;
     const f4* it = reinterpret_cast<const f4*>(initT);
     cf* d = reinterpret_cast<cf*>(disp);
     switch (M) {

@@ -22,7 +22,8 @@ L.mw_debug_get_stamps.argtypes = [C.c_void_p]
 assert L.mw_debug_get_stamps(st.ctypes.data) == 0
 names1 = {0: "start", 1: "animate (global loads + sincos)"}
 for f in range(3):
-    names1.update({2 + 8 * f: f"f{f} build + WAR barrier", 3 + 8 * f: f"f{f} dftP + lds write", 7 + 8 * f: f"f{f} middle passes (barriers, lds, twiddles, dftP)",
+    names1.update({2 + 8 * f: f"f{f} build + WAR barrier", 3 + 8 * f: f"f{f} dftP + lds write", 4 + 8 * f: f"f{f} s=1: barrier + lds read",
+                   5 + 8 * f: f"f{f} s=1: WAR barrier", 6 + 8 * f: f"f{f} s=1: twiddles + dftP + lds write", 7 + 8 * f: f"f{f} rest of the middle passes",
                    8 + 8 * f: f"f{f} lds read + final + global store"})
 names1[26] = "end"
 names2 = {0: "start"}
