@@ -7,11 +7,17 @@ prints ONE JSON line on rank 0.  A "step" is one time-step of one 1024 x 1024 FF
 no data-path collective, weak scaling.  Inputs (h0/h0conj -> packed spectrum tables) are resident in HBM
 before the timed region; outputs (vertices, normals, whitecap) stay in device memory.
 
+N = 1 drives one mw_ocean handle; N > 1 drives the product's tile API (include/mistral_water.h, mw_tiles_*): every
+rank owns one tile and one rank of an RCCL communicator that the LIBRARY creates (mw_comm_unique_id on rank 0, the 128
+bytes broadcast through torch.distributed, mw_tiles_create_rank everywhere).  torch.distributed carries only the id,
+the barriers and the max-over-ranks of the timing; `--gather` adds the library's own gather of the last step of every
+batch to rank 0 (ncclSend/ncclRecv on a side stream behind an event), overlapped with the next batch.
+
 Extra objects on the same line:
-  roofline      dominant kernel (k_pass2) algorithmic bytes / its mean launch duration measured live with
-                hipEvents on the launch stream, against the 8 TB/s HBM peak.
-  cpu_baseline  the oracle's literal restatement of the reference CPU path (S/FFTMesh.cs:192-249, O(N^4)),
-                single thread, on a bounded vertex sample of the same 1024^2 step.
+  roofline      dominant kernel (k_pass2) ALGORITHMIC bytes / its mean launch duration measured live with hipEvents on the
+                launch stream, against the 8 TB/s HBM peak (`frac`); `real_frac` = the HBM-side bytes the committed rocprofv3
+                PMC pass counted for the same launch / the same duration / 8 TB/s (what the kernel physically moves).
+  cpu_baseline  the oracle's restatement of the reference CPU path timed on this box's host cores, on a bounded sample.
 """
 import argparse
 import json
@@ -28,11 +34,13 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
 # BASELINE.json's metric string, verbatim
-BASELINE_METRIC = "ocean grid-points/sec (full spectrum\u2192IFFT\u2192disp\u2192Jacobian), 1024\u00b2 grid, 1/2/4/8 GPUs"
+BASELINE_METRIC = "ocean grid-points/sec (full spectrum→IFFT→disp→Jacobian), 1024² grid, 1/2/4/8 GPUs"
 BYTES_PER_POINT = 92       # SURVEY.md 8d canonical algorithmic traffic of one FFTMesh step
 BYTES_PASS1 = 16 + 24      # read (P,Q) + write 3 packed complex fields
 BYTES_PASS2 = 24 + 28      # read 3 packed complex fields + write vertex 12 + normal 12 + whitecap 4
 BYTES_POND = 24            # read position 12 + write position 12
+BYTES_RENDERER = 120       # see renderer()
+PROFILE_ROUND = "r02"      # profiles/<round>_<workload>_b<B>_pmc.json carry the counters of THIS build
 
 
 def parse():
@@ -47,22 +55,27 @@ def parse():
                          "timed region starts at steady clocks (the first ~5 ms after idle run ~25 %% slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of the last step's tiles (configs[2])")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: the library's RCCL gather of the last step of every batch to rank 0, on the side stream")
     return ap.parse_args()
 
 
-def pmc_traffic(N, B):
-    """HBM-side bytes per k_pass2 launch from the committed rocprofv3 PMC passes (tools/profile_r1.sh ->
-    profiles/r01_ocean{N}_b{B}_pmc.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, i.e. with the gfx950 correction the
+def host_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def pmc_traffic(workload, B, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/prof_workload.sh ->
+    profiles/<round>_<workload>_b<B>_pmc.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, i.e. with the gfx950 correction the
     micro-architecture guide prescribes (FETCH_SIZE counts 128-B requests at 64 B).  Counters cannot be read from
     inside this process, so this is the value measured by the same command under the profiler; None if absent."""
-    path = os.path.join(REPO, "profiles", f"r01_ocean{N}_b{B}_pmc.json")
+    path = os.path.join(REPO, "profiles", f"{PROFILE_ROUND}_{workload}_b{B}_pmc.json")
     try:
         d = json.load(open(path))["pmc_mean_per_launch"]
-        k = [v for name, v in d.items() if "k_pass2" in name][0]
+        k = [v for name, v in d.items() if kernel in name][0]
         return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, f"rocprofv3 --pmc, {os.path.relpath(path, REPO)}"
     except Exception:
-        return None, "no committed PMC pass for this workload/batch"
+        return None, f"no committed PMC pass for this workload/batch ({os.path.relpath(path, REPO)})"
 
 
 def preheat(enqueue, torch, ms):
@@ -78,41 +91,57 @@ def preheat(enqueue, torch, ms):
     return (time.perf_counter() - t0) * 1e3
 
 
-def cpu_baseline(p, h0, h0c, budget_s=12.0):
-    """Literal O(N^4) port (oracle) on a vertex sample sized for ~10-20 s of one host core."""
+def cpu_baseline_ocean(p, h0, h0c, gpu_step, budget_s=12.0):
+    """CPU legs of an FFTMesh workload, all on the same (h0, h0conj, t = 1.0) step the GPU parity gate evaluated:
+      value         the literal O(N^4) port (oracle/fftmesh_oracle.c, one core) on a vertex sample sized for ~10-20 s;
+      literal_f32_distance   GPU output vs that literal float32 sum at the sampled vertices (the north star's "match the
+                    reference C# CPU path": measured, not assumed);
+      fft_port*     numpy ifft2 in f64, and the float32 radix-2 Stockham port in C on 1 and on the best number of host threads."""
     from oracle import oracle as O
     N = p.N
     rng = np.random.default_rng(0)
-    probe = rng.choice(N * N, 8, replace=False).astype(np.int32)
+    probe = rng.choice(N * N, 4, replace=False).astype(np.int32)
     t0 = time.perf_counter()
     O.displacement_subset_f32(p, h0, h0c, 1.0, probe)
     per_vertex = (time.perf_counter() - t0) / probe.size
     count = int(max(8, min(4096, budget_s / per_vertex)))
-    idx = rng.choice(N * N, count, replace=False).astype(np.int32)
+    idx = np.sort(rng.choice(N * N, count, replace=False)).astype(np.int32)
     t0 = time.perf_counter()
-    O.displacement_subset_f32(p, h0, h0c, 1.0, idx)
+    hd, nor = O.displacement_subset_f32(p, h0, h0c, 1.0, idx)
     el = time.perf_counter() - t0
-    # the same model through numpy's FFT (f64, 1 thread): what a CPU *port with an FFT* achieves
+    dist = None
+    if gpu_step is not None:
+        v, n = gpu_step
+        rest = O.rest_mesh(p)[0]
+        scale = max(float(np.abs(hd).max()), 1e-30)
+        dist = {"vertices": count, "t": 1.0,
+                "height_rel": float(np.abs(v[idx, 1] - hd[:, 1]).max() / scale),
+                "disp_rel": float(max(np.abs((rest[idx, 0] - v[idx, 0]) - hd[:, 0] * p.choppiness).max(),
+                                      np.abs((rest[idx, 2] - v[idx, 2]) - hd[:, 2] * p.choppiness).max()) / scale),
+                "normal_abs": float(np.abs(n[idx] - nor).max()),
+                "note": "relative to max |displacement| of the sample; the literal float32 sum of N^2 terms is itself only "
+                        "~1e-4 accurate (tests/test_gpu_parity.py bounds it at 3e-4)"}
     t1 = time.perf_counter()
     O.eval_fft_f64(p, h0, h0c, 1.0)
     el_fft = time.perf_counter() - t1
-    # SURVEY 8d (ii): a float32 radix-2 Stockham port in C (oracle/cpu_fft_baseline.c), 1 thread and all host cores
+
     def time_c(nthreads, reps):
         O.cpu_fft_step_f32(p, h0, h0c, 1.0, nthreads)
         t2 = time.perf_counter()
         for r in range(reps):
             O.cpu_fft_step_f32(p, h0, h0c, 1.0 + r / 60.0, nthreads)
         return (time.perf_counter() - t2) / reps
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    el_c1 = time_c(1, 2)
+    cores = host_cores()
+    el_c1 = time_c(1, 2 if N <= 1024 else 1)
     # more threads than the memory system can feed only add barrier cost: report the best thread count, name it
     cands = sorted({c for c in (cores, cores // 2, cores // 4, cores // 8, 32, 16, 8) if 1 <= c <= cores})
-    el_call, best_threads = min((time_c(c, 3), c) for c in cands)
+    el_call, best_threads = min((time_c(c, 3 if N <= 1024 else 1), c) for c in cands)
     return {
         "value": count / el, "unit": "grid-points/s", "cores": 1, "kind": "port",
         "sample": f"{count} of {N * N} vertices of one {N}x{N} step through the literal O(N^4) "
                   f"FFTMesh.Displacement restatement (oracle/fftmesh_oracle.c), {el:.1f} s; "
                   f"host has {os.cpu_count()} cores",
+        "literal_f32_distance": dist,
         "fft_port": {"value": N * N / el_fft, "unit": "grid-points/s", "cores": 1,
                      "what": "same model via numpy ifft2 in f64 (oracle.eval_fft_f64), one full step"},
         "fft_port_c": {"value": N * N / el_c1, "unit": "grid-points/s", "cores": 1,
@@ -135,13 +164,15 @@ def main():
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     dist = None
+    same_device = os.environ.get("MW_BENCH_SAME_DEVICE") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # test hooks for a 1-GPU box (never set by the driver): MW_BENCH_BACKEND=gloo + MW_BENCH_SAME_DEVICE=1 run the
-        # N > 1 control flow (barriers, max-over-ranks, rank-0 reporting) with every rank on cuda:0
+        # N > 1 control flow (barriers, max-over-ranks, rank-0 reporting) with every rank on cuda:0; an RCCL communicator
+        # cannot hold one device twice, so that mode drives plain mw_ocean handles instead of the tile API
         backend = os.environ.get("MW_BENCH_BACKEND", "nccl")
-        if os.environ.get("MW_BENCH_SAME_DEVICE") == "1":
+        if same_device:
             local_rank = 0
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -167,70 +198,117 @@ def main():
     NN = N * N
     p = workloads.fftmesh_params(N)
     seed = 1 + rank
-    ocean = mw.Ocean(resolution=N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y),
-                     amplitude=p.amplitude, choppiness=p.choppiness, gravity=p.gravity, seed=seed, device=local_rank)
-    ocean.set_stream(stream.cuda_stream)
-    B = max(1, min(a.batch, ocean.max_batch))
-    dv = torch.empty((B, NN, 3), dtype=torch.float32, device=dev)
-    dn = torch.empty((B, NN, 3), dtype=torch.float32, device=dev)
-    dw = torch.empty((B, NN), dtype=torch.float32, device=dev)
+    kw = dict(resolution=N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude,
+              choppiness=p.choppiness, gravity=p.gravity)
+    use_tiles = world > 1 and not same_device
+    tiles = ocean = None
+    if use_tiles:
+        # the product's tile API: the LIBRARY owns the RCCL communicator; torch.distributed only carries its 128-byte id
+        box = [mw.Tiles.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        B = max(1, min(a.batch, 32))
+        tiles = mw.Tiles(max_steps=B, seed=1, comm_id=box[0], rank=rank, nranks=world, device=local_rank, **kw)
+        ptrs = tiles.outputs(0)
+    else:
+        ocean = mw.Ocean(seed=seed, device=local_rank, **kw)
+        ocean.set_stream(stream.cuda_stream)
+        B = max(1, min(a.batch, ocean.max_batch))
+        dv = torch.empty((B, NN, 3), dtype=torch.float32, device=dev)
+        dn = torch.empty((B, NN, 3), dtype=torch.float32, device=dev)
+        dw = torch.empty((B, NN), dtype=torch.float32, device=dev)
 
-    # ---- parity gate before any timing (same run, same inputs) ----------------------------------------
-    parity = None
-    if not a.no_parity and rank == 0:
+    def enqueue(times):
+        if use_tiles:
+            tiles.evaluate(times)
+        else:
+            ocean.evaluate_device(times, dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+
+    def sync():
+        if use_tiles:
+            tiles.synchronize()
+        torch.cuda.synchronize()
+
+    # ---- parity gate before any timing (same run, same inputs): rank 0, N = 1 path ---------------------
+    parity, gpu_step, h0 = None, None, None
+    if not a.no_parity and rank == 0 and not use_tiles:
         h0, h0c = ocean.get_spectrum()
         ocean.evaluate_device([1.0], dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
         ocean.synchronize()
         vf, nf, cf, hds = O.eval_fft_f64(p, h0, h0c, 1.0, return_hds=True)
-        workloads.assert_parity(dv[0].cpu().numpy(), dn[0].cpu().numpy(), dw[0].cpu().numpy()[:, None], vf, nf,
+        gpu_step = (dv[0].cpu().numpy(), dn[0].cpu().numpy())
+        workloads.assert_parity(gpu_step[0], gpu_step[1], dw[0].cpu().numpy()[:, None], vf, nf,
                                 cf[:, :1], O.rest_mesh(p)[0], np.abs(hds).max(), tag="bench parity gate")
         parity = "ok (vs oracle f64, tol workloads.REL_TOL)"
+        del vf, nf, cf, hds
 
-    def run(nsteps, k0):
+    gathers = [0]
+
+    def run(nsteps, k0, gather=False):
         k = k0
         while k < k0 + nsteps:
             nb = min(B, k0 + nsteps - k)
-            ocean.evaluate_device([(kk + 1) / 60.0 for kk in range(k, k + nb)], dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+            enqueue([(kk + 1) / 60.0 for kk in range(k, k + nb)])
+            if gather:      # the previous batch's tiles travel on the side stream while this batch computes
+                tiles.gather(step=nb - 1, root=0)
+                gathers[0] += 1
             k += nb
 
     barrier()   # rank 0 may have spent seconds in the parity gate: line the ranks up BEFORE warming the clocks
     preheat_ms = preheat(lambda: run(B, 0), torch, a.preheat_ms)
     run(a.warmup, 0)
+    sync()
     barrier()
     t0 = time.perf_counter()
     run(a.steps, a.warmup)
-    torch.cuda.synchronize()
+    sync()
     el = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-
-    # ---- kernel-level timing with HIP events on the launch stream (rank 0) ----------------------------
-    preheat(lambda: run(B, 0), torch, a.preheat_ms)     # the gather/all-reduce above may have let the clocks drop
-    kern = ocean.profile_kernels(nsteps=B, iters=100)   # in situ: pass1/pass2 alternate as in the timed loop
-    k2_ms = kern[1][1]
-    roof_ach = BYTES_PASS2 * NN * B / (k2_ms * 1e-3)
-    traffic, traffic_note = pmc_traffic(N, B)
-    roofline = {"bound": "hbm", "kernel": "k_pass2", "achieved": roof_ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": roof_ach / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
-                "bytes_per_launch": BYTES_PASS2 * NN * B, "launch_us": k2_ms * 1e3,
-                "kernels": [{"name": nm, "us_per_launch": ms * 1e3,
-                             "algorithmic_GBps": (BYTES_PASS1 if i == 0 else BYTES_PASS2) * NN * B / (ms * 1e-3) / 1e9}
-                            for i, (nm, ms) in enumerate(kern)]}
-
-    gather_ms = None
-    if a.gather and dist is not None:
-        last = torch.cat([dv[B - 1].reshape(-1), dn[B - 1].reshape(-1), dw[B - 1].reshape(-1)])
-        bufs = [torch.empty_like(last) for _ in range(world)] if rank == 0 else None
+    el_gather = None
+    if a.gather and use_tiles:      # the same K steps again, now with the per-batch gather to rank 0 overlapped
+        run(a.warmup, 0, gather=True)
+        sync()
         barrier()
         t1 = time.perf_counter()
-        dist.gather(last, bufs, dst=0)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - t1) * 1e3
+        run(a.steps, a.warmup, gather=True)
+        sync()
+        el_gather = time.perf_counter() - t1
+        barrier()
+    if dist is not None:
+        tt = torch.tensor([el, el_gather or 0.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt[0].item())
+        el_gather = float(tt[1].item()) if el_gather is not None else None
+
+    # ---- kernel-level timing with HIP events on the launch stream (rank 0) ----------------------------
+    prof = tiles_ocean = None
+    if use_tiles:
+        # the tile's own mw_ocean handle (borrowed) runs the in-situ profile on the tile's compute stream
+        tiles_ocean = mw.Ocean.__new__(mw.Ocean)
+        import ctypes as C
+        tiles_ocean._h = C.c_void_p(mw.lib().mw_tiles_ocean(tiles._h, 0))
+        prof = tiles_ocean
+    else:
+        prof = ocean
+    preheat(lambda: run(B, 0), torch, a.preheat_ms)     # the all-reduce above may have let the clocks drop
+    kern = prof.profile_kernels(nsteps=B, iters=100)     # in situ: pass1/pass2 alternate as in the timed loop
+    if tiles_ocean is not None:
+        tiles_ocean._h = None                            # borrowed: the tiles own it
+    k2_ms = kern[1][1]
+    roof_ach = BYTES_PASS2 * NN * B / (k2_ms * 1e-3)
+    traffic, traffic_note = pmc_traffic(a.workload, B, "k_pass2")
+    traffic1, _ = pmc_traffic(a.workload, B, "k_pass1")
+    roofline = {"bound": "hbm", "kernel": "k_pass2", "achieved": roof_ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": roof_ach / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
+                "real_frac": (traffic / (k2_ms * 1e-3) / HBM_PEAK) if traffic else None,
+                "physical_bytes_per_point": (traffic / (NN * B)) if traffic else None,
+                "bytes_per_launch": BYTES_PASS2 * NN * B, "algorithmic_bytes_per_point": BYTES_PASS2, "launch_us": k2_ms * 1e3,
+                "kernels": [{"name": nm, "us_per_launch": ms * 1e3,
+                             "algorithmic_GBps": (BYTES_PASS1 if i == 0 else BYTES_PASS2) * NN * B / (ms * 1e-3) / 1e9,
+                             "physical_GBps": (tr / (ms * 1e-3) / 1e9) if tr else None}
+                            for i, ((nm, ms), tr) in enumerate(zip(kern, (traffic1, traffic)))]}
 
     value = world * a.steps * NN / el
+    phys_pt = ((traffic or 0) + (traffic1 or 0)) / (NN * B) if (traffic and traffic1) else None
     out = {
         "metric": BASELINE_METRIC if N == 1024
         else f"ocean grid-points/sec (full spectrum->IFFT->disp->Jacobian), {N}^2 grid",
@@ -238,23 +316,36 @@ def main():
         "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "preheat_ms": preheat_ms,
         "config": {"workload": f"FFTMesh-semantics ocean tile {N}x{N}, height+choppy+normals+Jacobian whitecap, "
-                               f"t_k = k/60 s, one independent tile per GPU (seed = 1 + rank)",
+                               f"unit_width {p.unit_width:g}, length {p.length:g}, wind ({p.wind_x:g}, {p.wind_y:g}), "
+                               f"amplitude {p.amplitude:.3g} (1.5e-8 (1024/N)^2: wave heights O(1 m) at every N; SURVEY 8d's "
+                               f"0.41 saturates normals and whitecap and is a parity case, tests/test_gpu_parity.py), "
+                               f"choppiness {p.choppiness:g}, t_k = k/60 s, one independent tile per GPU (seed = 1 + rank); "
+                               f"throughput of {B} independent time-steps per enqueue, not a per-frame latency",
                    "grid": N, "steps_per_enqueue": B, "tiles": world, "semantics": "MW_SEM_FFTMESH",
-                   "parallelism": f"tile{world}"},
+                   "parallelism": f"tile{world}", "api": "mw_tiles_* (library-owned RCCL communicator)" if use_tiles else "mw_ocean_*"},
         "hbm_roofline_frac_whole_step": value / world * BYTES_PER_POINT / HBM_PEAK,
+        "hbm_real_frac_whole_step": (value / world * phys_pt / HBM_PEAK) if phys_pt else None,
+        "physical_bytes_per_point_whole_step": phys_pt,
         "roofline": roofline,
         "parity": parity,
     }
-    if gather_ms is not None:
-        out["gather_last_step_ms"] = gather_ms
+    if el_gather is not None:
+        out["with_gather"] = {"value": world * a.steps * NN / el_gather, "ms_per_step": el_gather / a.steps * 1e3,
+                              "gathers": gathers[0], "bytes_per_gather_per_tile": NN * 28,
+                              "what": "the same K steps with the library's RCCL gather of every batch's last step to rank 0 "
+                                      "(mw_tiles_gather: ncclSend/ncclRecv on the side stream behind an event)"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        h0, h0c = ocean.get_spectrum()
-        out["cpu_baseline"] = cpu_baseline(p, h0, h0c)
+        if h0 is None:
+            h0, h0c = ocean.get_spectrum()
+        out["cpu_baseline"] = cpu_baseline_ocean(p, h0, h0c, gpu_step)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    ocean.close()
+    if tiles is not None:
+        tiles.close()
+    if ocean is not None:
+        ocean.close()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -266,6 +357,7 @@ def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):
     + 16 (re-read by the normal/whitecap passes) + 16 (normal, white out) = 120."""
     import ctypes as C
     from mistral_water import _native as nat
+    from oracle import oracle as O
     o = mw.Ocean(resolution=128, length=434.48, wind=(14.45, 12.0), amplitude=0.41, choppiness=0.46, mult=1.5,
                  seed=1 + rank, semantics=mw.MW_SEM_OCEANRENDERER, device=dev.index)
     o.set_stream(stream.cuda_stream)
@@ -283,16 +375,33 @@ def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     barrier()
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # the oracle's restatement of the shader pipeline (oracle/ocean_renderer_oracle.c: dispersion, spectrum, normal and
+        # whitecap passes in C, the 2 x 20 Stockham blits through numpy's fft2), one core, whole frames of the same texture
+        rp = O.RendererParams(resolution=128, length=434.48, wind_x=14.45, wind_y=12.0, amplitude=0.41, choppiness=0.46, mult=1.5)
+        init4 = O.renderer_initial_spectrum(rp, 1)
+        ph = np.zeros((M, M), np.float32)
+        O.renderer_step_f64(rp, init4, ph, 1.0 / 60.0, literal_passes=False)
+        t1 = time.perf_counter()
+        frames = 3
+        for _ in range(frames):
+            O.renderer_step_f64(rp, init4, ph, 1.0 / 60.0, literal_passes=False)
+        elc = (time.perf_counter() - t1) / frames
+        cpu = {"value": M * M / elc, "unit": "texels/s", "cores": 1, "kind": "port",
+               "sample": f"{frames} whole GenerateTexture() frames of the same 1024^2 texture through oracle/ocean_renderer_oracle.c "
+                         f"(+ numpy fft2 for the Stockham blits), {elc:.2f} s per frame; host has {os.cpu_count()} cores"}
     if rank == 0:
         v = world * a.steps * M * M / el
         print(json.dumps({
             "metric": "OceanRenderer-semantics texels/sec (dispersion+spectrum -> 2-D Stockham -> normal -> whitecap), 1024^2",
             "value": v, "unit": "texels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "config": {"workload": "OceanRenderer GenerateTexture(), 1024x1024 textures, shipped demo parameters",
+            "data": "synthetic", "config": {"workload": "OceanRenderer GenerateTexture(), 1024x1024 textures, shipped demo parameters "
+                                                        "(length 434.48, wind (14.45, 12), amplitude 0.41, choppiness 0.46)",
                                             "semantics": "MW_SEM_OCEANRENDERER"},
-            "roofline": {"bound": "hbm", "kernel": "whole frame (3 kernels)", "achieved": v * 120 / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": v * 120 / HBM_PEAK, "traffic": None}, "cpu_baseline": None}))
+            "roofline": {"bound": "hbm", "kernel": "whole frame (3 kernels)", "achieved": v * BYTES_RENDERER / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": v * BYTES_RENDERER / HBM_PEAK, "traffic": None}, "cpu_baseline": cpu}))
     o.close()
 
 
@@ -329,8 +438,8 @@ def pond(a, mw, torch, dev, stream, barrier, dist, rank, world):
 
     # parity gate on a sample of the lattice, first and last step of one launch
     parity = None
+    from oracle import oracle as O
     if rank == 0 and not a.no_parity:
-        from oracle import oracle as O
         run(B, 0)
         torch.cuda.synchronize()
         idx = np.random.default_rng(0).integers(0, nv, 4096)
@@ -356,8 +465,39 @@ def pond(a, mw, torch, dev, stream, barrier, dist, rank, world):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     step_us = e0.elapsed_time(e1) * 1e3 / a.steps
-    ach = BYTES_POND * nv / (step_us * 1e-6)
     real = (12.0 / B + 12.0) * nv / (step_us * 1e-6)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # CPU_GERSTNER: the shader's own float32 arithmetic (oracle/gerstner_oracle.c), whole
+        # 1M-vertex steps, one thread and all host cores (the lattice split into contiguous ranges, GIL released in C)
+        from concurrent.futures import ThreadPoolExecutor
+        hp = np.ascontiguousarray(pos.cpu().numpy(), np.float32)
+        ho = np.empty_like(hp)
+        args = (W, P["amplitude"], P["frequency"], P["steepness"])
+
+        def step_cpu(nthreads, t):
+            if nthreads == 1:
+                O.gerstner_f32_range(hp, 0, nv, *args, t, ho)
+                return
+            cuts = np.linspace(0, nv, nthreads + 1).astype(np.int64)
+            with ThreadPoolExecutor(nthreads) as ex:
+                list(ex.map(lambda i: O.gerstner_f32_range(hp, int(cuts[i]), int(cuts[i + 1]), *args, t, ho), range(nthreads)))
+
+        def time_cpu(nthreads, reps):
+            step_cpu(nthreads, 0.0)
+            t1 = time.perf_counter()
+            for r in range(reps):
+                step_cpu(nthreads, (r + 1) / 60.0)
+            return (time.perf_counter() - t1) / reps
+        el1 = time_cpu(1, 5)
+        cores = host_cores()
+        cands = sorted({c for c in (cores, cores // 2, cores // 4, 32, 16, 8) if 1 < c <= cores}) or [1]
+        eln, bestn = min((time_cpu(c, 5), c) for c in cands)
+        cpu = {"value": nv / el1, "unit": "vertices/s", "cores": 1, "kind": "port",
+               "sample": f"5 whole steps of the same 1M-vertex, 8-wave lattice through the float32 restatement of Gerstner() "
+                         f"(oracle/gerstner_oracle.c), {el1 * 1e3:.0f} ms per step; host has {os.cpu_count()} cores",
+               "all_cores": {"value": nv / eln, "unit": "vertices/s", "cores": bestn,
+                             "what": f"the same split over host threads; best of {cands} on the {cores}-core host"}}
     if rank == 0:
         print(json.dumps({
             "metric": "pond Gerstner vertices/sec (1M vertices, 8 waves)", "value": world * a.steps * nv / el,
@@ -368,10 +508,9 @@ def pond(a, mw, torch, dev, stream, barrier, dist, rank, world):
             "roofline": {"bound": "hbm", "kernel": "k_gerstner_steps<8>" if B > 1 else "k_gerstner",
                          "achieved": real / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": real / HBM_PEAK, "traffic": None,
                          "us_per_step": step_us,
-                         "note": f"one launch of {B} time values must move 12 B/vertex of positions once and 12 B/vertex per "
-                                 f"step of results: (12/{B} + 12) B/vertex/step.  At SURVEY 8d's per-step figure of 24 B/vertex "
-                                 f"(position read counted every step) the same time is {ach / 1e9:.0f} GB/s"},
-            "parity": parity, "cpu_baseline": None}))
+                         "note": f"one launch of {B} time values moves 12 B/vertex of positions once and 12 B/vertex per step of "
+                                 f"results: (12/{B} + 12) B/vertex/step is what the kernel must and does move"},
+            "parity": parity, "cpu_baseline": cpu}))
 
 
 if __name__ == "__main__":

@@ -27,3 +27,25 @@ void orc_gerstner_f64(const float* pos_xyz, int64_t nverts, const float* waves, 
         out_xyz[3 * v + 2] = z + oz;
     }
 }
+
+/* The same in the shader's own arithmetic (float32; sinf/cosf): the "CPU_GERSTNER" baseline of BASELINE.md section 4 --
+ * what a CPU port of W/MistralWaterLib.cginc:71-99 costs per vertex.  Vertices [v0, v1) so that callers can split a lattice
+ * across host threads. */
+void orc_gerstner_f32_range(const float* pos_xyz, int64_t v0, int64_t v1, const float* waves, int nwaves, float amplitude,
+                            float frequency, float steepness, float t, float* out_xyz) {
+    for (int64_t v = v0; v < v1; v++) {
+        float x = pos_xyz[3 * v], y = pos_xyz[3 * v + 1], z = pos_xyz[3 * v + 2];
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        for (int i = 0; i < nwaves; i++) {
+            float dx = waves[3 * i], dy = waves[3 * i + 1], sp = waves[3 * i + 2];
+            float th = frequency * (dx * x + dy * z) + t * sp;
+            float c = cosf(th), s = sinf(th);
+            ox += c * steepness * amplitude * dx;
+            oz += c * steepness * amplitude * dy;
+            oy += s;
+        }
+        out_xyz[3 * v] = x + ox;
+        out_xyz[3 * v + 1] = y + amplitude * oy;
+        out_xyz[3 * v + 2] = z + oz;
+    }
+}

@@ -300,6 +300,13 @@ def gerstner_f64(pos_xyz, waves, amplitude, frequency, steepness, t):
     return out
 
 
+def gerstner_f32_range(pos_xyz, v0, v1, waves, amplitude, frequency, steepness, t, out):
+    """CPU_GERSTNER baseline: the shader's float32 arithmetic on vertices [v0, v1); releases the GIL."""
+    wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)
+    lib().orc_gerstner_f32_range(_fp(pos_xyz), C.c_int64(v0), C.c_int64(v1), _fp(wv), C.c_int(wv.shape[0]), C.c_float(amplitude),
+                                 C.c_float(frequency), C.c_float(steepness), C.c_float(t), _fp(out))
+
+
 class PondParams(C.Structure):
     """Material properties of the pond shader (W/MistralWaterLib.cginc:53-66); layout of mw_pond_params."""
     _fields_ = [("mode", C.c_int32), ("amplitude", C.c_float), ("frequency", C.c_float), ("speed", C.c_float),
