@@ -223,6 +223,9 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
  * (S/FFTMesh.cs:146,183) is compared bit for bit with the oracle.  mw_debug_get_omega: the stored table in its
  * transposed [j][i] layout.  mw_debug_sincos: the library's range-reduced sin/cos on n host floats.            */
 mw_status mw_debug_omega_t(mw_ocean* o, float t, float* out_host);
+/* one EvaluateWaves(t) that also returns hds [N*N*2] = (d.x, d.z) of S/FFTMesh.cs:247 as the kernels hold it: the whitecap
+ * stage (forward differences, edge rules :258-274, halo rows between workgroups) is then checked bit for bit           */
+mw_status mw_debug_evaluate_hds(mw_ocean* o, float t, float* vertices_xyz, float* normals_xyz, float* colors_rgba, float* hds_xy);
 mw_status mw_debug_get_omega(mw_ocean* o, float* out_host);
 mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host);
 /* the pond kernels' hardware-sine variant (v_sin_f32 / v_cos_f32 after an exact revolution count) */

@@ -397,6 +397,7 @@ struct P2Args {
     float* white;     // [step][N*N*white_stride]
     int white_stride; // 1 (scalar) or 4 (Unity Color, S/FFTMesh.cs:274)
     OceanConsts c;
+    cf* hds_dump = nullptr;  // test hook (mw_debug_evaluate_hds): hds = (d.x, d.z) of S/FFTMesh.cs:247 as [step][a*N + b], else NULL
 };
 
 template <int N, int P>
@@ -558,6 +559,15 @@ MW_HD void p2_publish_hds(int tid, const ST& st, cf* lds) {
     cf* row = lds + g * P2Buf<N, P>::BUFSTRIDE;
 #pragma unroll
     for (int q = 0; q < P; q++) row[u + T * q] = st.d[q];
+}
+
+// test hook (P2Args::hds_dump, kernels instantiated with DUMP = true only for mw_debug_evaluate_hds): the R2 published hds
+// rows of this block, LDS -> global.  The product kernels (DUMP = false) contain none of it: even a never-taken branch
+// changed the register allocation of the 2-virtual-thread kernels (256 VGPRs -> spills).
+template <int N, int P, int R2>
+MW_HD void p2_dump_hds(const P2Args& A, int ab, int step, int lane, int nlanes, const cf* lds) {
+    cf* out = A.hds_dump + (size_t)step * N * N + (size_t)ab * R2 * N;
+    for (int i = lane; i < R2 * N; i += nlanes) out[i] = lds[(i / N) * P2Buf<N, P>::BUFSTRIDE + (i % N)];
 }
 
 // S/FFTMesh.cs:243-247: the displaced vertex

@@ -185,7 +185,7 @@ __device__ __forceinline__ int p2_row_block(int b) {
     return (XG > 1 && NBLK % (8 * XG) == 0) ? (cidx / XG) * (8 * XG) + xcd * XG + (cidx % XG) : b;
 }
 
-template <int N, int P, int R2>
+template <int N, int P, int R2, bool DUMP = false>
 __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(P == 8 ? MW_WAVES_P2 : 3))) void k_pass2(
     P2Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -262,6 +262,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
     MW_STAMP(1, 25);
     if (p2_active<N, P, R2>(ab, tid, 1)) p2_publish_hds<N, P, R2>(tid, st, set0 + cur * G::SETSTRIDE);
     __syncthreads();
+    if constexpr (DUMP) p2_dump_hds<N, P, R2>(A, ab, step, tid, G::NTHREADS, set0 + cur * G::SETSTRIDE);  // test hook
     MW_STAMP(1, 26);
     if (g < R2) p2_epilogue<N, P, R2>(A, ab, step, tid, st, set0 + cur * G::SETSTRIDE, noise_lds);
     MW_STAMP(1, 27);
@@ -295,7 +296,7 @@ constexpr int hs_min_waves(int nthreads, int lds_bytes) {
     const int w = nthreads / 64 * wgs / 4;
     return w < 1 ? 1 : (w > 8 ? 8 : w);
 }
-template <int N, int P, int R2, int VT>
+template <int N, int P, int R2, int VT, bool DUMP = false>
 __global__ __launch_bounds__((P2Geom<N, P, R2, true>::NTHREADS / VT))
 __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS / VT, P2Geom<N, P, R2, true>::LDS_BYTES)))) void k_pass2_hs(P2Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -366,6 +367,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
 #pragma unroll
         MW_VT(h) p2_publish_hds<N, P, R2>(MW_VTID(h), st[h], set0);  // every row into its own buffer, plain index b
         __syncthreads();
+        if constexpr (DUMP) p2_dump_hds<N, P, R2>(A, ab, step, tid0, NT, set0);  // test hook
         const bool has_halo = (ab * R2 + R2 < N);  // block-uniform
         // Rows 0..R2-2 have their (a+1) neighbour published already: they form 1 - J now.  Buffer 0 (row 0's copy) is
         // then free for the halo row's transform; row R2-1 waits for it and works from its own published copy, so that
@@ -557,7 +559,7 @@ static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nstep
         k_pass1<N, P, VT><<<dim3(GX, nsteps), dim3(NT), LB, st>>>(A, tm);
     return hipGetLastError();
 }
-template <int N>
+template <int N, bool DUMP>
 static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     constexpr int P = Plan<N>::P2, R2 = Plan<N>::R2;
     constexpr bool HS = Plan<N>::HS;
@@ -566,15 +568,15 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     static AttrOnce attr;
     {
         const void* fn;
-        if constexpr (HS) fn = reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, VT>);
-        else fn = reinterpret_cast<const void*>(&k_pass2<N, P, R2>);
+        if constexpr (HS) fn = reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, VT, DUMP>);
+        else fn = reinterpret_cast<const void*>(&k_pass2<N, P, R2, DUMP>);
         hipError_t e = attr.set(fn, LB);
         if (e != hipSuccess) return e;
     }
     if constexpr (HS)
-        k_pass2_hs<N, P, R2, VT><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
+        k_pass2_hs<N, P, R2, VT, DUMP><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
     else
-        k_pass2<N, P, R2><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
+        k_pass2<N, P, R2, DUMP><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
     return hipGetLastError();
 }
 
@@ -604,12 +606,14 @@ static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipS
     if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pass1 launch: ") + hipGetErrorString(e));
     return MW_OK;
 }
-static mw_status launch_pass2(mw_ocean* o, int nsteps, float* dv, float* dn, float* dw, int white_stride) {
+static mw_status launch_pass2(mw_ocean* o, int nsteps, float* dv, float* dn, float* dw, int white_stride, cf* hds_dump = nullptr) {
     P2Args A;
     A.E = o->E; A.Cj0 = o->Cj0; A.TW = o->TW2; A.vertices = dv; A.normals = dn; A.white = dw; A.white_stride = white_stride;
+    A.hds_dump = hds_dump;
     A.c = consts_of(o);
     hipError_t e = hipSuccess;
-    MW_DISPATCH_N(o->N, e = launch_pass2_n<NN>(A, nsteps, o->stream));
+    if (hds_dump) { MW_DISPATCH_N(o->N, (e = launch_pass2_n<NN, true>(A, nsteps, o->stream))); }
+    else { MW_DISPATCH_N(o->N, (e = launch_pass2_n<NN, false>(A, nsteps, o->stream))); }
     if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pass2 launch: ") + hipGetErrorString(e));
     return MW_OK;
 }
@@ -1138,6 +1142,38 @@ mw_status mw_debug_omega_t(mw_ocean* o, float t, float* out_host) {
     hipError_t e = hipStreamSynchronize(o->stream);
     hipFree(d);
     return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, "mw_debug_omega_t failed");
+}
+
+// test hook: one EvaluateWaves(t) that also returns hds = (d.x, d.z) exactly as the kernels hold it (S/FFTMesh.cs:247), so
+// that the whitecap stage -- forward differences, the i = N-1 / j = N-1 edge rules (:258-274), the halo rows handed
+// between workgroups -- can be compared BIT FOR BIT with the oracle's float32 whitecap of the same hds and normals
+mw_status mw_debug_evaluate_hds(mw_ocean* o, float t, float* vertices_xyz, float* normals_xyz, float* colors_rgba, float* hds_xy) {
+    if (!o || !hds_xy) return fail(MW_EINVAL, "mw_debug_evaluate_hds: NULL argument");
+    if (o->sem != MW_SEM_FFTMESH) return fail(MW_ESTATE, "mw_debug_evaluate_hds: FFTMesh semantics only");
+    HIP_TRY(hipSetDevice(o->device));
+    const size_t NN = (size_t)o->N * o->N;
+    cf* dh = nullptr;
+    if (o->use_fft) {
+        void* buf = nullptr;
+        mw_status s = scratch_reserve(o, NN * sizeof(cf), &buf);
+        if (s != MW_OK) return s;
+        dh = static_cast<cf*>(buf);
+        if ((s = ensure_exchange(o, 1)) != MW_OK) return s;
+        StepTimes tm;
+        tm.t[0] = t;
+        if ((s = launch_pass1(o, tm, 1, o->stream)) != MW_OK) return s;
+        if ((s = launch_pass2(o, 1, o->s_vert, o->s_norm, o->s_white, 4, dh)) != MW_OK) return s;
+    } else {
+        mw_status s = mw_ocean_evaluate_device(o, &t, 1, o->s_vert, o->s_norm, o->s_white, MW_OUT_COLOR_RGBA);
+        if (s != MW_OK) return s;
+        dh = o->direct.hds;
+    }
+    if (vertices_xyz) HIP_TRY(hipMemcpyAsync(vertices_xyz, o->s_vert, NN * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (normals_xyz) HIP_TRY(hipMemcpyAsync(normals_xyz, o->s_norm, NN * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (colors_rgba) HIP_TRY(hipMemcpyAsync(colors_rgba, o->s_white, NN * 4 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipMemcpyAsync(hds_xy, dh, NN * sizeof(cf), hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
 }
 
 // test hooks: the stored omega table and the device sincos

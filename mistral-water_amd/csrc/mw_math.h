@@ -28,7 +28,22 @@ struct cf {
 MW_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
 MW_HD cf operator+(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
 MW_HD cf operator-(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
-MW_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// MW_FFT_STRICT (default): the transform's rounding is fixed by the SOURCE -- cmul writes its two fused multiply-adds out
+// and every butterfly below is compiled with FMA contraction off -- not by which a*b + c the optimiser happens to fuse in
+// one instantiation of a kernel template and not in another.  A transformed row is then the same bit pattern whichever
+// workgroup, thread mapping or kernel variant produced it: the halo row a workgroup transforms for its Jacobian IS the row
+// its owner stores (tests/test_gpu_parity.py::test_whitecap_stage_bit_exact_on_device), and the host emulation equals the
+// device up to the sine.
+#ifndef MW_FFT_STRICT
+#define MW_FFT_STRICT 1
+#endif
+MW_HD cf cmul(cf a, cf b) {
+#if MW_FFT_STRICT && !defined(MW_CMUL_NO_FMA)
+    return mk(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));  // the two FMAs written out
+#else
+    return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
+}
 MW_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
 MW_HD cf cconj(cf a) { return mk(a.x, -a.y); }
 template <int SGN>
@@ -171,6 +186,9 @@ MW_HD float uniform01(uint64_t seed, uint64_t counter) {  // in (0,1]
     return (float)((uint32_t)(bits >> 40) + 1u) * (1.0f / 16777216.0f);
 }
 
+#if MW_FFT_STRICT && defined(__clang__)
+#pragma clang fp contract(off)  // file scope: every function down to the matching pragma below
+#endif
 // ---- small in-register DFTs, natural-order in, natural-order out -------------------------
 // SGN = +1: kernel e^{+2 pi i nk/R} (unnormalised inverse);  SGN = -1: forward.
 template <int SGN>
@@ -440,6 +458,9 @@ MW_HD void final_stage(cf (&x)[P], int u, const cf* __restrict__ TF) {
     }
 }
 
+#if MW_FFT_STRICT && defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
 // ---- spectrum algebra (DESIGN.md "Hermitian packing") ---------------------------------------
 // h(k,t) = P e^{i th} + Q e^{-i th}
 MW_HD cf animate(float px, float py, float qx, float qy, float c, float s) {

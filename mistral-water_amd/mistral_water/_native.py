@@ -56,7 +56,10 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
            "-Wno-unused-value",
            # the SLP vectoriser's v_pk_* packing costs ~300 v_mov per kernel and 50 % more VGPRs
-           "-fno-slp-vectorize", "-o", LIB_PATH, os.path.join(CSRC_DIR, "mistral_water.hip")]
+           "-fno-slp-vectorize",
+           # the 2-virtual-thread kernels are ~20k IR instructions once their field loop is unrolled: above the default cap
+           # (16384) the pragma is ignored, the field index stays dynamic and the state arrays land in scratch
+           "-mllvm", "-pragma-unroll-threshold=1000000", "-o", LIB_PATH, os.path.join(CSRC_DIR, "mistral_water.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout, r.stderr)
@@ -136,6 +139,7 @@ def lib():
         "mw_pond_displace": (C.c_int, [C.POINTER(MwPondParams), f32p, C.c_int64, C.c_float, f32p, f32p, C.c_int32]),
         "mw_pond_displace_device": (C.c_int, [C.POINTER(MwPondParams), vp, C.c_int64, C.c_float, vp, vp, vp]),
         "mw_debug_omega_t": (C.c_int, [vp, C.c_float, f32p]),
+        "mw_debug_evaluate_hds": (C.c_int, [vp, C.c_float, f32p, f32p, f32p, f32p]),
         "mw_debug_get_omega": (C.c_int, [vp, f32p]),
         "mw_debug_sincos": (C.c_int, [f32p, C.c_int32, f32p, f32p]),
         "mw_debug_sincos_fast": (C.c_int, [f32p, C.c_int32, f32p, f32p]),
@@ -161,7 +165,7 @@ ABI_SYMBOLS = [
     "mw_ocean_evaluate_device", "mw_ocean_max_batch", "mw_ocean_generate_texture",
     "mw_ocean_generate_texture_device", "mw_host_register", "mw_host_unregister", "mw_ocean_generate_texture_rgba", "mw_ocean_generate_texture_rgba_device",
     "mw_ocean_displace_mesh", "mw_ocean_displace_mesh_device", "mw_ocean_profile_kernels", "mw_gerstner_displace",
-    "mw_gerstner_displace_device", "mw_gerstner_displace_steps_device", "mw_gerstner_max_steps", "mw_pond_displace", "mw_pond_displace_device", "mw_debug_omega_t", "mw_debug_get_omega", "mw_debug_sincos", "mw_debug_sincos_fast", "mw_debug_stream_read",
+    "mw_gerstner_displace_device", "mw_gerstner_displace_steps_device", "mw_gerstner_max_steps", "mw_pond_displace", "mw_pond_displace_device", "mw_debug_omega_t", "mw_debug_evaluate_hds", "mw_debug_get_omega", "mw_debug_sincos", "mw_debug_sincos_fast", "mw_debug_stream_read",
 ]
 
 

@@ -166,6 +166,14 @@ class Ocean:
         nat.check(nat.lib().mw_ocean_profile_kernels(self._h, nsteps, iters, ms, names, C.byref(nk)))
         return [(names[k].decode(), float(ms[k])) for k in range(nk.value)]
 
+    def debug_evaluate_hds(self, t: float):
+        """EvaluateWaves(t) plus hds [N*N, 2] exactly as the kernels hold it (test hook of the whitecap stage)."""
+        NN = self.N * self.N
+        v, n = np.empty((NN, 3), np.float32), np.empty((NN, 3), np.float32)
+        c, h = np.empty((NN, 4), np.float32), np.empty((NN, 2), np.float32)
+        nat.check(nat.lib().mw_debug_evaluate_hds(self._h, C.c_float(t), _p(v), _p(n), _p(c), _p(h)))
+        return v, n, c, h
+
     def debug_omega_t(self, t: float):
         out = np.empty((self.N, self.N), np.float32)
         nat.check(nat.lib().mw_debug_omega_t(self._h, C.c_float(t), _p(out)))

@@ -57,6 +57,75 @@ def test_fftmesh_256_vs_literal_f32_sample(mw, oracle):
     assert np.abs(n[idx] - nor).max() < 3e-4
 
 
+def test_fftmesh_1024_vs_literal_f32_sample(mw, oracle):
+    """BASELINE's headline size: the distance to the reference's literal float32 O(N^4) loop (S/FFTMesh.cs:192-220),
+    measured on 64 vertices of the 1024^2 bench workload (bench.py prints the same figure for its own sample)."""
+    p = workloads.fftmesh_params(1024)
+    h0, h0c = oracle.generate_spectrum(p, 1)
+    idx = np.sort(np.random.default_rng(1).choice(1024 * 1024, 64, replace=False)).astype(np.int32)
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        v, n, c = o.evaluate(1.0)
+    hd, nor = oracle.displacement_subset_f32(p, h0, h0c, 1.0, idx)
+    rest = oracle.rest_mesh(p)[0]
+    scale = np.abs(hd).max()
+    assert np.abs(v[idx, 1] - hd[:, 1]).max() < 3e-4 * scale
+    assert np.abs((rest[idx, 0] - v[idx, 0]) - hd[:, 0] * p.choppiness).max() < 3e-4 * scale
+    assert np.abs((rest[idx, 2] - v[idx, 2]) - hd[:, 2] * p.choppiness).max() < 3e-4 * scale
+    assert np.abs(n[idx] - nor).max() < 3e-4
+
+
+def test_fftmesh_survey_config2_literal_parameters(mw, oracle):
+    """SURVEY.md 8d config 2 with its literal parameters (amplitude 0.41, the shipped OceanRenderer value, on a 1024 m
+    patch): waves of hundreds of metres, normals nearly horizontal, whitecap saturated -- the relative tolerance must hold
+    there too (bench.py times the same model at an amplitude that keeps heights O(1 m), workloads.fftmesh_params)."""
+    p = oracle.Params(N=1024, unit_width=1.0, length=1024.0, wind_x=14.45, wind_y=12.0, amplitude=0.41, choppiness=0.46)
+    h0, h0c = oracle.generate_spectrum(p, 1)
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        g0, g0c = o.get_spectrum()
+        sc = np.abs(h0).max()
+        assert np.abs(g0 - h0).max() < 4e-6 * sc and np.abs(g0c - h0c).max() < 4e-6 * sc
+        o.set_spectrum(h0, h0c)
+        for t in (1.0 / 60.0, 1000.0 / 60.0):       # first and last of the config's 1000 steps
+            v, n, c = o.evaluate(t)
+            vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, t, return_hds=True)
+            assert np.abs(vf[:, 1]).max() > 50.0     # it really is the saturated regime
+            workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"config 2 literal, t={t}")
+
+
+@pytest.mark.parametrize("N,u,L", [(64, 1.0, 64.0), (256, 0.5, 128.0), (512, 1.0, 512.0), (1024, 1.0, 1024.0), (2048, 1.0, 2048.0),
+                                   (4096, 1.0, 4096.0), (12, 1.0, 12.39), (33, 0.9, 33.0)])
+def test_whitecap_stage_bit_exact_on_device(mw, oracle, N, u, L):
+    """The Jacobian / whitecap stage (S/FFTMesh.cs:251-276) is index and sign work once hds and the normals exist: forward
+    differences, the i = N-1 and j = N-1 edge rules, strict-float32 J, noise, SmoothStep.  With hds taken from the device
+    (mw_debug_evaluate_hds) the device's colours must equal the oracle's float32 whitecap of the SAME hds and normals bit
+    for bit -- in every kernel family (8 and 4 rows + halo group, sequential halo with virtual threads, direct sum), which
+    also proves that a halo row handed to the previous workgroup is the very row its owner computed."""
+    amp = 1.5e-8 * (1024.0 / N) ** 2 * u * u * 400.0          # steep enough that the mesh folds here and there
+    p = oracle.Params(N=N, unit_width=u, length=L, wind_x=14.45, wind_y=12.0, amplitude=amp if N >= 64 else 0.01, choppiness=1.3)
+    h0, h0c = oracle.generate_spectrum(p, 21)
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        for t in (0.0, 2.5):
+            v, n, c, hds = o.debug_evaluate_hds(t)
+            want = oracle.whitecap_f32(N, hds, n)
+            assert (c == want).all(), f"N={N} t={t}: {(c != want).sum()} colours differ"
+            cc = c[:, 0].reshape(N, N)
+            assert cc.min() >= 0 and cc.max() <= 1 + 2.0 ** -22    # -2t^3 + 3t^2 left to right in float32 can pass 1 by an ulp (:273)
+            if N >= 64:
+                assert cc.max() > 0.1 and cc.min() < 0.05       # not a saturated or empty field: the stage is exercised
+            # the hook runs a second instantiation of the same kernel templates (with the hds store compiled in): the same
+            # values up to the compiler's choice of fused multiply-adds in the butterflies
+            v2, n2, c2 = o.evaluate(t)
+            sc = np.abs(hds).max()
+            assert np.abs(v - v2).max() < 2e-6 * sc and np.abs(n - n2).max() < 2e-6 and np.abs(c - c2).max() < 2e-5 * max(1.0, sc)
+            # hds is what the vertices were displaced by (S/FFTMesh.cs:243-247), to the rounding of rest - d * choppiness
+            rest = oracle.rest_mesh(p)[0]
+            d = (rest[:, [0, 2]].astype(np.float64) - v[:, [0, 2]]) / p.choppiness
+            assert np.abs(d - hds).max() <= 2.0 ** -22 * np.abs(rest).max() / p.choppiness + 1e-7 * np.abs(hds).max()
+
+
 def test_fftmesh_random_inspector_settings(mw, oracle):
     """16 seeded random parameter sets (size, unit width, wind direction and speed, amplitude, choppiness, gravity, time,
     seed) with the library's OWN spectrum generation on both sides: device spectrum == oracle spectrum, then parity."""

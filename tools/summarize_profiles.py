@@ -11,7 +11,7 @@ pmc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        if "k_pass" in k or "gerstner" in k:
+        if any(t in k for t in ("k_pass", "gerstner", "k_or_", "k_pond")):
             pmc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
             pmc[k]["_dur_ns_" + row["Counter_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
 out = {"source": src, "bench_line": json.loads(bench_line[-1]) if bench_line else None, "pmc_mean_per_launch": {}}
@@ -23,7 +23,7 @@ for k, d in pmc.items():
             continue
         durs = d["_dur_ns_" + c]
         med = sorted(durs)[len(durs) // 2]
-        keep = [v for v, t in zip(vals, durs) if abs(t - med) <= 0.15 * med]
+        keep = [v for v, t in zip(vals, durs) if abs(t - med) <= 0.15 * med]   # launches of another size would skew a per-launch mean
         o[c] = sum(keep) / len(keep)
         o.setdefault("_launch_us", {})[c] = med / 1e3
     out["pmc_mean_per_launch"][k] = o
