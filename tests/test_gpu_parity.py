@@ -374,7 +374,15 @@ def test_golden_pond_and_renderer_fixtures(mw):
         v, n, c = o.displace_mesh()
     for got, key in ((H, "height_rgba"), (D, "disp_rgba")):
         assert np.abs(got - z[key]).max() < 3e-6 * np.abs(z[key]).max(), key
-    assert np.quantile(np.abs(Nn - z["normal_rgba"]), 0.999) < 1e-4 and np.quantile(np.abs(W - z["white_rgba"]), 0.999) < 1e-4
+    import or_bounds
+    from oracle import oracle as O
+    rpz = O.RendererParams(resolution=int(pr[0]), length=float(pr[1]), wind_x=float(pr[2]), wind_y=float(pr[3]), amplitude=float(pr[4]),
+                           choppiness=float(pr[5]), gravity=float(pr[6]), mult=float(pr[7]))
+    or_bounds.assert_normal_white_stage(O, rpz, H, D, Nn, W, tag="golden renderer frame")
+    Dz, Hz = z["disp_rgba"].astype(np.float64), z["height_rgba"].astype(np.float64)
+    or_bounds.assert_normal_white(Nn[..., :3], W[..., 0], z["normal_rgba"][..., :3].astype(np.float64), z["white_rgba"][..., 0].astype(np.float64),
+                                  float(pr[1]), Dz[..., 0], Dz[..., 1], Dz[..., 2], Hz[..., 0], got=(D[..., 0], D[..., 1], D[..., 2], H[..., 0]),
+                                  tag="golden renderer frame")
     assert np.abs(v - z["mesh_vertices"]).max() < 1e-5
     assert np.quantile(np.abs(n - z["mesh_normals"]), 0.98) < 1e-4 and np.quantile(np.abs(c - z["mesh_colors"]), 0.98) < 1e-4
 
