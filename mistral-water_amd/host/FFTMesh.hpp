@@ -45,6 +45,7 @@ public:
     // ---- additions: the constants the reference hard-codes, and what Unity supplies implicitly --------
     float gravity = 9.81f;  // G, S/FFTMesh.cs:52
     uint64_t seed = 1;      // the reference never seeds UnityEngine.Random
+    bool fixedSeed = false; // true: every regeneration reproduces the same sea (tests); false: a new one, like GenerateMesh
     int device = 0;
     Mesh mesh;
 
@@ -77,7 +78,11 @@ private:
         mw_params_default(&p, MW_SEM_FFTMESH);
         p.resolution = resolution; p.unit_width = unitWidth; p.length = length; p.wind_x = wind.x; p.wind_y = wind.y;
         p.amplitude = amplitude; p.choppiness = choppiness; p.gravity = gravity; p.t_division = tDivision;
-        p.seed = seed; p.device = device;
+        // GenerateMesh draws fresh UnityEngine.Random values every time it runs (S/FFTMesh.cs:114-116): each regeneration
+        // is a NEW sea state unless fixedSeed asks for reproducibility
+        p.seed = fixedSeed ? seed : seed + generation_;
+        generation_++;
+        p.device = device;
         check(mw_ocean_create(&p, &ocean_));
         const size_t nn = (size_t)resolution * resolution;
         mesh.vertices.resize(nn); mesh.normals.resize(nn); mesh.uv.resize(nn); mesh.colors.resize(nn);
@@ -86,6 +91,7 @@ private:
     }
     mw_ocean* ocean_ = nullptr;
     float timer_ = 0.f;
+    uint64_t generation_ = 0;
 };
 
 class OceanRenderer {
@@ -115,10 +121,13 @@ public:
         check(mw_ocean_rest_mesh(ocean_, &mesh.vertices[0].x, &mesh.normals[0].x, &mesh.uv[0].x, mesh.indices.data()));
     }
     void Update(float deltaTime) {  // S/OceanRenderer.cs:91-110
-        check(mw_ocean_set_choppiness(ocean_, choppiness));
-        GenerateTexture(deltaTime);
-        if (oldLength_ != length || oldWind_.x != wind.x || oldWind_.y != wind.y || oldAmplitude_ != amplitude)
-            Create();  // RenderInitial again with the same seeds (:98-109)
+        GenerateTexture(deltaTime);                            // with the values the materials carried into this frame (:93)
+        check(mw_ocean_set_choppiness(ocean_, choppiness));    // spectrumMat._Choppiness for the NEXT frame (:96)
+        if (oldLength_ != length || oldWind_.x != wind.x || oldWind_.y != wind.y || oldAmplitude_ != amplitude) {
+            // RenderInitial again with the same seeds (:98-109): the phase textures keep running
+            check(mw_ocean_reinit_spectrum(ocean_, length, wind.x, wind.y, amplitude, seed));
+            oldLength_ = length; oldWind_ = wind; oldAmplitude_ = amplitude;
+        }
     }
     void GenerateTexture(float deltaTime) {  // S/OceanRenderer.cs:216-316
         const size_t mm = (size_t)M_ * M_;
