@@ -31,11 +31,17 @@ MW_HD void gerstner_vertex(const GerstnerWaves& wv, int nwaves, float amplitude,
 }
 
 #if defined(__HIPCC__)
-// 4 vertices (= 3 x float4) per thread: every load/store is a 16-B access, lanes contiguous.
-__global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts,
+// 16-B alignment of every address a kernel forms by reinterpreting a float* as f4* (f4 is alignas(16)): the base pointers
+// and, for step-strided outputs, the step stride.  A torch view or a caller's sub-array need not have it: the launchers
+// then pass nvec = 0 and the scalar loop serves every vertex (correct at any alignment, ~2x slower).
+static inline bool mw_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// 4 vertices (= 3 x float4) per thread: every load/store is a 16-B access, lanes contiguous.  Vertices [0, nvec) take that
+// path (nvec a multiple of 4; 0 when the buffers are not 16-B aligned), [nvec, nverts) a scalar grid-stride loop.
+__global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts, int64_t nvec,
                                                   GerstnerWaves wv, int nwaves, float amplitude, float frequency,
                                                   float steepness, float t) {
-    const int64_t nquads = nverts >> 2;
+    const int64_t nquads = nvec >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquads; qd += stride) {
         const f4* p = reinterpret_cast<const f4*>(pos) + qd * 3;
@@ -49,10 +55,8 @@ __global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos,
         f4 r0 = {v[0], v[1], v[2], v[3]}, r1 = {v[4], v[5], v[6], v[7]}, r2 = {v[8], v[9], v[10], v[11]};
         o[0] = r0; o[1] = r1; o[2] = r2;
     }
-    // tail (nverts % 4) by the first few threads of block 0
-    const int64_t tail0 = nquads << 2;
-    if (blockIdx.x == 0 && threadIdx.x < (nverts - tail0)) {
-        const int64_t vtx = tail0 + threadIdx.x;
+    // the rest (nverts % 4, or everything when the buffers are not 16-B aligned): one vertex per thread and trip
+    for (int64_t vtx = nvec + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vtx < nverts; vtx += stride) {
         float ox, oy, oz;
         gerstner_vertex(wv, nwaves, amplitude, frequency, steepness, t, pos[3 * vtx], pos[3 * vtx + 1], pos[3 * vtx + 2], &ox,
                         &oy, &oz);
@@ -94,10 +98,10 @@ MW_HD void gerstner_step_vertex(const GerstnerWaves& wv, const GerstnerPhases& p
 
 #if defined(__HIPCC__)
 template <int NW>
-__global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts,
+__global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts, int64_t nvec,
                                                         GerstnerWaves wv, GerstnerPhases ph, int nsteps, float amplitude,
                                                         float frequency, float steepness) {
-    const int64_t nquads = nverts >> 2;
+    const int64_t nquads = nvec >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquads; qd += stride) {
         const f4* p = reinterpret_cast<const f4*>(pos) + qd * 3;
@@ -116,9 +120,7 @@ __global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict_
             po[0] = r0; po[1] = r1; po[2] = r2;
         }
     }
-    const int64_t tail0 = nquads << 2;  // nverts % 4 by the first few threads of block 0
-    if (blockIdx.x == 0 && threadIdx.x < (nverts - tail0)) {
-        const int64_t vtx = tail0 + threadIdx.x;
+    for (int64_t vtx = nvec + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vtx < nverts; vtx += stride) {  // see k_gerstner
         float sa[NW], ca[NW];
         gerstner_position_part<NW>(wv, frequency, pos[3 * vtx], pos[3 * vtx + 2], sa, ca);
         for (int step = 0; step < nsteps; step++) {
@@ -149,14 +151,16 @@ static inline hipError_t gerstner_launch_steps(const float* d_pos, int64_t nvert
             ph.cb[k * nwaves + i] = (float)cos(b);
             ph.sb[k * nwaves + i] = (float)sin(b);
         }
-    int64_t nquads = nverts >> 2;
-    int64_t blocks = (nquads + 255) / 256;
+    // the step stride of the output is nverts * 12 B: 16-B aligned for every step only when nverts % 4 == 0
+    const bool vec = mw_aligned16(d_pos) && mw_aligned16(d_out) && (nsteps == 1 || (nverts & 3) == 0);
+    const int64_t nvec = vec ? (nverts & ~(int64_t)3) : 0;
+    int64_t blocks = ((vec ? (nverts >> 2) : nverts) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (nwaves == 4)
-        k_gerstner_steps<4><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness);
+        k_gerstner_steps<4><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, nverts, nvec, wv, ph, nsteps, amplitude, frequency, steepness);
     else
-        k_gerstner_steps<8><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness);
+        k_gerstner_steps<8><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, nverts, nvec, wv, ph, nsteps, amplitude, frequency, steepness);
     return hipGetLastError();
 }
 #endif
@@ -170,11 +174,12 @@ static inline hipError_t gerstner_launch(const float* d_pos, int64_t nverts, con
         wv.dy[i] = i < nwaves ? waves[3 * i + 1] : 0.f;
         wv.speed[i] = i < nwaves ? waves[3 * i + 2] : 0.f;
     }
-    int64_t nquads = nverts >> 2;
-    int64_t blocks = (nquads + 255) / 256;
+    const bool vec = mw_aligned16(d_pos) && mw_aligned16(d_out);
+    const int64_t nvec = vec ? (nverts & ~(int64_t)3) : 0;
+    int64_t blocks = ((vec ? (nverts >> 2) : nverts) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
-    hipLaunchKernelGGL(k_gerstner, dim3((unsigned)blocks), dim3(256), 0, st, d_pos, d_out, nverts, wv, nwaves, amplitude,
+    hipLaunchKernelGGL(k_gerstner, dim3((unsigned)blocks), dim3(256), 0, st, d_pos, d_out, nverts, nvec, wv, nwaves, amplitude,
                        frequency, steepness, t);
     return hipGetLastError();
 }

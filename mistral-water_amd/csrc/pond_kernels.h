@@ -95,11 +95,12 @@ MW_HD void pond_vertex(const PondParams& P, float t, float px, float py, float p
 }
 
 #if defined(__HIPCC__)
-// 4 vertices (= 3 x float4) per thread: every load/store is a 16-B access, lanes contiguous.
+// 4 vertices (= 3 x float4) per thread: every load/store is a 16-B access, lanes contiguous.  Vertices [0, nvec) take that
+// path (nvec = 0 when a buffer is not 16-B aligned, gerstner_kernels.h), [nvec, nverts) a scalar grid-stride loop.
 template <bool NORMALS>
 __global__ __launch_bounds__(256) void k_pond(const float* __restrict__ pos, float* __restrict__ out, float* __restrict__ nrm,
-                                              int64_t nverts, PondParams P, float t) {
-    const int64_t nquads = nverts >> 2;
+                                              int64_t nverts, int64_t nvec, PondParams P, float t) {
+    const int64_t nquads = nvec >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquads; qd += stride) {
         const f4* p = reinterpret_cast<const f4*>(pos) + qd * 3;
@@ -117,9 +118,7 @@ __global__ __launch_bounds__(256) void k_pond(const float* __restrict__ pos, flo
             pn[0] = m0; pn[1] = m1; pn[2] = m2;
         }
     }
-    const int64_t tail0 = nquads << 2;  // nverts % 4 by the first few threads of block 0
-    if (blockIdx.x == 0 && threadIdx.x < (nverts - tail0)) {
-        const int64_t vtx = tail0 + threadIdx.x;
+    for (int64_t vtx = nvec + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vtx < nverts; vtx += stride) {
         float o[3], n[3];
         pond_vertex(P, t, pos[3 * vtx], pos[3 * vtx + 1], pos[3 * vtx + 2], o, n);
         out[3 * vtx] = o[0]; out[3 * vtx + 1] = o[1]; out[3 * vtx + 2] = o[2];
@@ -129,14 +128,15 @@ __global__ __launch_bounds__(256) void k_pond(const float* __restrict__ pos, flo
 
 static inline hipError_t pond_launch(const PondParams& P, const float* d_pos, int64_t nverts, float t, float* d_out,
                                      float* d_nrm, hipStream_t st) {
-    int64_t nquads = nverts >> 2;
-    int64_t blocks = (nquads + 255) / 256;
+    const bool vec = mw_aligned16(d_pos) && mw_aligned16(d_out) && (!d_nrm || mw_aligned16(d_nrm));
+    const int64_t nvec = vec ? (nverts & ~(int64_t)3) : 0;
+    int64_t blocks = ((vec ? (nverts >> 2) : nverts) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (d_nrm)
-        k_pond<true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, d_nrm, nverts, P, t);
+        k_pond<true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, d_nrm, nverts, nvec, P, t);
     else
-        k_pond<false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, nullptr, nverts, P, t);
+        k_pond<false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, nullptr, nverts, nvec, P, t);
     return hipGetLastError();
 }
 #endif

@@ -21,7 +21,12 @@ _LIB = None
 
 
 def build(force: bool = False) -> str:
-    """Compile liboracle.so with gcc (make)."""
+    """Compile liboracle.so with gcc (make).  MW_SANITIZE=1 selects the AddressSanitizer + UBSan build (liboracle_san.so;
+    the process must then run with libasan preloaded -- tests/test_sanitizers.py does that in a subprocess)."""
+    if os.environ.get("MW_SANITIZE") == "1":
+        so = os.path.join(_HERE, "liboracle_san.so")
+        subprocess.run(["make", "-C", _HERE, "liboracle_san.so"], check=True, capture_output=True)
+        return so
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)

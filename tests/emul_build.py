@@ -12,6 +12,13 @@ CSRC = os.path.join(os.path.dirname(HERE), "mistral-water_amd", "csrc")
 
 
 def build():
+    if os.environ.get("MW_SANITIZE") == "1":   # AddressSanitizer + UBSan build (tests/test_sanitizers.py, libasan preloaded)
+        so = os.path.join(HERE, "emul", "libemul_san.so")
+        deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+        if not (os.path.exists(so) and all(os.path.getmtime(d) <= os.path.getmtime(so) for d in deps)):
+            subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fno-omit-frame-pointer",
+                            "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", so, SRC], check=True)
+        return so
     deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if os.path.exists(SO) and all(os.path.getmtime(d) <= os.path.getmtime(SO) for d in deps):
         return SO

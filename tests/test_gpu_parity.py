@@ -426,6 +426,37 @@ def test_gerstner_time_batched(mw, oracle):
     assert e.value.status == mw.MW_EINVAL
 
 
+def test_pond_unaligned_device_views(mw, oracle):
+    """Device pointers that are NOT 16-byte aligned (a torch view starting one vertex into a buffer, a 1003-vertex step
+    stride): the kernels' float4 path must not be taken; results equal the aligned call bit for bit."""
+    import torch
+    P, W = workloads.POND, workloads.pond_waves8()
+    nv = 1003
+    pos = workloads.pond_lattice(40, seed=3)[:nv]
+    base = torch.zeros((nv + 1) * 3 + 4, dtype=torch.float32, device="cuda")
+    obuf = torch.zeros(3 * nv * 3 + 8, dtype=torch.float32, device="cuda")
+    for off in (1, 3):                                            # 4- and 12-byte offsets from a 16-B aligned base
+        dp = base[off:off + nv * 3]
+        dp.copy_(torch.from_numpy(pos).reshape(-1).cuda())
+        do = obuf[off:off + 3 * nv * 3]
+        assert dp.data_ptr() % 16 != 0 and do.data_ptr() % 16 != 0
+        times = [0.0, 3.25, 600.0]
+        mw.gerstner_displace_steps_device(dp.data_ptr(), nv, W, P["amplitude"], P["frequency"], P["steepness"], times, do.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = do.cpu().numpy().reshape(3, nv, 3)
+        for k, t in enumerate(times):
+            want = oracle.gerstner_f64(pos, W, P["amplitude"], P["frequency"], P["steepness"], t)
+            assert np.abs(got[k] - want).max() < 8e-6, (off, k)
+        mat = mw.PondMaterial(mode=mw.MW_POND_WAVE, **workloads.POND_MATERIAL)
+        nbuf = torch.zeros(nv * 3 + 8, dtype=torch.float32, device="cuda")
+        dn = nbuf[off + 2:off + 2 + nv * 3]
+        mat.displace_device(dp.data_ptr(), nv, 2.0, do.data_ptr(), dn.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ho, hn = mat.displace(pos, 2.0)
+        assert (do[:nv * 3].cpu().numpy().reshape(nv, 3) == ho).all() and (dn.cpu().numpy().reshape(nv, 3) == hn).all()
+
+
 def test_pond_material_displacement_modes(mw, oracle):
     """W/MistralWaterLib.cginc:154-180 Displacement() in its three modes (Wave with its finite-difference normal, Gerstner,
     GerstnerLevelOne) through mw_pond_displace, vs the f64 oracle (oracle/pond_oracle.c); 1M-vertex and ragged sizes."""
