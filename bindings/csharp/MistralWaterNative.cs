@@ -64,6 +64,8 @@ public static class MistralWaterNative
     // ---- lifecycle ----------------------------------------------------------------------------------------------
     [DllImport(Lib)] public static extern Status mw_ocean_create(ref Params p, out IntPtr ocean);
     [DllImport(Lib)] public static extern void mw_ocean_destroy(IntPtr ocean);
+    [DllImport(Lib)] public static extern Status mw_ocean_create_batch(ref Params p, int ntiles, out IntPtr ocean);
+    [DllImport(Lib)] public static extern int mw_ocean_batch_size(IntPtr ocean);
     [DllImport(Lib)] public static extern Status mw_ocean_set_stream(IntPtr ocean, IntPtr hipStream);
     [DllImport(Lib)] public static extern Status mw_ocean_use_own_stream(IntPtr ocean);
     [DllImport(Lib)] public static extern IntPtr mw_ocean_get_stream(IntPtr ocean);

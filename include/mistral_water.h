@@ -78,6 +78,14 @@ void mw_params_default(mw_params* p, int32_t semantics); /* Inspector defaults o
  * from params->seed (Phillips, S/FFTMesh.cs:149-166; Box-Muller htilde0, :168-176).                */
 mw_status mw_ocean_create(const mw_params* params, mw_ocean** out);
 void mw_ocean_destroy(mw_ocean* o);
+/* OceanRenderer semantics, `ntiles` independent oceans in ONE handle: tile k is the ocean of `params` with seed
+ * params->seed + k.  One 1024^2 frame is three launches of a few hundred workgroups -- latency-, not bandwidth-bound -- and
+ * the stateful phase (F/FFTCommon.cginc:101-104) forbids batching in time, so the tile axis is what fills the device: every
+ * GenerateTexture() of the handle advances all tiles in the same three launches.  Every OceanRenderer entry point of a
+ * batched handle takes / returns arrays with a leading tile axis ([ntiles][M*M*...], [ntiles][resolution^2*...] for
+ * mw_ocean_displace_mesh); the rest mesh is one mesh.  Per-tile results are identical to single handles of seed + k.     */
+mw_status mw_ocean_create_batch(const mw_params* params, int32_t ntiles, mw_ocean** out);
+int32_t mw_ocean_batch_size(const mw_ocean* o);
 
 /* Run all subsequent work of this handle on an existing hipStream_t (e.g. torch's current stream).  The argument means
  * what it says: NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is by default), as in

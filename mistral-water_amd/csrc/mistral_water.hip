@@ -697,9 +697,12 @@ void mw_ocean_destroy(mw_ocean* o) {
     delete o;
 }
 
-mw_status mw_ocean_create(const mw_params* params, mw_ocean** out) {
+static mw_status ocean_create_impl(const mw_params* params, int tiles, mw_ocean** out) {
     if (!params || !out) return fail(MW_EINVAL, "mw_ocean_create: NULL argument");
     *out = nullptr;
+    if (tiles < 1 || tiles > 64) return fail(MW_EINVAL, "mw_ocean_create_batch: ntiles must be in [1,64]");
+    if (tiles > 1 && params->semantics != MW_SEM_OCEANRENDERER)
+        return fail(MW_EINVAL, "mw_ocean_create_batch: OceanRenderer semantics only (FFTMesh batches in time, mw_ocean_evaluate_device)");
     if (params->semantics != MW_SEM_FFTMESH && params->semantics != MW_SEM_OCEANRENDERER)
         return fail(MW_EINVAL, "mw_ocean_create: unknown semantics");
     if (params->resolution < 2) return fail(MW_EINVAL, "mw_ocean_create: resolution must be >= 2");
@@ -755,7 +758,7 @@ mw_status mw_ocean_create(const mw_params* params, mw_ocean** out) {
         if (!is_pow2(M)) { mw_ocean_destroy(o); return fail(MW_ENOTPOW2, "OceanRenderer: 8*resolution must be a power of two"); }
         if (M < 64 || M > 4096) { mw_ocean_destroy(o); return fail(MW_EINVAL, "OceanRenderer: texture size must be in [64,4096]"); }
         o->N = M;
-        if ((s = or_create(o->orr, *params, M, o->stream)) != MW_OK) {
+        if ((s = or_create(o->orr, *params, M, o->stream, tiles)) != MW_OK) {
             std::string m = or_last_error();
             mw_ocean_destroy(o);
             return fail(s, m);
@@ -766,6 +769,10 @@ mw_status mw_ocean_create(const mw_params* params, mw_ocean** out) {
     *out = o;
     return MW_OK;
 }
+
+mw_status mw_ocean_create(const mw_params* params, mw_ocean** out) { return ocean_create_impl(params, 1, out); }
+mw_status mw_ocean_create_batch(const mw_params* params, int32_t ntiles, mw_ocean** out) { return ocean_create_impl(params, ntiles, out); }
+int32_t mw_ocean_batch_size(const mw_ocean* o) { return o ? (o->sem == MW_SEM_OCEANRENDERER ? o->orr.tiles : 1) : 0; }
 
 mw_status mw_ocean_set_stream(mw_ocean* o, void* hip_stream) {
     if (!o) return fail(MW_EINVAL, "NULL handle");
@@ -811,16 +818,17 @@ mw_status mw_ocean_reset_timer(mw_ocean* o) {
 mw_status mw_ocean_set_spectrum(mw_ocean* o, const float* h0_xy, const float* h0conj_xy) {
     if (!o || !h0_xy || !h0conj_xy) return fail(MW_EINVAL, "mw_ocean_set_spectrum: NULL argument");
     HIP_TRY(hipSetDevice(o->device));
-    const size_t bytes = sizeof(cf) * (size_t)o->N * o->N;
-    if (o->sem == MW_SEM_OCEANRENDERER) {  // initialTexture.rg / .ba, texel (px,py) at py*M + px
+    const int tiles = (o->sem == MW_SEM_OCEANRENDERER) ? o->orr.tiles : 1;
+    const size_t bytes = sizeof(cf) * (size_t)o->N * o->N * tiles;
+    if (o->sem == MW_SEM_OCEANRENDERER) {  // initialTexture.rg / .ba, texel (px,py) at py*M + px, tile-major
         void* buf = nullptr;
         mw_status s = scratch_reserve(o, 2 * align256(bytes), &buf);
         if (s != MW_OK) return s;
         cf *a = static_cast<cf*>(buf), *b = reinterpret_cast<cf*>(static_cast<char*>(buf) + align256(bytes));
         HIP_TRY(hipMemcpyAsync(a, h0_xy, bytes, hipMemcpyHostToDevice, o->stream));
         HIP_TRY(hipMemcpyAsync(b, h0conj_xy, bytes, hipMemcpyHostToDevice, o->stream));
-        k_or_set_init<<<dim3((unsigned)(((size_t)o->N * o->N + 255) / 256)), dim3(256), 0, o->stream>>>(o->N, a, b, o->orr.initT,
-                                                                                                   o->orr.phaseT);
+        k_or_set_init<<<dim3((unsigned)(((size_t)o->N * o->N + 255) / 256), tiles), dim3(256), 0, o->stream>>>(o->N, a, b, o->orr.initT,
+                                                                                                          o->orr.phaseT);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(o->stream));
         return MW_OK;
@@ -835,13 +843,14 @@ mw_status mw_ocean_set_spectrum(mw_ocean* o, const float* h0_xy, const float* h0
 mw_status mw_ocean_get_spectrum(mw_ocean* o, float* h0_xy, float* h0conj_xy) {
     if (!o || !h0_xy || !h0conj_xy) return fail(MW_EINVAL, "mw_ocean_get_spectrum: NULL argument");
     HIP_TRY(hipSetDevice(o->device));
-    const size_t bytes = sizeof(cf) * (size_t)o->N * o->N;
+    const int tiles = (o->sem == MW_SEM_OCEANRENDERER) ? o->orr.tiles : 1;
+    const size_t bytes = sizeof(cf) * (size_t)o->N * o->N * tiles;
     if (o->sem == MW_SEM_OCEANRENDERER) {
         void* buf = nullptr;
         mw_status s = scratch_reserve(o, 2 * align256(bytes), &buf);
         if (s != MW_OK) return s;
         cf *a = static_cast<cf*>(buf), *b = reinterpret_cast<cf*>(static_cast<char*>(buf) + align256(bytes));
-        k_or_get_init<<<dim3((unsigned)(((size_t)o->N * o->N + 255) / 256)), dim3(256), 0, o->stream>>>(o->N, o->orr.initT, a, b);
+        k_or_get_init<<<dim3((unsigned)(((size_t)o->N * o->N + 255) / 256), tiles), dim3(256), 0, o->stream>>>(o->N, o->orr.initT, a, b);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h0_xy, a, bytes, hipMemcpyDeviceToHost, o->stream));
         HIP_TRY(hipMemcpyAsync(h0conj_xy, b, bytes, hipMemcpyDeviceToHost, o->stream));
@@ -885,12 +894,12 @@ static mw_status phase_copy(mw_ocean* o, float* host_out, const float* host_in, 
     if (!o || (!host_out && !host_in)) return fail(MW_EINVAL, std::string(who) + ": NULL argument");
     if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, std::string(who) + ": OceanRenderer semantics only (FFTMesh state is the timer)");
     HIP_TRY(hipSetDevice(o->device));
-    const size_t MM = (size_t)o->N * o->N, bytes = MM * sizeof(float);
+    const size_t MM = (size_t)o->N * o->N, bytes = MM * sizeof(float) * o->orr.tiles;
     void* buf = nullptr;
     mw_status s = scratch_reserve(o, bytes, &buf);
     if (s != MW_OK) return s;
     float* tmp = static_cast<float*>(buf);
-    const dim3 grid((unsigned)((MM + 255) / 256)), block(256);
+    const dim3 grid((unsigned)((MM + 255) / 256), o->orr.tiles), block(256);
     if (host_out) {  // device [px][py] -> host texel order py*M + px
         k_or_phase_transpose<<<grid, block, 0, o->stream>>>(o->N, o->orr.phaseT, tmp);
         HIP_TRY(hipGetLastError());
@@ -994,7 +1003,7 @@ mw_status mw_ocean_generate_texture(mw_ocean* o, float delta_time, float* height
     if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_generate_texture: OceanRenderer semantics only");
     mw_status s = mw_ocean_generate_texture_device(o, delta_time, nullptr, nullptr, nullptr, nullptr);
     if (s != MW_OK) return s;
-    const size_t MM = (size_t)o->N * o->N;
+    const size_t MM = (size_t)o->N * o->N * o->orr.tiles;
     if (height) HIP_TRY(hipMemcpyAsync(height, o->orr.out_height, MM * sizeof(float), hipMemcpyDeviceToHost, o->stream));
     if (disp_xz) HIP_TRY(hipMemcpyAsync(disp_xz, o->orr.out_disp, MM * 2 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
     if (normal_xyz) HIP_TRY(hipMemcpyAsync(normal_xyz, o->orr.out_normal, MM * 3 * sizeof(float), hipMemcpyDeviceToHost, o->stream));
@@ -1031,7 +1040,7 @@ mw_status mw_ocean_generate_texture_rgba(mw_ocean* o, float delta_time, float* h
     if (!o) return fail(MW_EINVAL, "NULL handle");
     if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_generate_texture_rgba: OceanRenderer semantics only");
     HIP_TRY(hipSetDevice(o->device));
-    const size_t bytes = (size_t)o->N * o->N * 4 * sizeof(float), stride = align256(bytes);
+    const size_t bytes = (size_t)o->N * o->N * 4 * sizeof(float) * o->orr.tiles, stride = align256(bytes);
     float* host[4] = {height_rgba, disp_rgba, normal_rgba, white_rgba};
     float* dev[4] = {nullptr, nullptr, nullptr, nullptr};
     void* buf = nullptr;
@@ -1060,7 +1069,7 @@ mw_status mw_ocean_displace_mesh(mw_ocean* o, float* vertices_xyz, float* normal
     if (!o || !vertices_xyz) return fail(MW_EINVAL, "mw_ocean_displace_mesh: NULL argument");
     if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_displace_mesh: OceanRenderer semantics only");
     HIP_TRY(hipSetDevice(o->device));
-    const size_t nv = (size_t)o->p.resolution * o->p.resolution, b3 = align256(nv * 3 * sizeof(float));
+    const size_t nv = (size_t)o->p.resolution * o->p.resolution * o->orr.tiles, b3 = align256(nv * 3 * sizeof(float));
     void* buf = nullptr;
     mw_status s = scratch_reserve(o, 2 * b3 + align256(nv * sizeof(float)), &buf);
     if (s != MW_OK) return s;

@@ -26,8 +26,13 @@ struct AttrOnce {
     }
 };
 
+// `tiles` independent oceans (seed, seed + 1, ...) share one handle: every buffer below carries a leading tile axis and
+// every kernel one more grid dimension, so a GenerateTexture() of all tiles is still three launches (mw_ocean_create_batch).
+// A frame of ONE 1024^2 texture is latency-bound (three launches of 256-768 workgroups); the phase recurrence forbids
+// batching in time, so the tile axis is what fills the machine.  omT (a function of k alone) is shared by the tiles.
 struct OrState {
     int M = 0;
+    int tiles = 1;
     OrConsts c{};
     float mult = 1.f, choppiness = 0.f;
     f4* initT = nullptr;
@@ -52,14 +57,18 @@ __global__ void k_or_init(int M, float length, float wind_x, float wind_y, float
                           float* phaseT) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * M) return;
+    const size_t toff = (size_t)blockIdx.y * M * M;  // tile blockIdx.y: seed + tile
     // idx enumerates the transposed array (px major) so the writes coalesce
-    or_init_element(M, length, wind_x, wind_y, amp, gravity, seed, idx / M, idx % M, initT, phaseT);
+    or_init_element(M, length, wind_x, wind_y, amp, gravity, seed + blockIdx.y, idx / M, idx % M, initT + toff,
+                    phaseT ? phaseT + toff : nullptr);
 }
 
 // initialTexture <-> (h0, h0conj) arrays in the reference's texel order idx = py*M + px
 __global__ void k_or_set_init(int M, const cf* h0, const cf* h0c, f4* initT, float* phaseT) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * M) return;
+    const size_t toff = (size_t)blockIdx.y * M * M;
+    h0 += toff; h0c += toff; initT += toff; phaseT += toff;
     const int px = idx / M, py = idx % M;  // transposed enumeration: coalesced writes
     const cf a = h0[(size_t)py * M + px], b = h0c[(size_t)py * M + px];
     f4 v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
@@ -69,6 +78,8 @@ __global__ void k_or_set_init(int M, const cf* h0, const cf* h0c, f4* initT, flo
 __global__ void k_or_get_init(int M, const f4* initT, cf* h0, cf* h0c) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * M) return;
+    const size_t toff = (size_t)blockIdx.y * M * M;
+    initT += toff; h0 += toff; h0c += toff;
     const int py = idx / M, px = idx % M;
     const f4 v = initT[(size_t)px * M + py];
     h0[idx] = mk(v.x, v.y);
@@ -81,15 +92,24 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Arg
     using G = OrP1Geom<N, P>;
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = FftGeom<N, P>::T;
-    const int tid = threadIdx.x, jb = blockIdx.x, f = blockIdx.y;  // one field per block
+    // gridDim.y == 3: one field per block (a single texture is latency-bound: the three fields of a column job run as three
+    // concurrent blocks, each recomputing the cheap h~); gridDim.y == 1: the block does the three fields one after the other
+    // from ONE read of the spectrum and phase (a batched handle is bandwidth-bound: 24 instead of 41.5 B per texel read)
+    const int tid = threadIdx.x, jb = blockIdx.x;
+    const int f0 = gridDim.y == 1 ? 0 : (int)blockIdx.y, f1 = gridDim.y == 1 ? 3 : f0 + 1;
+    {   // tile blockIdx.z of a batched handle
+        const size_t toff = (size_t)blockIdx.z * N * N;
+        A.initT += toff; A.phase_in += toff; A.phase_out += toff; A.E += 3 * toff;
+    }
     const int w = tid / T, u = tid % T;
     for (int i = tid; i < TwGeom<N, P>::LDS_CF; i += G::NTHREADS) lds[i] = A.TW[i];
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     cf h[P], x[P];
-    or_p1_animate<N, P>(A, jb, tid, f == 0, h);
-    {
+    or_p1_animate<N, P>(A, jb, tid, f0 == 0, h);
+    for (int f = f0; f < f1; f++) {
         or_p1_build<N, P>(A, jb, tid, f, h, x);
+        if (f != f0) __syncthreads();  // the previous field's final-pass reads of the buffers are done
         stage0_store<N, P, -1>(x, u, set0 + w * G::BUFSTRIDE);
         __syncthreads();
 #pragma unroll
@@ -110,6 +130,12 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = FftGeom<N, P>::T;
     const int tid = threadIdx.x, ab = blockIdx.x;
+    {   // tile blockIdx.z of a batched handle
+        const size_t toff = (size_t)blockIdx.z * N * N;
+        A.E += 3 * toff; A.height += toff; A.disp += toff; A.disp_g += toff;
+        if (A.height_g) A.height_g += toff;
+        if (A.disp_a) A.disp_a += toff;
+    }
     for (int i = tid; i < TwGeom<N, P>::LDS_CF; i += G::NTHREADS) lds[i] = A.TW[i];
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
@@ -143,6 +169,10 @@ __global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float
     const unsigned blk = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
     int idx = blk * blockDim.x + threadIdx.x;
     if (idx >= c.M * c.M) return;
+    {   // tile blockIdx.y of a batched handle
+        const size_t toff = (size_t)blockIdx.y * c.M * c.M;
+        height += toff; disp += toff; disp_g += toff; normal += 3 * toff; white += toff;
+    }
     float nxz[2];
     or_normal_element(c, idx % c.M, idx / c.M, height, disp, disp_g, normal, nxz);
     or_white_element(c, idx % c.M, idx / c.M, disp, normal, white, nxz);
@@ -152,13 +182,17 @@ __global__ void k_or_pack_rgba(int M, const float* height, const float* height_g
                                const float* disp_a, const float* normal, const float* white, f4* H, f4* D, f4* Nn, f4* W) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)M * M) return;
-    or_pack_rgba_element(idx, height, height_g, disp, disp_g, disp_a, normal, white, H, D, Nn, W);
+    const size_t toff = (size_t)blockIdx.y * M * M;  // tile blockIdx.y
+    or_pack_rgba_element(idx, height + toff, height_g + toff, disp + toff, disp_g + toff, disp_a + toff, normal + 3 * toff, white + toff,
+                         H ? H + toff : nullptr, D ? D + toff : nullptr, Nn ? Nn + toff : nullptr, W ? W + toff : nullptr);
 }
 __global__ void k_or_displace_mesh(int M, int res, float unit_width, const float* height, const cf* disp, const float* normal,
                                    const float* white, float* vert, float* nrm, float* col) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= res * res) return;
-    or_mesh_vertex(M, res, unit_width, idx / res, idx % res, height, disp, normal, white, vert, nrm, col);
+    const size_t toff = (size_t)blockIdx.y * M * M, voff = (size_t)blockIdx.y * res * res;  // tile blockIdx.y
+    or_mesh_vertex(M, res, unit_width, idx / res, idx % res, height + toff, disp + toff, normal + 3 * toff, white + toff, vert + 3 * voff,
+                   nrm ? nrm + 3 * voff : nullptr, col ? col + voff : nullptr);
 }
 
 std::vector<cf> build_twiddle_table(int N, int P, int sgn);  // mistral_water.hip
@@ -170,21 +204,22 @@ static inline void or_free(OrState& s) {
     s = OrState();
 }
 
-static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStream_t st) {
+static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStream_t st, int tiles = 1) {
     s.M = M;
+    s.tiles = tiles;
     s.c.M = M; s.c.length = p.length; s.c.gravity = p.gravity; s.c.choppiness = p.choppiness; s.c.normal_length = p.length;
     s.mult = p.mult; s.choppiness = p.choppiness;
-    const size_t MM = (size_t)M * M;
+    const size_t MM = (size_t)M * M, TM = MM * (size_t)tiles;
     std::vector<cf> tab = build_twiddle_table(M, plan_points_host(M), -1);
 #define OR_ALLOC(ptr, bytes) if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { g_or_err = "OceanRenderer: hipMalloc failed"; return MW_ENOMEM; }
-    OR_ALLOC(s.initT, sizeof(f4) * MM) OR_ALLOC(s.phaseT, sizeof(float) * MM) OR_ALLOC(s.phaseT2, sizeof(float) * MM) OR_ALLOC(s.omT, sizeof(float) * MM) OR_ALLOC(s.TW, sizeof(cf) * tab.size())
-    OR_ALLOC(s.E, sizeof(cf) * 3 * MM) OR_ALLOC(s.out_height, sizeof(float) * MM) OR_ALLOC(s.out_disp_cf, sizeof(cf) * MM)
-    OR_ALLOC(s.out_disp_g, sizeof(float) * MM) OR_ALLOC(s.out_normal, sizeof(float) * 3 * MM) OR_ALLOC(s.out_white, sizeof(float) * MM)
+    OR_ALLOC(s.initT, sizeof(f4) * TM) OR_ALLOC(s.phaseT, sizeof(float) * TM) OR_ALLOC(s.phaseT2, sizeof(float) * TM) OR_ALLOC(s.omT, sizeof(float) * MM) OR_ALLOC(s.TW, sizeof(cf) * tab.size())
+    OR_ALLOC(s.E, sizeof(cf) * 3 * TM) OR_ALLOC(s.out_height, sizeof(float) * TM) OR_ALLOC(s.out_disp_cf, sizeof(cf) * TM)
+    OR_ALLOC(s.out_disp_g, sizeof(float) * TM) OR_ALLOC(s.out_normal, sizeof(float) * 3 * TM) OR_ALLOC(s.out_white, sizeof(float) * TM)
 #undef OR_ALLOC
     s.out_disp = reinterpret_cast<float*>(s.out_disp_cf);
     if (hipMemcpy(s.TW, tab.data(), sizeof(cf) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) { g_or_err = "twiddle upload failed"; return MW_EDEVICE; }
-    k_or_init<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(M, p.length, p.wind_x, p.wind_y, p.amplitude / 10000.f,
-                                                                       p.gravity, p.seed, s.initT, s.phaseT);
+    k_or_init<<<dim3((unsigned)((MM + 255) / 256), tiles), dim3(256), 0, st>>>(M, p.length, p.wind_x, p.wind_y, p.amplitude / 10000.f,
+                                                                              p.gravity, p.seed, s.initT, s.phaseT);
     k_or_omega<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(s.c, s.omT);
     if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_init launch failed"; return MW_EDEVICE; }
     return MW_OK;
@@ -195,8 +230,8 @@ static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStre
 static inline mw_status or_reinit(OrState& s, float length, float wind_x, float wind_y, float amplitude, uint64_t seed, hipStream_t st) {
     const size_t MM = (size_t)s.M * s.M;
     s.c.length = length;
-    k_or_init<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(s.M, length, wind_x, wind_y, amplitude / 10000.f, s.c.gravity,
-                                                                       seed, s.initT, nullptr);
+    k_or_init<<<dim3((unsigned)((MM + 255) / 256), s.tiles), dim3(256), 0, st>>>(s.M, length, wind_x, wind_y, amplitude / 10000.f,
+                                                                                s.c.gravity, seed, s.initT, nullptr);
     k_or_omega<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(s.c, s.omT);
     if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_init launch failed"; return MW_EDEVICE; }
     return MW_OK;
@@ -205,7 +240,8 @@ static inline mw_status or_reinit(OrState& s, float length, float wind_x, float 
 __global__ void k_or_phase_transpose(int M, const float* src, float* dst) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * M) return;
-    dst[idx] = src[(size_t)(idx % M) * M + idx / M];
+    const size_t toff = (size_t)blockIdx.y * M * M;  // tile blockIdx.y
+    (dst + toff)[idx] = (src + toff)[(size_t)(idx % M) * M + idx / M];
 }
 
 template <int N>
@@ -221,14 +257,14 @@ static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
     OrP1Args A1;
     A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.E = s.E; A1.c = s.c; A1.dt = dt;
     constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
-    k_or_pass1<N, P><<<dim3(N / 4, 3), dim3(NT1), LB1, st>>>(A1);
+    k_or_pass1<N, P><<<dim3(N / 4, s.tiles > 1 ? 1 : 3, s.tiles), dim3(NT1), LB1, st>>>(A1);
     std::swap(s.phaseT, s.phaseT2);
     OrP2Args A2;
     A2.E = s.E; A2.TW = s.TW; A2.height = s.out_height; A2.disp = s.out_disp_cf; A2.disp_g = s.out_disp_g; A2.c = s.c;
     A2.height_g = s.want_imag ? s.out_height_g : nullptr;
     A2.disp_a = s.want_imag ? s.out_disp_a : nullptr;
     constexpr int NT2 = OrP2Geom<N, P>::NTHREADS, LB2 = OrP2Geom<N, P>::LDS_BYTES;
-    k_or_pass2<N, P><<<dim3(N / 4, 2), dim3(NT2), LB2, st>>>(A2);
+    k_or_pass2<N, P><<<dim3(N / 4, 2, s.tiles), dim3(NT2), LB2, st>>>(A2);
     return hipGetLastError();
 }
 
@@ -238,7 +274,7 @@ static inline mw_status or_generate(OrState& s, float delta_time, float* d_heigh
     s.c.choppiness = s.choppiness;
     const float dt = delta_time * s.mult;  // S/OceanRenderer.cs:223
     if (s.want_imag && !s.out_height_g) {
-        const size_t bytes = sizeof(float) * (size_t)s.M * s.M;
+        const size_t bytes = sizeof(float) * (size_t)s.M * s.M * s.tiles;
         if (hipMalloc((void**)&s.out_height_g, bytes) != hipSuccess || hipMalloc((void**)&s.out_disp_a, bytes) != hipSuccess) {
             g_or_err = "OceanRenderer: hipMalloc failed";
             return MW_ENOMEM;
@@ -256,16 +292,18 @@ static inline mw_status or_generate(OrState& s, float delta_time, float* d_heigh
         default: g_or_err = "OceanRenderer: unsupported texture size"; return MW_EINVAL;
     }
     if (e != hipSuccess) { g_or_err = std::string("OceanRenderer pass launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
-    const size_t MM = (size_t)s.M * s.M;
+    const size_t MM = (size_t)s.M * s.M, TM = MM * (size_t)s.tiles;
     const unsigned nb = (unsigned)((MM + 255) / 256);
-    k_or_normal_white<<<dim3(nb), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white);
+    k_or_normal_white<<<dim3(nb, s.tiles), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white);
     if (hipGetLastError() != hipSuccess) { g_or_err = "OceanRenderer normal/white launch failed"; return MW_EDEVICE; }
     s.have_frame = true;
     s.have_imag = s.want_imag;
-    if (d_height) hipMemcpyAsync(d_height, s.out_height, MM * 4, hipMemcpyDeviceToDevice, st);
-    if (d_disp) hipMemcpyAsync(d_disp, s.out_disp_cf, MM * 8, hipMemcpyDeviceToDevice, st);
-    if (d_normal) hipMemcpyAsync(d_normal, s.out_normal, MM * 12, hipMemcpyDeviceToDevice, st);
-    if (d_white) hipMemcpyAsync(d_white, s.out_white, MM * 4, hipMemcpyDeviceToDevice, st);
+    hipError_t ce = hipSuccess;
+    if (d_height && ce == hipSuccess) ce = hipMemcpyAsync(d_height, s.out_height, TM * 4, hipMemcpyDeviceToDevice, st);
+    if (d_disp && ce == hipSuccess) ce = hipMemcpyAsync(d_disp, s.out_disp_cf, TM * 8, hipMemcpyDeviceToDevice, st);
+    if (d_normal && ce == hipSuccess) ce = hipMemcpyAsync(d_normal, s.out_normal, TM * 12, hipMemcpyDeviceToDevice, st);
+    if (d_white && ce == hipSuccess) ce = hipMemcpyAsync(d_white, s.out_white, TM * 4, hipMemcpyDeviceToDevice, st);
+    if (ce != hipSuccess) { g_or_err = std::string("OceanRenderer result copy: ") + hipGetErrorString(ce); return MW_EDEVICE; }
     return MW_OK;
 }
 
@@ -276,7 +314,7 @@ static inline mw_status or_generate_rgba(OrState& s, float delta_time, f4* d_hei
     mw_status r = or_generate(s, delta_time, nullptr, nullptr, nullptr, nullptr, st);
     if (r != MW_OK) return r;
     const size_t MM = (size_t)s.M * s.M;
-    k_or_pack_rgba<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(s.M, s.out_height, s.out_height_g, s.out_disp_cf,
+    k_or_pack_rgba<<<dim3((unsigned)((MM + 255) / 256), s.tiles), dim3(256), 0, st>>>(s.M, s.out_height, s.out_height_g, s.out_disp_cf,
                                                                               s.out_disp_g, s.out_disp_a, s.out_normal,
                                                                               s.out_white, d_height, d_disp, d_normal, d_white);
     if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_pack_rgba launch failed"; return MW_EDEVICE; }
@@ -288,7 +326,7 @@ static inline mw_status or_displace_mesh(OrState& s, int res, float unit_width, 
                                          hipStream_t st) {
     if (!s.have_frame) { g_or_err = "displace_mesh: no GenerateTexture() yet"; return MW_ESTATE; }
     const int nv = res * res;
-    k_or_displace_mesh<<<dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st>>>(s.M, res, unit_width, s.out_height,
+    k_or_displace_mesh<<<dim3((unsigned)((nv + 255) / 256), s.tiles), dim3(256), 0, st>>>(s.M, res, unit_width, s.out_height,
                                                                                  s.out_disp_cf, s.out_normal, s.out_white,
                                                                                  d_vert, d_nrm, d_col);
     if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_displace_mesh launch failed"; return MW_EDEVICE; }

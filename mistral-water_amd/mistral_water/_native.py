@@ -88,6 +88,8 @@ def lib():
         "mw_params_default": (None, [C.POINTER(MwParams), C.c_int32]),
         "mw_ocean_create": (C.c_int, [C.POINTER(MwParams), C.POINTER(vp)]),
         "mw_ocean_destroy": (None, [vp]),
+        "mw_ocean_create_batch": (C.c_int, [C.POINTER(MwParams), C.c_int32, C.POINTER(vp)]),
+        "mw_ocean_batch_size": (C.c_int32, [vp]),
         "mw_ocean_set_stream": (C.c_int, [vp, vp]),
         "mw_ocean_use_own_stream": (C.c_int, [vp]),
         "mw_ocean_reinit_spectrum": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint64]),
@@ -155,7 +157,7 @@ def lib():
 
 #: every symbol include/mistral_water.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [
-    "mw_abi_version", "mw_last_error", "mw_device_count", "mw_params_default", "mw_ocean_create", "mw_ocean_destroy",
+    "mw_abi_version", "mw_last_error", "mw_device_count", "mw_params_default", "mw_ocean_create", "mw_ocean_destroy", "mw_ocean_create_batch", "mw_ocean_batch_size",
     "mw_ocean_set_stream", "mw_ocean_use_own_stream", "mw_ocean_get_stream", "mw_ocean_synchronize", "mw_ocean_set_choppiness",
     "mw_ocean_set_spectrum", "mw_ocean_get_spectrum", "mw_ocean_reinit_spectrum", "mw_ocean_get_phase", "mw_ocean_set_phase",
     "mw_ocean_set_timer", "mw_comm_unique_id", "mw_tiles_create", "mw_tiles_create_rank", "mw_tiles_destroy", "mw_tiles_count",

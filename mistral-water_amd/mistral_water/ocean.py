@@ -23,12 +23,18 @@ class Ocean:
     """Thin RAII wrapper of an ``mw_ocean*``."""
 
     def __init__(self, *, resolution, unit_width=1.0, length=1.0, wind=(1.0, 1.0), amplitude=1.0, choppiness=1.0,
-                 gravity=9.81, t_division=1.0, mult=1.0, seed=1, semantics=nat.MW_SEM_FFTMESH, device=0):
+                 gravity=9.81, t_division=1.0, mult=1.0, seed=1, semantics=nat.MW_SEM_FFTMESH, device=0, ntiles=1):
+        """ntiles > 1 (OceanRenderer semantics): a batched handle, tile k = seed + k; every OceanRenderer array then carries a
+        leading tile axis (mw_ocean_create_batch)."""
         self._h = C.c_void_p()
         self.params = nat.MwParams(int(resolution), float(unit_width), float(length), float(wind[0]), float(wind[1]),
                                    float(amplitude), float(choppiness), float(gravity), float(t_division), float(mult),
                                    int(seed), int(semantics), int(device))
-        nat.check(nat.lib().mw_ocean_create(C.byref(self.params), C.byref(self._h)))
+        self.ntiles = int(ntiles)
+        if self.ntiles == 1:
+            nat.check(nat.lib().mw_ocean_create(C.byref(self.params), C.byref(self._h)))
+        else:
+            nat.check(nat.lib().mw_ocean_create_batch(C.byref(self.params), self.ntiles, C.byref(self._h)))
         self.N = nat.lib().mw_ocean_grid_size(self._h)
         self.mesh_resolution = int(resolution)
         self.semantics = int(semantics)
@@ -74,12 +80,16 @@ class Ocean:
     def set_spectrum(self, h0, h0conj):
         h0 = np.ascontiguousarray(h0, np.float32)
         h0conj = np.ascontiguousarray(h0conj, np.float32)
-        assert h0.size == 2 * self.N * self.N and h0conj.size == h0.size
+        assert h0.size == 2 * self.N * self.N * self.ntiles and h0conj.size == h0.size
         nat.check(nat.lib().mw_ocean_set_spectrum(self._h, _p(h0), _p(h0conj)))
 
+    def _t(self, *shape):
+        """Array shape with the leading tile axis of a batched handle."""
+        return ((self.ntiles,) if self.ntiles > 1 else ()) + tuple(shape)
+
     def get_spectrum(self):
-        h0 = np.empty((self.N, self.N, 2), np.float32)
-        h0c = np.empty((self.N, self.N, 2), np.float32)
+        h0 = np.empty(self._t(self.N, self.N, 2), np.float32)
+        h0c = np.empty(self._t(self.N, self.N, 2), np.float32)
         nat.check(nat.lib().mw_ocean_get_spectrum(self._h, _p(h0), _p(h0c)))
         return h0, h0c
 
@@ -97,13 +107,13 @@ class Ocean:
 
     def get_phase(self):
         """OceanRenderer: the stateful phase texture [M, M] (texel (px,py) at [py, px])."""
-        ph = np.empty((self.N, self.N), np.float32)
+        ph = np.empty(self._t(self.N, self.N), np.float32)
         nat.check(nat.lib().mw_ocean_get_phase(self._h, _p(ph)))
         return ph
 
     def set_phase(self, phase):
         ph = np.ascontiguousarray(phase, np.float32)
-        assert ph.size == self.N * self.N
+        assert ph.size == self.N * self.N * self.ntiles
         nat.check(nat.lib().mw_ocean_set_phase(self._h, _p(ph)))
 
     def set_timer(self, t: float):
@@ -182,10 +192,10 @@ class Ocean:
     # -- OceanRenderer semantics -------------------------------------------------------------
     def generate_texture(self, delta_time: float):
         M = self.N
-        h = np.empty((M, M), np.float32)
-        d = np.empty((M, M, 2), np.float32)
-        n = np.empty((M, M, 3), np.float32)
-        w = np.empty((M, M), np.float32)
+        h = np.empty(self._t(M, M), np.float32)
+        d = np.empty(self._t(M, M, 2), np.float32)
+        n = np.empty(self._t(M, M, 3), np.float32)
+        w = np.empty(self._t(M, M), np.float32)
         nat.check(nat.lib().mw_ocean_generate_texture(self._h, C.c_float(delta_time), _p(h), _p(d), _p(n), _p(w)))
         return h, d, n, w
 
@@ -194,7 +204,7 @@ class Ocean:
         (S/OceanRenderer.cs:143-146): height (Re h, Im h, Re h, Im h), displacement (Re Dx, Im Dx, Re Dz, Im Dz),
         normal (n, 1), white (w, w, w, 1)."""
         M = self.N
-        t = [np.empty((M, M, 4), np.float32) for _ in range(4)]
+        t = [np.empty(self._t(M, M, 4), np.float32) for _ in range(4)]
         nat.check(nat.lib().mw_ocean_generate_texture_rgba(self._h, C.c_float(delta_time), *[_p(a) for a in t]))
         return tuple(t)
 
@@ -202,7 +212,7 @@ class Ocean:
         """The ocean material's vertex stage (W/TestOcean.shader:61-79) on the resolution^2 mesh, from the textures
         of the latest generate_texture*(): -> (vertices [n,3], normals [n,3], colors [n])."""
         n = self.mesh_resolution * self.mesh_resolution
-        v, nr, c = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty(n, np.float32)
+        v, nr, c = np.empty(self._t(n, 3), np.float32), np.empty(self._t(n, 3), np.float32), np.empty(self._t(n), np.float32)
         nat.check(nat.lib().mw_ocean_displace_mesh(self._h, _p(v), _p(nr), _p(c)))
         return v, nr, c
 

@@ -237,3 +237,50 @@ def test_tiles_per_process_form_with_one_rank(mw):
     with mw.Ocean(seed=3, **kw) as o:
         v, n, c = o.evaluate(0.75)
     assert (got[:NN * 3].reshape(NN, 3) == v).all() and (got[NN * 6:] == c[:, 0]).all()
+
+
+def test_batched_oceanrenderer_handle_equals_single_handles(mw, oracle):
+    """mw_ocean_create_batch: ntiles independent oceans advanced by the same three launches per GenerateTexture(); every tile
+    must be, bit for bit, the single handle of seed + k (S/OceanRenderer.cs:216-316 per tile)."""
+    rp = shipped(resolution=16, length=60.0)
+    T = 3
+    kw = dict(resolution=rp.resolution, unit_width=0.75, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude,
+              choppiness=rp.choppiness, gravity=rp.gravity, mult=rp.mult, semantics=mw.MW_SEM_OCEANRENDERER)
+    with mw.Ocean(seed=5, ntiles=T, **kw) as b:
+        assert mw.lib().mw_ocean_batch_size(b.handle) == T
+        singles = [mw.Ocean(seed=5 + k, **kw) for k in range(T)]
+        g0, g0c = b.get_spectrum()
+        assert g0.shape == (T, rp.M, rp.M, 2)
+        for k, o in enumerate(singles):
+            s0, s0c = o.get_spectrum()
+            assert (g0[k] == s0).all() and (g0c[k] == s0c).all()
+        assert not (g0[0] == g0[1]).all()
+        for dt in (0.016, 0.3, 0.033):
+            H, D, Nn, W = b.generate_texture(dt)
+            for k, o in enumerate(singles):
+                h, d, n, w = o.generate_texture(dt)
+                assert (H[k] == h).all() and (D[k] == d).all() and (Nn[k] == n).all() and (W[k] == w).all(), (dt, k)
+        tex = b.generate_texture_rgba(0.05)
+        V, Nv, Cv = b.displace_mesh()
+        ph = b.get_phase()
+        for k, o in enumerate(singles):
+            t1 = o.generate_texture_rgba(0.05)
+            for a, c in zip(tex, t1):
+                assert (a[k] == c).all()
+            v, nv_, cv = o.displace_mesh()
+            assert (V[k] == v).all() and (Nv[k] == nv_).all() and (Cv[k] == cv).all()
+            assert (ph[k] == o.get_phase()).all()
+        # checkpoint of the whole batch into a fresh batched handle (tile-major arrays)
+        g0, g0c = b.get_spectrum()
+        want = b.generate_texture(0.02)
+        with mw.Ocean(seed=77, ntiles=T, **kw) as c:
+            c.set_spectrum(g0, g0c)
+            c.set_phase(ph)
+            got = c.generate_texture(0.02)
+        for x, y in zip(got, want):
+            assert (x == y).all()
+        for o in singles:
+            o.close()
+    with pytest.raises(mw.MistralWaterError) as e:              # FFTMesh batches in time, not in tiles
+        mw.Ocean(resolution=64, length=64.0, ntiles=2)
+    assert e.value.status == mw.MW_EINVAL
