@@ -411,6 +411,24 @@ MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
 #else
     const bool POWERS = (ALLOW_POW && TwGeom<N, P>::POW_STAGE != 0 && s == TwGeom<N, P>::POW_STAGE);  // folds: s is unrolled
 #endif
+#if defined(MW_TW_SHUFFLE) && defined(__HIP_DEVICE_COMPILE__)
+    // A/B experiment (BASELINE.json's "wavefront shuffle for the twiddle rows", profiles/r02_twiddle_shuffle_ab.json): the
+    // first radix-8 pass needs e^{SGN 2 pi i r k / 64}, r k < 64: ONE 64-entry row held across the wave (lane l keeps entry l
+    // in two VGPRs) and fetched by ds_bpermute -- two 32-bit permutes per complex twiddle instead of one ds_read_b64 of the
+    // LDS table.  Both go through the LDS crossbar; the permute form issues twice as many DS instructions.
+    if (P == 8 && s == 1) {
+        const int lane = (int)__lane_id();
+        float ws, wc;
+        sincospif((float)lane * (1.0f / 32.0f), &ws, &wc);
+        ws = SGN > 0 ? ws : -ws;
+#pragma unroll
+        for (int r = 1; r < P; r++) {
+            const int src = (r * k) & 63;
+            const cf w = mk(__shfl(wc, src), __shfl(ws, src));
+            x[r] = cmul(x[r], w);
+        }
+    } else
+#endif
     if (POWERS) {  // one table read per thread, the other P-2 twiddles as its powers (product tree <= log2 P deep)
         cf w[P];
         w[1] = row[1];
