@@ -27,6 +27,16 @@ struct StepTimes {
     float t[MW_MAX_BATCH];
 };
 
+// Exchange-buffer geometry.  E[step][f] is stored as [j / CW][a][j % CW]: CW spectrum columns x 16/CW rows make one 128-B
+// line, so a pass-1 workgroup that owns CW columns writes whole lines and a pass-2 workgroup that owns 16/CW * k rows reads
+// whole (or, for fewer rows, contiguous fractions of) lines.  CW = 4 everywhere except 4096^2, where four 4096-point columns
+// need 139 KiB of LDS (one workgroup per CU); with CW = 2 pass 1 is two 70-KiB workgroups per CU (MW_CW2_MIN_N, A/B in
+// DESIGN.md section 6).
+#ifndef MW_CW2_MIN_N
+#define MW_CW2_MIN_N 8192  // grids from this size up use CW = 2 (8192 = none)
+#endif
+template <int N> struct Exch { static constexpr int CW = (N >= MW_CW2_MIN_N) ? 2 : 4; };
+
 #ifndef MW_FAST_SINCOS
 #define MW_FAST_SINCOS 1  // hardware v_sin/v_cos after an exact reduction (1.8e-7 abs; +1 % at 1024^2, -4 % OceanRenderer frame time)
 #endif
@@ -270,14 +280,15 @@ MW_HD int p1_grid_blocks(int gx, int nsteps, int tgroup) {
 template <int N, int P>
 struct P1Geom {
     static constexpr int T = FftGeom<N, P>::T;
-    static constexpr int NTHREADS = 4 * T;
+    static constexpr int CW = Exch<N>::CW;  // spectrum columns per workgroup
+    static constexpr int NTHREADS = CW * T;
     static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4;
     static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;  // cf units, 16-B aligned
-    static constexpr int SETSTRIDE = 4 * BUFSTRIDE;
+    static constexpr int SETSTRIDE = CW * BUFSTRIDE;
     // 2: ping-pong exchange buffers, one barrier per exchange (when both sets fit a 100 KiB budget)
     static constexpr int NBUF = (MW_DBUF && (TW_LDS + 2 * SETSTRIDE) * 8 <= 100 * 1024) ? 2 : 1;
     static constexpr int LDS_BYTES = (TW_LDS + NBUF * SETSTRIDE) * (int)sizeof(cf);
-    static constexpr int GRID_X = N / 4 + 1;
+    static constexpr int GRID_X = N / CW + 1;
     static_assert(NTHREADS <= 1024, "workgroup too large: use P = 16 for this N");
 };
 
@@ -312,15 +323,16 @@ MW_HD void field_coeffs(int f, float kx, float kz, cf* cx, cf* cz) {
 // first 1-D transform its rows are Hermitian in j: T(a, N-j) = conj T(a, j).  Only columns j <= N/2 are
 // transformed and stored (blocks jb <= N/8); pass 2 rebuilds the other half by conjugation (p2_load).  The
 // Nyquist-column job (jb == N/4) has no height term at all.
-MW_HD bool p1_field_active(int N, int jb, int f) { return f != 0 || jb <= N / 8; }
+MW_HD bool p1_field_active(int N, int jb, int f, int cw = 4) { return f != 0 || jb <= N / (2 * cw); }
 
 // animated packed spectrum, P points per thread (column job w, i = u + T q)
 template <int N, int P>
 MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, P1State<P>& st) {
     constexpr int T = FftGeom<N, P>::T;
+    constexpr int CW = Exch<N>::CW;
     const int w = wave_uniform<(T % 64) == 0>(tid / T), u = tid % T;
-    const bool fix = (jb == N / 4);
-    const int j = fix ? 0 : 4 * jb + w;
+    const bool fix = (jb == N / CW);
+    const int j = fix ? 0 : CW * jb + w;
     const f4* __restrict__ pqrow = fix ? A.dPQ_j0 : A.PQt + (size_t)j * N;  // wave-uniform row base
     const float* __restrict__ omrow = A.Om + (size_t)j * N;
     const bool live = !fix || w == 0;
@@ -344,9 +356,10 @@ MW_HD void p1_animate(const P1Args& A, int jb, int tid, float t, P1State<P>& st)
 template <int N, int P>
 MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, const P1State<P>& st, cf (&x)[P]) {
     constexpr int T = FftGeom<N, P>::T;
+    constexpr int CW = Exch<N>::CW;
     const int w = tid / T, u = tid % T;
-    const bool fix = (jb == N / 4);
-    const int j = fix ? 0 : 4 * jb + w;
+    const bool fix = (jb == N / CW);
+    const int j = fix ? 0 : CW * jb + w;
     if (f == 0) {
 #pragma unroll
         for (int q = 0; q < P; q++) x[q] = st.hh[q];
@@ -368,10 +381,11 @@ MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, const P1State<P>& s
 template <int N, int P>
 MW_HD void p1_finish(const P1Args& A, const Twiddles& tw, int jb, int step, int tid, int f, cf (&x)[P], const cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
-    const int w2 = tid & 3, u2 = tid >> 2;
+    constexpr int CW = Exch<N>::CW;
+    const int w2 = tid % CW, u2 = tid / CW;
     load_slots<N, P>(x, u2, lds + w2 * P1Geom<N, P>::BUFSTRIDE);
     final_stage<N, P, +1>(x, u2, tw.TF);
-    if (jb == N / 4) {
+    if (jb == N / CW) {
         if (w2 == 0) {
             cf* C = A.Cj0 + ((size_t)step * 3 + f) * N;
 #pragma unroll
@@ -379,10 +393,10 @@ MW_HD void p1_finish(const P1Args& A, const Twiddles& tw, int jb, int step, int 
         }
         return;
     }
-    cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)jb * N * 4;  // block-uniform
-    const unsigned voff = (unsigned)(u2 * 4 + w2);
+    cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)jb * N * CW;  // block-uniform
+    const unsigned voff = (unsigned)(u2 * CW + w2);
 #pragma unroll
-    for (int q = 0; q < P; q++) mw_store_stream<mw_nt_exchange(N)>(&(Ef + (size_t)T * q * 4)[voff], x[q]);
+    for (int q = 0; q < P; q++) mw_store_stream<mw_nt_exchange(N)>(&(Ef + (size_t)T * q * CW)[voff], x[q]);
 }
 
 // =============================== pass 2: transform along j + epilogue ========================
@@ -461,9 +475,10 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
     int r1, u1;
     p2_load_map<N, P, R2>(tid, &r1, &u1);
     const int row = ab * R2 + r1;
-    const cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * 4;  // block-uniform base (first row of the block)
-    // per-lane 32-bit offset of element j = u1 (slot q adds the uniform T*q/4 chunks of N*4)
-    const unsigned voff = (unsigned)(((u1 >> 2) * N + r1) * 4 + (u1 & 3));
+    constexpr int CW = Exch<N>::CW;
+    const cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * CW;  // block-uniform base (first row of the block)
+    // per-lane 32-bit offset of element j = u1 (slot q adds the uniform T*q/CW chunks of N*CW)
+    const unsigned voff = (unsigned)(((u1 / CW) * N + r1) * CW + (u1 % CW));
 #ifdef MW_ABLATE_SEQ_READ  // timing experiment (wrong results): the same bytes from ONE contiguous block per workgroup
     {
         const cf* Es = A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * N;
@@ -477,11 +492,11 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
         const int j = u1 + T * q;
         if (f == 0 && j > N / 2) {  // height: stored for j <= N/2 only; T(a, j) = conj T(a, N - j)
             const int m = N - j;
-            x[q] = cconj(mw_load_stream(&Ef[(unsigned)(((m >> 2) * N + r1) * 4 + (m & 3))]));
-        } else if (T % 4 == 0) {
-            x[q] = mw_load_stream(&(Ef + (size_t)(T / 4) * q * N * 4)[voff]);
+            x[q] = cconj(mw_load_stream(&Ef[(unsigned)(((m / CW) * N + r1) * CW + (m % CW))]));
+        } else if (T % CW == 0) {
+            x[q] = mw_load_stream(&(Ef + (size_t)(T / CW) * q * N * CW)[voff]);
         } else {
-            x[q] = Ef[(unsigned)(((j >> 2) * N + r1) * 4 + (j & 3))];
+            x[q] = Ef[(unsigned)(((j / CW) * N + r1) * CW + (j % CW))];
         }
     }
     if (u1 == 0 && f != 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];  // Nyquist column j = 0
@@ -740,10 +755,11 @@ template <int N, int P, int R2>
 MW_HD void p2_hs_halo_fetch(const P2Args& A, int ab, int step, int u, cf (&x)[P]) {
     constexpr int T = FftGeom<N, P>::T;
     const int row = ab * R2 + R2;
-    const cf* Ef = A.E + ((size_t)step * 3 + 1) * N * N + (size_t)row * 4;  // block-uniform
-    const unsigned voff = (unsigned)((u >> 2) * N * 4 + (u & 3));
+    constexpr int CW = Exch<N>::CW;
+    const cf* Ef = A.E + ((size_t)step * 3 + 1) * N * N + (size_t)row * CW;  // block-uniform
+    const unsigned voff = (unsigned)((u / CW) * N * CW + (u % CW));
 #pragma unroll
-    for (int q = 0; q < P; q++) x[q] = (Ef + (size_t)(T / 4) * q * N * 4)[voff];
+    for (int q = 0; q < P; q++) x[q] = (Ef + (size_t)(T / CW) * q * N * CW)[voff];
     if (u == 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + 1) * N + row];  // Nyquist column j = 0
 }
 // transformed halo row -> plain hds row in buffer 0

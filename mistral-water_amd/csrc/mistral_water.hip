@@ -130,18 +130,18 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
     MW_STAMP(0, 1);
 #pragma unroll
     for (int f = 0; f < 3; f++) {
-        if (!p1_field_active(N, jb, f)) continue;  // block-uniform: height needs columns j <= N/2 only
+        if (!p1_field_active(N, jb, f, G::CW)) continue;  // block-uniform: height needs columns j <= N/2 only
 #pragma unroll
         MW_VT(h) p1_build<N, P>(A, jb, tid + h * NT, f, st[h], x[h]);
         if (G::NBUF == 1 && f) __syncthreads();
         MW_STAMP(0, 2 + 8 * f);
 #ifdef MW_ABLATE_FFT
         {
-            cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)(jb % (N / 4)) * N * 4;
+            cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)(jb % (N / G::CW)) * N * G::CW;
 #pragma unroll
             MW_VT(h)
 #pragma unroll
-            for (int q = 0; q < P; q++) Ef[(size_t)(((tid + h * NT) >> 2) + T * q) * 4 + (tid & 3)] = x[h][q];
+            for (int q = 0; q < P; q++) Ef[(size_t)(((tid + h * NT) / G::CW) + T * q) * G::CW + (tid % G::CW)] = x[h][q];
             continue;
         }
 #endif

@@ -58,7 +58,7 @@ struct Tables {
 template <int N, int P>
 void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
     constexpr int T = FftGeom<N, P>::T, NT = P1Geom<N, P>::NTHREADS, BS = P1Geom<N, P>::BUFSTRIDE;
-    std::vector<cf> lds(4 * BS);
+    std::vector<cf> lds(P1Geom<N, P>::CW * BS);
     const Twiddles tw = TwGeom<N, P>::view(A.TW);
     struct St { P1State<P> s; cf x[P]; };
     std::vector<St> st(NT);
@@ -67,7 +67,7 @@ void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
             const float t = tm.t[step];
             for (int tid = 0; tid < NT; tid++) p1_animate<N, P>(A, jb, tid, t, st[tid].s);
             for (int f = 0; f < 3; f++) {
-                if (!p1_field_active(N, jb, f)) continue;
+                if (!p1_field_active(N, jb, f, P1Geom<N, P>::CW)) continue;
                 for (int tid = 0; tid < NT; tid++) {
                     p1_build<N, P>(A, jb, tid, f, st[tid].s, st[tid].x);
                     stage0_store<N, P, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
@@ -242,7 +242,7 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
         A.omT = om.data();
         A.initT = initT; A.phase_in = phaseT; A.phase_out = phase_next.data(); A.TW = tb.TW.data(); A.E = E.data(); A.c = C; A.dt = dt;
         constexpr int NT = OrP1Geom<N, P>::NTHREADS, BS = OrP1Geom<N, P>::BUFSTRIDE;
-        std::vector<cf> lds(4 * BS);
+        std::vector<cf> lds(P1Geom<N, P>::CW * BS);
         struct St { cf h[P]; cf x[P]; };
         std::vector<St> st(NT);
         for (int jb = 0; jb < N / 4; jb++)
@@ -265,7 +265,7 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
         A.E = E.data(); A.TW = tb.TW.data(); A.height = height; A.disp = disp; A.disp_g = disp_g; A.c = C;
         A.height_g = height_g; A.disp_a = disp_a;
         constexpr int NT = OrP2Geom<N, P>::NTHREADS, BS = OrP2Geom<N, P>::BUFSTRIDE;
-        std::vector<cf> lds(4 * BS);
+        std::vector<cf> lds(P1Geom<N, P>::CW * BS);
         struct St { cf x[P]; float dx[P]; };
         std::vector<St> st(NT);
         for (int ab = 0; ab < N / 4; ab++)
