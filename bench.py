@@ -63,6 +63,19 @@ def parse():
     return ap.parse_args()
 
 
+def emit(obj):
+    """The ONE JSON line, as the LAST line of stdout: RCCL writes a version banner through C stdio when a communicator is
+    created; it sits in libc's buffer until exit unless it is flushed first."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if obj is not None:
+        print(json.dumps(obj), flush=True)
+
+
 def host_cores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
@@ -203,16 +216,26 @@ def main():
     seed = 1 + rank
     kw = dict(resolution=N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude,
               choppiness=p.choppiness, gravity=p.gravity)
-    use_tiles = world > 1 and not same_device
+    # MW_BENCH_FORCE_TILES=1 (test hook): the tile API path with a one-rank communicator on a 1-GPU box
+    use_tiles = (world > 1 and not same_device) or os.environ.get("MW_BENCH_FORCE_TILES") == "1"
     tiles = ocean = None
     if use_tiles:
         # the product's tile API: the LIBRARY owns the RCCL communicator; torch.distributed only carries its 128-byte id
-        box = [mw.Tiles.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        B = max(1, min(a.batch, 32))
-        tiles = mw.Tiles(max_steps=B, seed=1, comm_id=box[0], rank=rank, nranks=world, device=local_rank, **kw)
-        ptrs = tiles.outputs(0)
-    else:
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = mw.Tiles.unique_id()
+            except mw.MistralWaterError as e:      # RCCL not loadable: say so in the result instead of dying on every rank
+                box[0] = "ERR:" + str(e)
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], str):
+            use_tiles, tiles_note = False, box[0]
+        else:
+            B = max(1, min(a.batch, 32))
+            tiles = mw.Tiles(max_steps=B, seed=1, comm_id=box[0], rank=rank, nranks=world, device=local_rank, **kw)
+    tiles_note = locals().get("tiles_note")
+    if not use_tiles:
         ocean = mw.Ocean(seed=seed, device=local_rank, **kw)
         ocean.set_stream(stream.cuda_stream)
         B = max(1, min(a.batch, ocean.max_batch))
@@ -310,6 +333,18 @@ def main():
                              "physical_GBps": (tr / (ms * 1e-3) / 1e9) if tr else None}
                             for i, ((nm, ms), tr) in enumerate(zip(kern, (traffic1, traffic)))]}
 
+    # one step per enqueue (what a frame-at-a-time host sees; the headline value is batched THROUGHPUT): untimed region
+    single_us = None
+    if not use_tiles and rank == 0:
+        for _ in range(20):
+            enqueue([1.0])
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for k in range(200):
+            enqueue([(k + 1) / 60.0])
+        torch.cuda.synchronize()
+        single_us = (time.perf_counter() - t2) / 200 * 1e6
+
     value = world * a.steps * NN / el
     phys_pt = ((traffic or 0) + (traffic1 or 0)) / (NN * B) if (traffic and traffic1) else None
     out = {
@@ -325,7 +360,9 @@ def main():
                                f"choppiness {p.choppiness:g}, t_k = k/60 s, one independent tile per GPU (seed = 1 + rank); "
                                f"throughput of {B} independent time-steps per enqueue, not a per-frame latency",
                    "grid": N, "steps_per_enqueue": B, "tiles": world, "semantics": "MW_SEM_FFTMESH",
-                   "parallelism": f"tile{world}", "api": "mw_tiles_* (library-owned RCCL communicator)" if use_tiles else "mw_ocean_*"},
+                   "parallelism": f"tile{world}", "api": "mw_tiles_* (library-owned RCCL communicator)" if use_tiles
+                   else ("mw_ocean_*" + (f" (tile API unavailable: {tiles_note})" if tiles_note else ""))},
+        "single_step_us": single_us,     # one time-step per enqueue, back to back (two launches of 1/32 of the batched grid)
         "hbm_roofline_frac_whole_step": value / world * BYTES_PER_POINT / HBM_PEAK,
         "hbm_real_frac_whole_step": (value / world * phys_pt / HBM_PEAK) if phys_pt else None,
         "physical_bytes_per_point_whole_step": phys_pt,
@@ -343,14 +380,13 @@ def main():
         out["cpu_baseline"] = cpu_baseline_ocean(p, h0, h0c, gpu_step)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out))
     if tiles is not None:
         tiles.close()
     if ocean is not None:
         ocean.close()
     if dist is not None:
         dist.destroy_process_group()
+    emit(out if rank == 0 else None)
 
 
 def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):

@@ -479,6 +479,18 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
     const cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * CW;  // block-uniform base (first row of the block)
     // per-lane 32-bit offset of element j = u1 (slot q adds the uniform T*q/CW chunks of N*CW)
     const unsigned voff = (unsigned)(((u1 / CW) * N + r1) * CW + (u1 % CW));
+#ifdef MW_ABLATE_WIDE_READ  // timing experiment (wrong results): the same bytes, contiguous, as 16-B per-lane loads
+    {
+        const f4* E4 = reinterpret_cast<const f4*>(A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * N);
+#pragma unroll
+        for (int q = 0; q < P / 2; q++) {
+            const f4 v = (E4 + (size_t)R2 * T * q)[(unsigned)(tid % (R2 * T))];
+            x[2 * q] = mk(v.x, v.y);
+            x[2 * q + 1] = mk(v.z, v.w);
+        }
+        return;
+    }
+#endif
 #ifdef MW_ABLATE_SEQ_READ  // timing experiment (wrong results): the same bytes from ONE contiguous block per workgroup
     {
         const cf* Es = A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * N;
