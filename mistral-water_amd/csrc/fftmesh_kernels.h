@@ -32,6 +32,9 @@ struct StepTimes {
 // whole (or, for fewer rows, contiguous fractions of) lines.  CW = 4 everywhere except 4096^2, where four 4096-point columns
 // need 139 KiB of LDS (one workgroup per CU); with CW = 2 pass 1 is two 70-KiB workgroups per CU (MW_CW2_MIN_N, A/B in
 // DESIGN.md section 6).
+#ifndef MW_BUF_PAD
+#define MW_BUF_PAD 4  // cf entries between the row / column exchange buffers of a workgroup (2: -4 % at 4096^2; 8, 12: neutral)
+#endif
 #ifndef MW_CW2_MIN_N
 #define MW_CW2_MIN_N 8192  // grids from this size up use CW = 2 (8192 = none)
 #endif
@@ -49,10 +52,12 @@ MW_HD void mw_sincos_fast(float x, float* s, float* c) { sincos_fast_f32(x, s, c
 #ifndef MW_NT_STORES
 #define MW_NT_STORES 1  // measured: pass 1 -10 % (exchange-buffer stores), pass 2 -3 % (results)
 #endif
-// Results (vertices, normals, whitecap): non-temporal only where measured faster -- 512^2 (+5 % step) and 1024^2 (+2 % on
-// top of the exchange-buffer stores); slower at 256^2 (everything is cache-resident: -8 % pass 2) and in the 4096^2
-// sequential-halo kernel (-3 %), neutral at 2048^2.  
-MW_HD constexpr bool mw_nt_results(int N) { return N == 512 || N == 1024; }
+// Results (vertices, normals, whitecap): non-temporal from 512^2 up (512^2 +5 % step, 1024^2 +2 %, and with the round-2
+// kernels 2048^2 +3 %, 4096^2 +2 % in pass 2); slower at 256^2, where everything is cache-resident (-8 % pass 2).
+#ifndef MW_NT_RESULTS_MIN_N
+#define MW_NT_RESULTS_MIN_N 512
+#endif
+MW_HD constexpr bool mw_nt_results(int N) { return N >= MW_NT_RESULTS_MIN_N; }
 // exchange buffer: non-temporal from 512^2 up (pass 1 -10 %); at 256^2 the whole batch's buffer is cache-resident and
 // pass 2 reads it back 12 % slower if it was streamed out
 #ifndef MW_NT_EXCHANGE_MIN_N
@@ -282,7 +287,7 @@ struct P1Geom {
     static constexpr int T = FftGeom<N, P>::T;
     static constexpr int CW = Exch<N>::CW;  // spectrum columns per workgroup
     static constexpr int NTHREADS = CW * T;
-    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4;
+    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + MW_BUF_PAD;
     static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;  // cf units, 16-B aligned
     static constexpr int SETSTRIDE = CW * BUFSTRIDE;
     // 2: ping-pong exchange buffers, one barrier per exchange (when both sets fit a 100 KiB budget)
@@ -415,7 +420,7 @@ struct P2Args {
 };
 
 template <int N, int P>
-struct P2Buf { static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4; };  // one row's exchange buffer, cf units
+struct P2Buf { static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + MW_BUF_PAD; };  // one row's exchange buffer, cf units
 
 // HS = "sequential halo" variant for large N (Plan<N>::HS): no halo thread group and no halo buffer -- the halo row is
 // transformed by group 0 AFTER the displacement field, in buffer 0, once rows 0..R2-2 have formed their Jacobians from

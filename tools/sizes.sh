@@ -1,6 +1,6 @@
 #!/bin/bash
 # steady-state sweep over grid sizes: tools/sizes.sh [extra bench args]
-for w in "ocean256 32 20000" "ocean512 32 8000" "ocean1024 32 4000" "ocean2048 8 1000" "ocean4096 4 200"; do
+for w in "ocean256 32 20000" "ocean512 32 8000" "ocean1024 32 4000" "ocean2048 32 640" "ocean4096 32 192"; do
   set -- $w
   python bench.py --workload $1 --batch $2 --steps $3 --warmup $2 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys,json
