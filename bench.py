@@ -55,6 +55,10 @@ def parse():
                          "timed region starts at steady clocks (the first ~5 ms after idle run ~25 %% slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--latency", action="store_true",
+                    help="also measure one time-step per enqueue (200 single-step enqueues, untimed region); off by default so that "
+                         "the default command launches full batches only and its rocprofv3 per-kernel averages are those of the "
+                         "timed launches")
     ap.add_argument("--tiles", type=int, default=1,
                     help="renderer1024: independent oceans per GenerateTexture() (mw_ocean_create_batch); the phase recurrence "
                          "forbids batching in time, the tile axis is what fills the device")
@@ -335,7 +339,7 @@ def main():
 
     # one step per enqueue (what a frame-at-a-time host sees; the headline value is batched THROUGHPUT): untimed region
     single_us = None
-    if not use_tiles and rank == 0:
+    if a.latency and not use_tiles and rank == 0:
         for _ in range(20):
             enqueue([1.0])
         torch.cuda.synchronize()
