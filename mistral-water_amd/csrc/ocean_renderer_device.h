@@ -244,6 +244,9 @@ __global__ void k_or_phase_transpose(int M, const float* src, float* dst) {
     (dst + toff)[idx] = (src + toff)[(size_t)(idx % M) * M + idx / M];
 }
 
+#ifndef MW_OR_STREAM_E_TILES
+#define MW_OR_STREAM_E_TILES 2
+#endif
 template <int N>
 static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
     constexpr int P = Plan<N>::P;
@@ -256,6 +259,7 @@ static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
     }
     OrP1Args A1;
     A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.E = s.E; A1.c = s.c; A1.dt = dt;
+    A1.stream_E = (s.tiles >= MW_OR_STREAM_E_TILES) ? 1 : 0;
     constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
     k_or_pass1<N, P><<<dim3(N / 4, s.tiles > 1 ? 1 : 3, s.tiles), dim3(NT1), LB1, st>>>(A1);
     std::swap(s.phaseT, s.phaseT2);

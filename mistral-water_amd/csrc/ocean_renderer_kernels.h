@@ -96,6 +96,7 @@ struct OrP1Args {
     cf* E;            // [3][M/4][M][4]
     OrConsts c;
     float dt;         // deltaTime * mult (S/OceanRenderer.cs:223)
+    int stream_E;     // non-temporal exchange stores (batched handles)
 };
 template <int N, int P>
 struct OrP1Geom {
@@ -145,8 +146,13 @@ MW_HD void or_p1_finish(const OrP1Args& A, const Twiddles& tw, int jb, int tid, 
     load_slots<N, P>(x, u2, lds + w2 * OrP1Geom<N, P>::BUFSTRIDE);
     final_stage<N, P, -1>(x, u2, tw.TF);
     cf* Ef = A.E + (size_t)f * N * N + (size_t)jb * N * 4;
+    if (A.stream_E) {  // batched handle: the tiles' exchange buffers together exceed the caches -- write-once stream
 #pragma unroll
-    for (int q = 0; q < P; q++) Ef[(size_t)(u2 + T * q) * 4 + w2] = x[q];
+        for (int q = 0; q < P; q++) mw_store_stream<true>(&Ef[(size_t)(u2 + T * q) * 4 + w2], x[q]);
+    } else {           // one texture: 24 MB, pass 2 finds most of it in L2 / the Infinity Cache
+#pragma unroll
+        for (int q = 0; q < P; q++) Ef[(size_t)(u2 + T * q) * 4 + w2] = x[q];
+    }
 }
 
 struct OrP2Args {

@@ -236,6 +236,7 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
     std::vector<cf> E((size_t)3 * N * N);
     {
         OrP1Args A;
+        A.stream_E = 0;
         std::vector<float> phase_next((size_t)N * N), om((size_t)N * N);
         for (int px = 0; px < N; px++)
             for (int py = 0; py < N; py++) om[(size_t)px * N + py] = or_omega(C, px, py);
