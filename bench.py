@@ -236,9 +236,38 @@ def main():
         if isinstance(box[0], str):
             use_tiles, tiles_note = False, box[0]
         else:
+            # ncclCommInitRank is collective: if it fails or hangs on ANY rank the whole job would die without a result.
+            # Create the tiles in a worker thread with a deadline, agree on the outcome over torch.distributed, and fall
+            # back to plain per-rank handles (still one tile per GPU, no collective) if any rank did not make it.
+            import threading
             B = max(1, min(a.batch, 32))
-            tiles = mw.Tiles(max_steps=B, seed=1, comm_id=box[0], rank=rank, nranks=world, device=local_rank, **kw)
+            made = {}
+
+            def _make():
+                try:
+                    made["tiles"] = mw.Tiles(max_steps=B, seed=1, comm_id=box[0], rank=rank, nranks=world, device=local_rank, **kw)
+                except Exception as e:      # noqa: BLE001 -- reported in the result line
+                    made["err"] = repr(e)
+            th = threading.Thread(target=_make, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("MW_BENCH_TILES_TIMEOUT", "120")))
+            ok_local = 1 if "tiles" in made else 0
+            if dist is not None:
+                flag = torch.tensor([ok_local], dtype=torch.int32, device=red_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok_all = int(flag.item())
+            else:
+                ok_all = ok_local
+            if ok_all:
+                tiles = made["tiles"]
+            else:
+                use_tiles = False
+                tiles_note = made.get("err", "mw_tiles_create_rank did not return in time on some rank" if ok_local else "timed out")
+                if "tiles" in made:
+                    made["tiles"].close()
+                hung = th.is_alive()
     tiles_note = locals().get("tiles_note")
+    hung = locals().get("hung", False)
     if not use_tiles:
         ocean = mw.Ocean(seed=seed, device=local_rank, **kw)
         ocean.set_stream(stream.cuda_stream)
@@ -391,6 +420,8 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     emit(out if rank == 0 else None)
+    if hung:            # a worker thread is still blocked inside the communicator bootstrap: do not wait for it at exit
+        os._exit(0)
 
 
 def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):
