@@ -287,7 +287,7 @@ struct P1Geom {
     static constexpr int T = FftGeom<N, P>::T;
     static constexpr int CW = Exch<N>::CW;  // spectrum columns per workgroup
     static constexpr int NTHREADS = CW * T;
-    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + MW_BUF_PAD;
+    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + (XLay<N, P>::EXACT ? XLay<N, P>::PAD_RD4 : MW_BUF_PAD);
     static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;  // cf units, 16-B aligned
     static constexpr int SETSTRIDE = CW * BUFSTRIDE;
     // 2: ping-pong exchange buffers, one barrier per exchange (when both sets fit a 100 KiB budget)
@@ -388,7 +388,7 @@ MW_HD void p1_finish(const P1Args& A, const Twiddles& tw, int jb, int step, int 
     constexpr int T = FftGeom<N, P>::T;
     constexpr int CW = Exch<N>::CW;
     const int w2 = tid % CW, u2 = tid / CW;
-    load_slots<N, P>(x, u2, lds + w2 * P1Geom<N, P>::BUFSTRIDE);
+    load_last<N, P>(x, u2, lds + w2 * P1Geom<N, P>::BUFSTRIDE);
     final_stage<N, P, +1>(x, u2, tw.TF);
     if (jb == N / CW) {
         if (w2 == 0) {
@@ -420,7 +420,7 @@ struct P2Args {
 };
 
 template <int N, int P>
-struct P2Buf { static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + MW_BUF_PAD; };  // one row's exchange buffer, cf units
+struct P2Buf { static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + (XLay<N, P>::EXACT ? XLay<N, P>::PAD_WR4 : MW_BUF_PAD); };  // one row's exchange buffer, cf units
 
 // HS = "sequential halo" variant for large N (Plan<N>::HS): no halo thread group and no halo buffer -- the halo row is
 // transformed by group 0 AFTER the displacement field, in buffer 0, once rows 0..R2-2 have formed their Jacobians from
@@ -530,17 +530,23 @@ MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P]
     p2_stage0<N, P, R2>(tid, x, lds);
 }
 
-// middle passes keep the load-side (row-interleaved) mapping: measured fewer LDS bank conflicts than row-major
+// middle passes: with the padded LDS layout they keep the load-side (row-interleaved) mapping (measured fewer bank
+// conflicts than row-major); with the exact layouts (XLay) a wave stays inside one row, where every access is conflict-free
 template <int N, int P, int R2>
-MW_HD void p2_mid_load(int tid, cf (&x)[P], const cf* lds) {
+MW_HD void p2_mid_map(int tid, int* r1, int* u1) {
+    if (XLay<N, P>::EXACT) { *r1 = tid / FftGeom<N, P>::T; *u1 = tid % FftGeom<N, P>::T; }
+    else p2_load_map<N, P, R2>(tid, r1, u1);
+}
+template <int N, int P, int R2>
+MW_HD void p2_mid_load(int tid, int s, cf (&x)[P], const cf* lds) {  // s: the pass this load feeds
     int r1, u1;
-    p2_load_map<N, P, R2>(tid, &r1, &u1);
-    load_slots<N, P>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE);
+    p2_mid_map<N, P, R2>(tid, &r1, &u1);
+    load_slots<N, P>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE, s - 1);
 }
 template <int N, int P, int R2>
 MW_HD void p2_mid_store(const Twiddles& tw, int tid, int s, cf (&x)[P], cf* lds) {
     int r1, u1;
-    p2_load_map<N, P, R2>(tid, &r1, &u1);
+    p2_mid_map<N, P, R2>(tid, &r1, &u1);
     stage_store<N, P, +1>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE, tw, s);
 }
 
@@ -550,7 +556,7 @@ MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int 
                      const cf* lds, float* noise_lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
-    load_slots<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
+    load_last<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
     final_stage<N, P, +1>(x, u, tw.TF);
     if (f == 2) {  // slopes -> unit normal (S/FFTMesh.cs:218), stored at once
         float* nblk = A.normals + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;  // block-uniform
@@ -698,7 +704,7 @@ template <int N, int P, int R2>
 MW_HD void p2_hs_finish(const Twiddles& tw, int ab, int tid, int f, cf (&x)[P], P2StateHS<P>& st, const cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
-    load_slots<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
+    load_last<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
     final_stage<N, P, +1>(x, u, tw.TF);
 #pragma unroll
     for (int q = 0; q < P; q++) {
@@ -745,7 +751,7 @@ MW_HD void p2_hs_finish_slopes(const P2Args& A, const Twiddles& tw, int ab, int 
                                const P2StateHS<P>& st, const cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
-    load_slots<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
+    load_last<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
     final_stage<N, P, +1>(x, u, tw.TF);
     float* nblk = A.normals + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;  // block-uniform
     float* wblk = A.white + ((size_t)step * N * N + (size_t)ab * R2 * N) * A.white_stride;

@@ -152,7 +152,7 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
 #pragma unroll
-            MW_VT(h) load_slots<N, P>(x[h], MW_U(h), MW_BUF(h));
+            MW_VT(h) load_slots<N, P>(x[h], MW_U(h), MW_BUF(h), s - 1);
             if (s == 1) MW_STAMP(0, 4 + 8 * f);
 #ifndef MW_ABLATE_WAR  // timing experiment (wrong results): no write-after-read barrier (4096^2: pass 1 -2 %)
             if (G::NBUF == 1) __syncthreads(); else cur ^= 1;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
-            if (active) p2_mid_load<N, P, R2>(tid, x, set0 + cur * G::SETSTRIDE);
+            if (active) p2_mid_load<N, P, R2>(tid, s, x, set0 + cur * G::SETSTRIDE);
             if (G::NBUF == 1) __syncthreads(); else cur ^= 1;
             if (active) p2_mid_store<N, P, R2>(tw, tid, s, x, set0 + cur * G::SETSTRIDE);
             __syncthreads();
@@ -342,7 +342,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
 #pragma unroll
-            MW_VT(h) p2_mid_load<N, P, R2>(MW_VTID(h), x[h], set0);
+            MW_VT(h) p2_mid_load<N, P, R2>(MW_VTID(h), s, x[h], set0);
             __syncthreads();
 #pragma unroll
             MW_VT(h) p2_mid_store<N, P, R2>(tw, MW_VTID(h), s, x[h], set0);
@@ -398,13 +398,13 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
             __syncthreads();
 #pragma unroll
             for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                if (g0 == 0) load_slots<N, P>(x[0], u, set0);
+                if (g0 == 0) load_slots<N, P>(x[0], u, set0, s - 1);
                 __syncthreads();
                 if (g0 == 0) stage_store<N, P, +1>(x[0], u, set0, tw, s);
                 __syncthreads();
             }
             if (g0 == 0) {
-                load_slots<N, P>(x[0], u, set0);
+                load_last<N, P>(x[0], u, set0);
                 final_stage<N, P, +1>(x[0], u, tw.TF);
             }
             __syncthreads();

@@ -290,6 +290,34 @@ template <> struct LogP<16> { static constexpr int v = 4; };
 constexpr int mw_full_stages(int N, int P) { int s = 0; long long m = 1; while (m * P <= N) { m *= P; s++; } return s; }
 constexpr int mw_ipow(int P, int s) { int m = 1; for (int i = 0; i < s; i++) m *= P; return m; }
 
+// LDS layouts of the exchanges between the radix-P passes (cf units; element n of the length-N intermediate sequence).
+// A wave's ds_write_b64 is served in groups of 16 consecutive lanes over 32 dword banks, its ds_read_b64 in groups of 32
+// lanes over 64: a group is conflict-free when its 16 (32) cf indices are distinct mod 16 (32).
+//  * padded (every P, the only form up to round 2): n -> n + n/P in every exchange.  Stores are conflict-free, but the 32
+//    lanes of a read, n = u + T q, span 33 entries (u + u/16): one bank pair is hit twice, i.e. every read at half rate --
+//    and the compiler's ds_read2_b64 pairing (16-lane groups, 128 B/clk) merely hides it in the conflict counter.
+//  * exact (P = 16, T a multiple of 32):
+//      exchange 0  (stage 0 writes n = 16 u + r, a stride-16 scatter): the 16 x T transpose  n -> (n % 16) (T + 2) + n / 16.
+//                  Stores: lanes write consecutive entries.  Reads: lane u of a 32-lane group reads at 2 (u % 16) + u / 16 + const.
+//      exchange s >= 1 (pass s writes n = j + 16^s r with j = u within a 16-lane group): the identity, no padding; reads
+//                  n = u + T q are consecutive in u.
+//    Every read is then one conflict-free ds_read_b64 (256 B/clk); the build switches off the pairing of DS operations
+//    (-target-feature -load-store-opt) because a paired read of the transposed layout is 2-way conflicted.
+#ifndef MW_LDS_LAYOUT
+#define MW_LDS_LAYOUT 1
+#endif
+template <int N, int P>
+struct XLay {
+    static constexpr int T = N / P;
+    static constexpr bool EXACT = MW_LDS_LAYOUT && P == 16 && (T % 32) == 0;
+    static constexpr int ROW0 = T + 2;
+    static constexpr int LBUF = EXACT ? P * ROW0 : N + N / P;
+    // entries between the 4 buffers of a workgroup whose lanes interleave them (lane l -> buffer l % 4), LBUF = 0 mod 32:
+    // a read of 8 consecutive n from each of 4 buffers wants stride 8 mod 32 (pass 1's final read), a store of 4 consecutive
+    // n to each of 4 buffers stride 4 mod 16 (pass 2's stage 0)
+    static constexpr int PAD_RD4 = 8, PAD_WR4 = 4;
+};
+
 template <int N, int P>
 struct FftGeom {
     static constexpr int T = N / P;
@@ -298,7 +326,7 @@ struct FftGeom {
     static constexpr int PS = mw_ipow(P, S);
     static constexpr int RL = N / PS;               // radix of the final pass (1 = none)
     static constexpr int NB = P / RL;               // butterflies per thread in the final pass
-    static constexpr int LBUF = N + N / P;
+    static constexpr int LBUF = XLay<N, P>::LBUF;
     static_assert(N >= 64 && (N & (N - 1)) == 0 && N <= 4096, "N must be a power of two in [64,4096]");
     static_assert(S >= 1 && RL >= 1 && RL < P, "bad geometry");
 };
@@ -378,17 +406,36 @@ MW_HD void stage0_store(cf (&x)[P], int u, cf* buf) {
     if (u == 12345) buf[0] = x[0];
     return;
 #endif
+    if (XLay<N, P>::EXACT) {
+        cf* __restrict__ b = buf + u;
+#pragma unroll
+        for (int r = 0; r < P; r++) b[r * XLay<N, P>::ROW0] = x[r];
+        return;
+    }
     cf* __restrict__ b = buf + (P + 1) * u;  // lds_pad(P*u + r) = (P+1)*u + r for r < P
 #pragma unroll
     for (int r = 0; r < P; r++) b[r] = x[r];
 }
+// e: which exchange is read (0 = the one stage 0 wrote, s = the one pass s wrote)
 template <int N, int P>
-MW_HD void load_slots(cf (&x)[P], int u, const cf* buf) {
+MW_HD void load_slots(cf (&x)[P], int u, const cf* buf, int e) {
     constexpr int T = FftGeom<N, P>::T;
 #ifdef MW_ABLATE_LDS
     if (u == 12345) x[0] = buf[0];
     return;
 #endif
+    if (XLay<N, P>::EXACT) {
+        if (e == 0) {  // n = u + T q = 16 (u/16 + (T/16) q) + u % 16
+            const cf* __restrict__ b = buf + (u & (P - 1)) * XLay<N, P>::ROW0 + (u >> LogP<P>::v);
+#pragma unroll
+            for (int q = 0; q < P; q++) x[q] = b[(T / P) * q];
+        } else {
+            const cf* __restrict__ b = buf + u;
+#pragma unroll
+            for (int q = 0; q < P; q++) x[q] = b[T * q];
+        }
+        return;
+    }
     if (T % P == 0) {  // lds_pad(u + T*q) = lds_pad(u) + T*q + T*q/P
         const cf* __restrict__ b = buf + lds_pad<P>(u);
 #pragma unroll
@@ -401,6 +448,8 @@ MW_HD void load_slots(cf (&x)[P], int u, const cf* buf) {
 // radix-P pass s (1 <= s < S): p = P^s
 // ALLOW_POW = false keeps the table in every pass (the OceanRenderer kernels: their finite-difference normal amplifies
 // transform rounding at ill-conditioned texels, and a frame is latency- not throughput-bound anyway)
+template <int N, int P>
+MW_HD void load_last(cf (&x)[P], int u, const cf* buf) { load_slots<N, P>(x, u, buf, FftGeom<N, P>::S - 1); }  // input of the final pass
 template <int N, int P, int SGN, bool ALLOW_POW = true>
 MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
     const int p = 1 << (LogP<P>::v * s);
@@ -446,6 +495,12 @@ MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
     if (u == 12345) buf[j] = x[0];
     return;
 #endif
+    if (XLay<N, P>::EXACT) {
+        cf* __restrict__ b = buf + j;
+#pragma unroll
+        for (int r = 0; r < P; r++) b[p * r] = x[r];
+        return;
+    }
     cf* __restrict__ b = buf + lds_pad<P>(j);  // p is a multiple of P: lds_pad(j + p*r) = lds_pad(j) + p*r + p*r/P
 #pragma unroll
     for (int r = 0; r < P; r++) b[p * r + ((p * r) >> LogP<P>::v)] = x[r];

@@ -114,7 +114,7 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Arg
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
-            load_slots<N, P>(x, u, set0 + w * G::BUFSTRIDE);
+            load_slots<N, P>(x, u, set0 + w * G::BUFSTRIDE, s - 1);
             __syncthreads();
             stage_store<N, P, -1, false>(x, u, set0 + w * G::BUFSTRIDE, tw, s);
             __syncthreads();
@@ -150,9 +150,11 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
-            load_slots<N, P>(x, tid >> 2, set0 + (tid & 3) * G::BUFSTRIDE);
+            // exact LDS layouts: a wave stays inside one row; padded layout: the load-side (row-interleaved) mapping
+            const int um = XLay<N, P>::EXACT ? tid % FftGeom<N, P>::T : tid >> 2, rm = XLay<N, P>::EXACT ? tid / FftGeom<N, P>::T : tid & 3;
+            load_slots<N, P>(x, um, set0 + rm * G::BUFSTRIDE, s - 1);
             __syncthreads();
-            stage_store<N, P, -1, false>(x, tid >> 2, set0 + (tid & 3) * G::BUFSTRIDE, tw, s);
+            stage_store<N, P, -1, false>(x, um, set0 + rm * G::BUFSTRIDE, tw, s);
             __syncthreads();
         }
         or_p2_finish<N, P>(A, tw, ab, tid, f, x, dx, set0);

@@ -102,7 +102,7 @@ template <int N, int P>
 struct OrP1Geom {
     static constexpr int T = FftGeom<N, P>::T;
     static constexpr int NTHREADS = 4 * T;
-    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4;
+    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + (XLay<N, P>::EXACT ? XLay<N, P>::PAD_RD4 : 4);
     static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;
     static constexpr int LDS_BYTES = (TW_LDS + 4 * BUFSTRIDE) * (int)sizeof(cf);
 };
@@ -143,7 +143,7 @@ template <int N, int P>
 MW_HD void or_p1_finish(const OrP1Args& A, const Twiddles& tw, int jb, int tid, int f, cf (&x)[P], const cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int w2 = tid & 3, u2 = tid >> 2;
-    load_slots<N, P>(x, u2, lds + w2 * OrP1Geom<N, P>::BUFSTRIDE);
+    load_last<N, P>(x, u2, lds + w2 * OrP1Geom<N, P>::BUFSTRIDE);
     final_stage<N, P, -1>(x, u2, tw.TF);
     cf* Ef = A.E + (size_t)f * N * N + (size_t)jb * N * 4;
     if (A.stream_E) {  // batched handle: the tiles' exchange buffers together exceed the caches -- write-once stream
@@ -170,7 +170,7 @@ struct OrP2Geom {
     static constexpr int T = FftGeom<N, P>::T;
     static constexpr int R2 = 4;
     static constexpr int NTHREADS = R2 * T;
-    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + 4;
+    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + (XLay<N, P>::EXACT ? XLay<N, P>::PAD_WR4 : 4);
     static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;
     static constexpr int LDS_BYTES = (TW_LDS + R2 * BUFSTRIDE) * (int)sizeof(cf);
 };
@@ -192,7 +192,7 @@ MW_HD void or_p2_finish(const OrP2Args& A, const Twiddles& tw, int ab, int tid, 
                         const cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * 4 + g;  // a = py', b = px'
-    load_slots<N, P>(x, u, lds + g * OrP2Geom<N, P>::BUFSTRIDE);
+    load_last<N, P>(x, u, lds + g * OrP2Geom<N, P>::BUFSTRIDE);
     final_stage<N, P, -1>(x, u, tw.TF);
     const size_t rowoff = (size_t)a * N;
 #pragma unroll

@@ -59,7 +59,11 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
            "-fno-slp-vectorize",
            # the 2-virtual-thread kernels are ~20k IR instructions once their field loop is unrolled: above the default cap
            # (16384) the pragma is ignored, the field index stays dynamic and the state arrays land in scratch
-           "-mllvm", "-pragma-unroll-threshold=1000000", "-o", LIB_PATH, os.path.join(CSRC_DIR, "mistral_water.hip")]
+           "-mllvm", "-pragma-unroll-threshold=1000000",
+           # no pairing of DS operations into ds_read2/ds_write2: the exchange layouts (XLay, mw_math.h) are bank-exact for single
+           # 8-byte reads (256 B/clk); a paired read is served in 16-lane groups at 128 B/clk and is 2-way conflicted on them
+           "-Xclang", "-target-feature", "-Xclang", "-load-store-opt",
+           "-o", LIB_PATH, os.path.join(CSRC_DIR, "mistral_water.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout, r.stderr)

@@ -73,7 +73,7 @@ void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
                     stage0_store<N, P, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
                 }
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                    for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
+                    for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, s - 1);
                     for (int tid = 0; tid < NT; tid++)
                         stage_store<N, P, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, tw, s);
                 }
@@ -100,7 +100,7 @@ void run_pass2(const P2Args& A, int nsteps) {
                     if (p2_active<N, P, R2>(ab, tid, f)) p2_load<N, P, R2>(A, ab, step, tid, f, st[tid].x, lds.data());
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
                     for (int tid = 0; tid < NT; tid++)
-                        if (p2_active<N, P, R2>(ab, tid, f)) p2_mid_load<N, P, R2>(tid, st[tid].x, lds.data());
+                        if (p2_active<N, P, R2>(ab, tid, f)) p2_mid_load<N, P, R2>(tid, s, st[tid].x, lds.data());
                     for (int tid = 0; tid < NT; tid++)
                         if (p2_active<N, P, R2>(ab, tid, f)) p2_mid_store<N, P, R2>(tw, tid, s, st[tid].x, lds.data());
                 }
@@ -129,7 +129,7 @@ void run_pass2_hs(const P2Args& A, int nsteps) {
                 const int f = p2_hs_field(k);
                 for (int tid = 0; tid < NT; tid++) p2_load<N, P, R2>(A, ab, step, tid, f, st[tid].x, lds.data());
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                    for (int tid = 0; tid < NT; tid++) p2_mid_load<N, P, R2>(tid, st[tid].x, lds.data());
+                    for (int tid = 0; tid < NT; tid++) p2_mid_load<N, P, R2>(tid, s, st[tid].x, lds.data());
                     for (int tid = 0; tid < NT; tid++) p2_mid_store<N, P, R2>(tw, tid, s, st[tid].x, lds.data());
                 }
                 if (f == 2) {
@@ -150,10 +150,10 @@ void run_pass2_hs(const P2Args& A, int nsteps) {
                         stage0_store<N, P, +1>(st[u].x, u, lds.data());
                     }
                     for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                        for (int u = 0; u < T; u++) load_slots<N, P>(st[u].x, u, lds.data());
+                        for (int u = 0; u < T; u++) load_slots<N, P>(st[u].x, u, lds.data(), s - 1);
                         for (int u = 0; u < T; u++) stage_store<N, P, +1>(st[u].x, u, lds.data(), tw, s);
                     }
-                    for (int u = 0; u < T; u++) { load_slots<N, P>(st[u].x, u, lds.data()); final_stage<N, P, +1>(st[u].x, u, tw.TF); }
+                    for (int u = 0; u < T; u++) { load_last<N, P>(st[u].x, u, lds.data()); final_stage<N, P, +1>(st[u].x, u, tw.TF); }
                     for (int u = 0; u < T; u++) p2_hs_halo_publish<N, P, R2>(ab, u, st[u].x, lds.data());
                 }
                 for (int tid = (R2 - 1) * T; tid < NT; tid++)
@@ -217,10 +217,10 @@ int fft1d_np(const float* in_xy, float* out_xy) {
         for (int q = 0; q < P; q++) st[u].x[q] = mk(in_xy[2 * (u + T * q)], in_xy[2 * (u + T * q) + 1]);
     for (int u = 0; u < T; u++) stage0_store<N, P, +1>(st[u].x, u, lds.data());
     for (int s = 1; s < FftGeom<N, P>::S; s++) {
-        for (int u = 0; u < T; u++) load_slots<N, P>(st[u].x, u, lds.data());
+        for (int u = 0; u < T; u++) load_slots<N, P>(st[u].x, u, lds.data(), s - 1);
         for (int u = 0; u < T; u++) stage_store<N, P, +1>(st[u].x, u, lds.data(), tw, s);
     }
-    for (int u = 0; u < T; u++) { load_slots<N, P>(st[u].x, u, lds.data()); final_stage<N, P, +1>(st[u].x, u, tw.TF); }
+    for (int u = 0; u < T; u++) { load_last<N, P>(st[u].x, u, lds.data()); final_stage<N, P, +1>(st[u].x, u, tw.TF); }
     for (int u = 0; u < T; u++)
         for (int q = 0; q < P; q++) { out_xy[2 * (u + T * q)] = st[u].x[q].x; out_xy[2 * (u + T * q) + 1] = st[u].x[q].y; }
     return 0;
@@ -254,7 +254,7 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
                     stage0_store<N, P, -1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
                 }
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                    for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
+                    for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, s - 1);
                     for (int tid = 0; tid < NT; tid++) stage_store<N, P, -1, false>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, tw, s);
                 }
                 for (int tid = 0; tid < NT; tid++) or_p1_finish<N, P>(A, tw, jb, tid, f, st[tid].x, lds.data());
@@ -274,8 +274,12 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
                 const int f = or_p2_field(k);
                 for (int tid = 0; tid < NT; tid++) or_p2_load<N, P>(A, ab, tid, f, st[tid].x, lds.data());
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                    for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid >> 2, lds.data() + (tid & 3) * BS);
-                    for (int tid = 0; tid < NT; tid++) stage_store<N, P, -1, false>(st[tid].x, tid >> 2, lds.data() + (tid & 3) * BS, tw, s);
+                    constexpr bool EX = XLay<N, P>::EXACT;
+                    constexpr int T2 = FftGeom<N, P>::T;
+                    for (int tid = 0; tid < NT; tid++)
+                        load_slots<N, P>(st[tid].x, EX ? tid % T2 : tid >> 2, lds.data() + (EX ? tid / T2 : tid & 3) * BS, s - 1);
+                    for (int tid = 0; tid < NT; tid++)
+                        stage_store<N, P, -1, false>(st[tid].x, EX ? tid % T2 : tid >> 2, lds.data() + (EX ? tid / T2 : tid & 3) * BS, tw, s);
                 }
                 for (int tid = 0; tid < NT; tid++) or_p2_finish<N, P>(A, tw, ab, tid, f, st[tid].x, st[tid].dx, lds.data());
             }
