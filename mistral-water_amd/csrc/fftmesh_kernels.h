@@ -328,7 +328,23 @@ MW_HD void field_coeffs(int f, float kx, float kz, cf* cx, cf* cz) {
 // first 1-D transform its rows are Hermitian in j: T(a, N-j) = conj T(a, j).  Only columns j <= N/2 are
 // transformed and stored (blocks jb <= N/8); pass 2 rebuilds the other half by conjugation (p2_load).  The
 // Nyquist-column job (jb == N/4) has no height term at all.
-MW_HD bool p1_field_active(int N, int jb, int f, int cw = 4) { return f != 0 || jb <= N / (2 * cw); }
+//
+// The slope field (f = 2) is split, MW_SPLIT_SLOPES: Z3 = cx Ha_x + cz Ha_z with cz = kz(j) constant along the pass-1
+// direction, so its first transform is  T3(a,j) = G(a,j) + kz(j) T1(a,j) [+ the Nyquist-column term C3(a) at j = 0],
+// G = the transform of the cx part alone.  G belongs to the REAL output Sx, i.e. it is Hermitian in j like the height
+// rows: pass 1 transforms and stores G for j <= N/2 only and pass 2 assembles T3 from G and the height rows it reads
+// anyway (p2_fetch).  2.0 instead of 2.5 complex fields cross the exchange buffer and pass 1 transforms a fifth less.
+#ifndef MW_SPLIT_SLOPES
+#define MW_SPLIT_SLOPES 1
+#endif
+#ifndef MW_SLOPE_FENCE_Q
+#define MW_SLOPE_FENCE_Q 8
+#endif
+MW_HD bool p1_field_active(int N, int jb, int f, int cw = 4) {
+    if (f == 1) return true;
+    if (f == 2 && (!MW_SPLIT_SLOPES || jb == N / cw)) return true;  // whole field / the Nyquist-column job keeps its cz term
+    return jb <= N / (2 * cw);
+}
 
 // animated packed spectrum, P points per thread (column job w, i = u + T q)
 template <int N, int P>
@@ -377,7 +393,8 @@ MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, const P1State<P>& s
     for (int q = 0; q < P; q++) {
         cf cx, cz;
         field_coeffs(f, wave_k_fast(N, kscale, u + T * q), kz, &cx, &cz);
-        x[q] = cmul(cscale(cx, fx) + cz, st.hh[q]);
+        if (MW_SPLIT_SLOPES && f == 2) x[q] = cmul(fix ? cz : cx, st.hh[q]);  // regular column: G only (see p1_field_active)
+        else x[q] = cmul(cscale(cx, fx) + cz, st.hh[q]);
         if (q == 0) x[0] = x[0] + cmul(cx, st.dl0);  // i = 0 correction (dl0 == 0 unless u == 0)
     }
 }
@@ -474,7 +491,10 @@ MW_HD void p2_load_map(int tid, int* r1, int* u1) {
 
 // global loads of one field's row data (row-interleaved mapping).  Split from the stage-0 pass so that the kernel
 // can issue field k+1's loads before it starts field k's exchanges (software prefetch: twice the bytes in flight).
-template <int N, int P, int R2>
+// PART (slope field with MW_SPLIT_SLOPES only): 0 = the whole load; 1 = G alone, raw; 2 = the assembly x <- (x + kz T1')' on
+// top of part 1.  The sequential-halo kernel issues part 1 of all its virtual threads, then part 2 + stage 0 one virtual
+// thread at a time: the height rows' 2P registers are then live for one virtual thread only.
+template <int N, int P, int R2, int PART = 0>
 MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P]) {
     constexpr int T = FftGeom<N, P>::T;
     int r1, u1;
@@ -504,16 +524,59 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
         return;
     }
 #endif
+    // Half-stored fields (height; with MW_SPLIT_SLOPES also G): element j > N/2 is conj of element m = N - j.  With T a
+    // multiple of CW, slot q is mirrored for every lane (T q > N/2), for none (T (q + 1) <= N/2), or -- the one slot with
+    // T q == N/2 -- for the lanes u1 > 0: the decision is compile-time and two per-lane offsets serve all slots,
+    //   plain:    voff  + q (T/CW) N CW          mirrored (m = N - u1 - T q):   voffm - q (T/CW) N CW
+    const bool half = (f == 0) || (MW_SPLIT_SLOPES && f == 2);
+    if (half && T % CW == 0 && (N / 2) % T == 0) {
+        const int m0 = N - u1;  // u1 == 0: m0 = N is never dereferenced with q = 0 (slot 0 is plain)
+        const unsigned voffm = (unsigned)(((m0 / CW) * N + r1) * CW + (m0 % CW));
+        const cf* E0 = A.E + ((size_t)step * 3 + 0) * N * N + (size_t)ab * R2 * CW;  // height rows (for the slope assembly)
+        const float kscale = 2.0f * MW_PI_F / A.c.length;
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const bool all_mir = T * q > N / 2, edge = (T * q == N / 2);
+            const bool mir = all_mir || (edge && u1 > 0);
+            const size_t chunk = (size_t)(T / CW) * q * N * CW;
+            // the edge slot's two candidates differ per lane: select the (non-negative) offset, not the data
+            const size_t ub = edge ? 0 : chunk;  // uniform part
+            const unsigned off = all_mir ? voffm : (edge ? (u1 > 0 ? voffm - (unsigned)chunk : voff + (unsigned)chunk) : voff);
+            cf v = (PART == 2) ? x[q] : mw_load_stream(&(all_mir ? Ef - ub : Ef + ub)[off]);
+            if (PART == 1) { x[q] = v; continue; }
+            if (MW_SPLIT_SLOPES && f == 2) {  // T3(a,j) = G'(a,j) + kz(j) T1'(a,j)
+                const cf t = mw_load_stream(&(all_mir ? E0 - ub : E0 + ub)[off]);
+                const float kz = wave_k_fast(N, kscale, u1 + T * q);
+                v = mk(__builtin_fmaf(kz, t.x, v.x), __builtin_fmaf(kz, t.y, v.y));
+            }
+            x[q] = mir ? cconj(v) : v;
+            if (PART == 2 && MW_SLOPE_FENCE_Q && q % MW_SLOPE_FENCE_Q == MW_SLOPE_FENCE_Q - 1) mw_sched_fence();  // cap the height-row loads in flight
+        }
+        if (PART != 1 && u1 == 0 && f != 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];  // Nyquist column j = 0
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int j = u1 + T * q;
-        if (f == 0 && j > N / 2) {  // height: stored for j <= N/2 only; T(a, j) = conj T(a, N - j)
+        if (half && j > N / 2) {  // stored for j <= N/2 only; T(a, j) = conj T(a, N - j)
             const int m = N - j;
-            x[q] = cconj(mw_load_stream(&Ef[(unsigned)(((m / CW) * N + r1) * CW + (m % CW))]));
-        } else if (T % CW == 0) {
-            x[q] = mw_load_stream(&(Ef + (size_t)(T / CW) * q * N * CW)[voff]);
+            const unsigned off = (unsigned)(((m / CW) * N + r1) * CW + (m % CW));
+            cf v = mw_load_stream(&Ef[off]);
+            if (MW_SPLIT_SLOPES && f == 2) {
+                const cf t = mw_load_stream(&(A.E + ((size_t)step * 3 + 0) * N * N + (size_t)ab * R2 * CW)[off]);
+                const float kz = wave_k_fast(N, 2.0f * MW_PI_F / A.c.length, j);
+                v = mk(__builtin_fmaf(kz, t.x, v.x), __builtin_fmaf(kz, t.y, v.y));
+            }
+            x[q] = cconj(v);
         } else {
-            x[q] = Ef[(unsigned)(((j / CW) * N + r1) * CW + (j % CW))];
+            const unsigned off = (unsigned)(((j / CW) * N + r1) * CW + (j % CW));
+            cf v = (T % CW == 0) ? mw_load_stream(&(Ef + (size_t)(T / CW) * q * N * CW)[voff]) : Ef[off];
+            if (MW_SPLIT_SLOPES && f == 2) {
+                const cf t = mw_load_stream(&(A.E + ((size_t)step * 3 + 0) * N * N + (size_t)ab * R2 * CW)[off]);
+                const float kz = wave_k_fast(N, 2.0f * MW_PI_F / A.c.length, j);
+                v = mk(__builtin_fmaf(kz, t.x, v.x), __builtin_fmaf(kz, t.y, v.y));
+            }
+            x[q] = v;
         }
     }
     if (u1 == 0 && f != 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];  // Nyquist column j = 0
@@ -529,6 +592,9 @@ MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P]
     p2_fetch<N, P, R2>(A, ab, step, tid, f, x);
     p2_stage0<N, P, R2>(tid, x, lds);
 }
+// the slope field can be loaded in two parts (p2_fetch) when the fast half-field path applies
+template <int N, int P>
+struct P2SlopeParts { static constexpr bool value = MW_SPLIT_SLOPES && (FftGeom<N, P>::T % Exch<N>::CW == 0); };
 
 // middle passes: with the padded LDS layout they keep the load-side (row-interleaved) mapping (measured fewer bank
 // conflicts than row-major); with the exact layouts (XLay) a wave stays inside one row, where every access is conflict-free
@@ -801,6 +867,9 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 #ifndef MW_PT
 #define MW_PT 8
 #endif
+#ifndef MW_PT_OR
+#define MW_PT_OR MW_PT
+#endif
 #ifndef MW_PT1
 #define MW_PT1 16  // pass 1: 16 points/thread (one exchange fewer; 125 VGPRs, 4 workgroups of 4 waves per CU) measured 1 % ahead of 8
 #endif
@@ -859,7 +928,7 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 #define MW_R2_SMALL_N 256  // grids up to this size use 8 rows + halo per pass-2 workgroup (256^2: +3.5 %; 512^2: -3 %)
 #endif
 template <int N> struct Plan {
-    static constexpr int P = (N >= 2048) ? 16 : MW_PT;    // OceanRenderer passes
+    static constexpr int P = (N >= 2048) ? 16 : MW_PT_OR;  // OceanRenderer passes
     static constexpr int P1 = (N >= 2048) ? 16 : MW_PT1;  // 5 x N/8 threads would exceed 1024 at N = 2048
     static constexpr int P2 = (N >= 4096) ? MW_PT2_4096 : (N == 2048 ? MW_PT2_2048 : (N == 1024 ? MW_PT2_1024 : MW_PT2));
     static constexpr bool HS = (N >= 4096) ? (MW_HS_4096 != 0) : (N == 2048 ? (MW_HS_2048 != 0) : (N == 1024 ? (MW_HS_1024 != 0) : false));

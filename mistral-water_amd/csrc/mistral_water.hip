@@ -319,7 +319,10 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
 #ifndef MW_HS_HALO_EARLY
 #define MW_HS_HALO_EARLY 1
 #endif
-    constexpr bool HALO_EARLY = (MW_HS_HALO_EARLY != 0) && VT >= 2;
+#ifndef MW_HS_HALO_EARLY_2048
+#define MW_HS_HALO_EARLY_2048 0  // with the split slope field the 2048^2 kernel has no room for the 32 VGPRs (44 spilled dwords: -12 %)
+#endif
+    constexpr bool HALO_EARLY = (N == 2048 ? (MW_HS_HALO_EARLY_2048 != 0) : (MW_HS_HALO_EARLY != 0)) && VT >= 2;
     cf xh[HALO_EARLY ? P : 1];  // halo row data parked in registers across the displacement transform
     const int tid = tid0;  // MW_STAMP
     MW_STAMP(1, 0);
@@ -330,8 +333,19 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
         const int f = p2_hs_field(k);
         __syncthreads();  // k = 0: twiddle tables staged; later: the previous phase's LDS reads are done
         MW_STAMP(1, 1 + 8 * k);
+        if (f == 2 && P2SlopeParts<N, P>::value) {  // G of every virtual thread in flight, then height rows + stage 0 one at a time
 #pragma unroll
-        MW_VT(h) p2_load<N, P, R2>(A, ab, step, MW_VTID(h), f, x[h], set0);
+            MW_VT(h) p2_fetch<N, P, R2, 1>(A, ab, step, MW_VTID(h), f, x[h]);
+#pragma unroll
+            MW_VT(h) {
+                p2_fetch<N, P, R2, 2>(A, ab, step, MW_VTID(h), f, x[h]);
+                p2_stage0<N, P, R2>(MW_VTID(h), x[h], set0);
+                mw_sched_fence();
+            }
+        } else {
+#pragma unroll
+            MW_VT(h) p2_load<N, P, R2>(A, ab, step, MW_VTID(h), f, x[h], set0);
+        }
         // The halo row's lines are the next row block's own lines: fetched NOW, while that block (same XCD, same phase)
         // loads them too, they are L2 hits; fetched two phases later they have left the L2 and cost a second 128-B fill
         // per 32-B piece (measured +6 B per grid point).  Needs 2P spare VGPRs across the displacement transform: VT >= 2.
