@@ -101,9 +101,10 @@ MW_HD void mw_store_stream(f4* p, f4 v) {
 #ifndef MW_NT_LOADS
 #define MW_NT_LOADS 0
 #endif
-MW_HD cf mw_load_stream(const cf* p) {
+// MW_NT_LOADS: 1 = every exchange-buffer load non-temporal (-9 % at 1024^2), 2 = only the loads flagged `last_use`
+MW_HD cf mw_load_stream(const cf* p, bool last_use = false) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (MW_NT_LOADS) {
+    if (MW_NT_LOADS == 1 || (MW_NT_LOADS == 2 && last_use)) {
         typedef float f2v __attribute__((ext_vector_type(2)));
         const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(p));
         return mk(t.x, t.y);
@@ -329,20 +330,29 @@ MW_HD void field_coeffs(int f, float kx, float kz, cf* cx, cf* cz) {
 // transformed and stored (blocks jb <= N/8); pass 2 rebuilds the other half by conjugation (p2_load).  The
 // Nyquist-column job (jb == N/4) has no height term at all.
 //
-// The slope field (f = 2) is split, MW_SPLIT_SLOPES: Z3 = cx Ha_x + cz Ha_z with cz = kz(j) constant along the pass-1
-// direction, so its first transform is  T3(a,j) = G(a,j) + kz(j) T1(a,j) [+ the Nyquist-column term C3(a) at j = 0],
+// The slope field (f = 2) is half-stored too, MW_SPLIT_SLOPES: Z3 = cx Ha_x + cz Ha_z with cz = kz(j) constant along the
+// pass-1 direction, so its first transform is  T3(a,j) = G(a,j) + kz(j) T1(a,j) [+ the Nyquist-column term C3(a) at j = 0],
 // G = the transform of the cx part alone.  G belongs to the REAL output Sx, i.e. it is Hermitian in j like the height
-// rows: pass 1 transforms and stores G for j <= N/2 only and pass 2 assembles T3 from G and the height rows it reads
-// anyway (p2_fetch).  2.0 instead of 2.5 complex fields cross the exchange buffer and pass 1 transforms a fifth less.
+// rows T1, and kz(N - j) = -kz(j).  Pass 1 transforms and stores the slope field for the columns j <= N/2 only; pass 2 forms
+//   mode 1 (stores G):   T3(a,j) = G'(a,j) + kz(j) T1'(a,j)            -- every element needs its height-row element again
+//   mode 2 (stores T3):  T3(a,j) = T3(a,j)                              for j <= N/2
+//                        T3(a,j) = conj(T3(a,m) - 2 kz(m) T1(a,m)), m = N - j   -- only the mirrored half re-reads T1
+// 2.0 instead of 2.5 complex fields cross the exchange buffer and pass 1 transforms a fifth less.
+// Mode 2 issues half as many height-row loads: +2 % at 1024^2, +1 % at 2048^2, -0.8 % at 4096^2 (fetched bytes are equal:
+// either way pass 2 reads the stored half of the height rows a second time, 4 B per grid point, and it comes from beyond L2).
 #ifndef MW_SPLIT_SLOPES
-#define MW_SPLIT_SLOPES 1
+#define MW_SPLIT_SLOPES 2
 #endif
+#ifndef MW_SPLIT_SLOPES_4096
+#define MW_SPLIT_SLOPES_4096 (MW_SPLIT_SLOPES ? 1 : 0)
+#endif
+MW_HD constexpr int mw_split_slopes(int N) { return N >= 4096 ? MW_SPLIT_SLOPES_4096 : MW_SPLIT_SLOPES; }
 #ifndef MW_SLOPE_FENCE_Q
 #define MW_SLOPE_FENCE_Q 8
 #endif
 MW_HD bool p1_field_active(int N, int jb, int f, int cw = 4) {
     if (f == 1) return true;
-    if (f == 2 && (!MW_SPLIT_SLOPES || jb == N / cw)) return true;  // whole field / the Nyquist-column job keeps its cz term
+    if (f == 2 && (!mw_split_slopes(N) || jb == N / cw)) return true;  // whole field / the Nyquist-column job keeps its cz term
     return jb <= N / (2 * cw);
 }
 
@@ -393,7 +403,7 @@ MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, const P1State<P>& s
     for (int q = 0; q < P; q++) {
         cf cx, cz;
         field_coeffs(f, wave_k_fast(N, kscale, u + T * q), kz, &cx, &cz);
-        if (MW_SPLIT_SLOPES && f == 2) x[q] = cmul(fix ? cz : cx, st.hh[q]);  // regular column: G only (see p1_field_active)
+        if (mw_split_slopes(N) == 1 && f == 2) x[q] = cmul(fix ? cz : cx, st.hh[q]);  // regular column: G only (see p1_field_active)
         else x[q] = cmul(cscale(cx, fx) + cz, st.hh[q]);
         if (q == 0) x[0] = x[0] + cmul(cx, st.dl0);  // i = 0 correction (dl0 == 0 unless u == 0)
     }
@@ -457,7 +467,10 @@ struct P2Geom {
     static constexpr bool NOISE_REG = HS || !MW_NOISE_LDS;
     static constexpr int NOISE_OFF = TW_LDS + NBUF * SETSTRIDE;  // cf units
     static constexpr int NOISE_CF = NOISE_REG ? 0 : R2 * N / 2;
-    static constexpr int LDS_BYTES = (NOISE_OFF + NOISE_CF) * (int)sizeof(cf);
+#ifndef MW_P2_LDS_EXTRA
+#define MW_P2_LDS_EXTRA 0  // occupancy experiments: bytes of unused LDS per pass-2 workgroup
+#endif
+    static constexpr int LDS_BYTES = (NOISE_OFF + NOISE_CF) * (int)sizeof(cf) + MW_P2_LDS_EXTRA;
     static_assert(NTHREADS <= 1024, "workgroup too large");
 };
 
@@ -528,7 +541,7 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
     // multiple of CW, slot q is mirrored for every lane (T q > N/2), for none (T (q + 1) <= N/2), or -- the one slot with
     // T q == N/2 -- for the lanes u1 > 0: the decision is compile-time and two per-lane offsets serve all slots,
     //   plain:    voff  + q (T/CW) N CW          mirrored (m = N - u1 - T q):   voffm - q (T/CW) N CW
-    const bool half = (f == 0) || (MW_SPLIT_SLOPES && f == 2);
+    const bool half = (f == 0) || (mw_split_slopes(N) && f == 2);
     if (half && T % CW == 0 && (N / 2) % T == 0) {
         const int m0 = N - u1;  // u1 == 0: m0 = N is never dereferenced with q = 0 (slot 0 is plain)
         const unsigned voffm = (unsigned)(((m0 / CW) * N + r1) * CW + (m0 % CW));
@@ -542,12 +555,18 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
             // the edge slot's two candidates differ per lane: select the (non-negative) offset, not the data
             const size_t ub = edge ? 0 : chunk;  // uniform part
             const unsigned off = all_mir ? voffm : (edge ? (u1 > 0 ? voffm - (unsigned)chunk : voff + (unsigned)chunk) : voff);
-            cf v = (PART == 2) ? x[q] : mw_load_stream(&(all_mir ? Ef - ub : Ef + ub)[off]);
+            cf v = (PART == 2) ? x[q] : mw_load_stream(&(all_mir ? Ef - ub : Ef + ub)[off], f != 0);
             if (PART == 1) { x[q] = v; continue; }
-            if (MW_SPLIT_SLOPES && f == 2) {  // T3(a,j) = G'(a,j) + kz(j) T1'(a,j)
-                const cf t = mw_load_stream(&(all_mir ? E0 - ub : E0 + ub)[off]);
+            if (mw_split_slopes(N) == 1 && f == 2) {  // T3(a,j) = G'(a,j) + kz(j) T1'(a,j)
+                const cf t = mw_load_stream(&(all_mir ? E0 - ub : E0 + ub)[off], true);
                 const float kz = wave_k_fast(N, kscale, u1 + T * q);
                 v = mk(__builtin_fmaf(kz, t.x, v.x), __builtin_fmaf(kz, t.y, v.y));
+            }
+            if (mw_split_slopes(N) == 2 && f == 2 && (all_mir || edge)) {  // T3(a,j) = conj(T3(a,m) - 2 kz(m) T1(a,m)), kz(m) = -kz(j)
+                const cf t = mw_load_stream(&(all_mir ? E0 - ub : E0 + ub)[off], true);
+                const float k2 = 2.0f * wave_k_fast(N, kscale, u1 + T * q);
+                const float c = mir ? k2 : 0.f;  // the edge slot's lane u1 == 0 is j = N/2: plain
+                v = mk(__builtin_fmaf(c, t.x, v.x), __builtin_fmaf(c, t.y, v.y));
             }
             x[q] = mir ? cconj(v) : v;
             if (PART == 2 && MW_SLOPE_FENCE_Q && q % MW_SLOPE_FENCE_Q == MW_SLOPE_FENCE_Q - 1) mw_sched_fence();  // cap the height-row loads in flight
@@ -562,16 +581,16 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
             const int m = N - j;
             const unsigned off = (unsigned)(((m / CW) * N + r1) * CW + (m % CW));
             cf v = mw_load_stream(&Ef[off]);
-            if (MW_SPLIT_SLOPES && f == 2) {
+            if (mw_split_slopes(N) && f == 2) {
                 const cf t = mw_load_stream(&(A.E + ((size_t)step * 3 + 0) * N * N + (size_t)ab * R2 * CW)[off]);
-                const float kz = wave_k_fast(N, 2.0f * MW_PI_F / A.c.length, j);
+                const float kz = (mw_split_slopes(N) == 2 ? 2.0f : 1.0f) * wave_k_fast(N, 2.0f * MW_PI_F / A.c.length, j);
                 v = mk(__builtin_fmaf(kz, t.x, v.x), __builtin_fmaf(kz, t.y, v.y));
             }
             x[q] = cconj(v);
         } else {
             const unsigned off = (unsigned)(((j / CW) * N + r1) * CW + (j % CW));
-            cf v = (T % CW == 0) ? mw_load_stream(&(Ef + (size_t)(T / CW) * q * N * CW)[voff]) : Ef[off];
-            if (MW_SPLIT_SLOPES && f == 2) {
+            cf v = (T % CW == 0) ? mw_load_stream(&(Ef + (size_t)(T / CW) * q * N * CW)[voff], f != 0) : Ef[off];
+            if (mw_split_slopes(N) == 1 && f == 2) {
                 const cf t = mw_load_stream(&(A.E + ((size_t)step * 3 + 0) * N * N + (size_t)ab * R2 * CW)[off]);
                 const float kz = wave_k_fast(N, 2.0f * MW_PI_F / A.c.length, j);
                 v = mk(__builtin_fmaf(kz, t.x, v.x), __builtin_fmaf(kz, t.y, v.y));
@@ -594,7 +613,7 @@ MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P]
 }
 // the slope field can be loaded in two parts (p2_fetch) when the fast half-field path applies
 template <int N, int P>
-struct P2SlopeParts { static constexpr bool value = MW_SPLIT_SLOPES && (FftGeom<N, P>::T % Exch<N>::CW == 0); };
+struct P2SlopeParts { static constexpr bool value = mw_split_slopes(N) != 0 && (FftGeom<N, P>::T % Exch<N>::CW == 0); };
 
 // middle passes: with the padded LDS layout they keep the load-side (row-interleaved) mapping (measured fewer bank
 // conflicts than row-major); with the exact layouts (XLay) a wave stays inside one row, where every access is conflict-free

@@ -11,7 +11,15 @@ SO = os.path.join(HERE, "emul", "libemul.so")
 CSRC = os.path.join(os.path.dirname(HERE), "mistral-water_amd", "csrc")
 
 
-def build():
+def build(defs=()):
+    """defs: extra -D macros (a differently configured build of the same kernels, e.g. ("MW_SPLIT_SLOPES=1",)) -> its own .so"""
+    if defs:
+        so = os.path.join(HERE, "emul", "libemul_" + "_".join(d.replace("=", "") for d in defs) + ".so")
+        deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+        if not (os.path.exists(so) and all(os.path.getmtime(d) <= os.path.getmtime(so) for d in deps)):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"] + ["-D" + d for d in defs] + ["-o", so, SRC],
+                           check=True)
+        return so
     if os.environ.get("MW_SANITIZE") == "1":   # AddressSanitizer + UBSan build (tests/test_sanitizers.py, libasan preloaded)
         so = os.path.join(HERE, "emul", "libemul_san.so")
         deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -31,8 +39,8 @@ def _p(a):
 
 
 class Emul:
-    def __init__(self):
-        self.L = C.CDLL(build())
+    def __init__(self, defs=()):
+        self.L = C.CDLL(build(defs))
 
     def set_variant(self, force_hs=False):
         """force_hs: run the sequential-halo pass 2 (the product's N >= 4096 kernel) at every grid size."""

@@ -72,6 +72,39 @@ def test_pipeline_vs_oracle_f64(emul, oracle, N, pts):
         workloads.assert_parity(v[k], n[k], w[k], vf, nf, cf, rest, np.abs(hds).max(), tag=f"N={N} t={t}")
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_slope_field_storage_modes(oracle, mode):
+    """MW_SPLIT_SLOPES: the slope field crosses the exchange buffer whole (0), as the kx part G for j <= N/2 with
+    T3 = G + kz T1 assembled in pass 2 (1, the 4096^2 plan), or as T3 for j <= N/2 with the mirrored half rebuilt as
+    conj(T3 - 2 kz T1) (2, the default).  Every mode against the oracle, including the Nyquist lines; sequential-halo
+    kernel (the two-part load) and halo-group kernel bit-identical."""
+    import emul_build
+    e = emul_build.Emul(defs=(f"MW_SPLIT_SLOPES={mode}", f"MW_SPLIT_SLOPES_4096={mode}"))
+    for N, pts in ((128, 16), (256, 8)):
+        p = workloads.fftmesh_params(N)
+        h0, h0c = oracle.generate_spectrum(p, 5)
+        times = [0.0, 7.3]
+        v, n, w = e.evaluate(p, h0, h0c, times, pts=pts)
+        rest = oracle.rest_mesh(p)[0]
+        for k, t in enumerate(times):
+            vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, t, return_hds=True)
+            workloads.assert_parity(v[k], n[k], w[k], vf, nf, cf, rest, np.abs(hds).max(), tag=f"mode={mode} N={N} t={t}")
+        try:
+            e.set_variant(force_hs=True)
+            v1, n1, w1 = e.evaluate(p, h0, h0c, times, pts=pts)
+        finally:
+            e.set_variant(force_hs=False)
+        assert (v == v1).all() and (n == n1).all() and (w == w1).all()
+    # Nyquist lines only: the j = 0 column (C3 term) and the i = 0 row through every mode
+    p = workloads.fftmesh_params(64)
+    h0, h0c = oracle.generate_spectrum(p, 3)
+    m0 = np.zeros_like(h0); m0c = np.zeros_like(h0c)
+    m0[0, :] = h0[0, :]; m0[:, 0] = h0[:, 0]; m0c[0, :] = h0c[0, :]; m0c[:, 0] = h0c[:, 0]
+    v, n, w = e.evaluate(p, m0, m0c, [2.5], pts=16)
+    vf, nf, cf, hds = oracle.eval_fft_f64(p, m0, m0c, 2.5, return_hds=True)
+    workloads.assert_parity(v[0], n[0], w[0], vf, nf, cf, oracle.rest_mesh(p)[0], max(np.abs(hds).max(), 1e-30), tag=f"mode={mode} nyquist")
+
+
 @pytest.mark.parametrize("N,pts", [(64, 8), (128, 16), (256, 8)])
 def test_sequential_halo_pass2_equals_halo_group_pass2(emul, oracle, N, pts):
     """The N >= 4096 kernel (k_pass2_hs: no halo thread group, halo row transformed after the displacement field, whitecap
