@@ -289,7 +289,7 @@ struct P1Geom {
     static constexpr int CW = Exch<N>::CW;  // spectrum columns per workgroup
     static constexpr int NTHREADS = CW * T;
     static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + (XLay<N, P>::EXACT ? XLay<N, P>::PAD_RD4 : MW_BUF_PAD);
-    static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;  // cf units, 16-B aligned
+    static constexpr int TW_LDS = (TwGeom<N, P>::LDS_ALL + 1) & ~1;  // cf units, 16-B aligned
     static constexpr int SETSTRIDE = CW * BUFSTRIDE;
     // 2: ping-pong exchange buffers, one barrier per exchange (when both sets fit a 100 KiB budget)
     static constexpr int NBUF = (MW_DBUF && (TW_LDS + 2 * SETSTRIDE) * 8 <= 100 * 1024) ? 2 : 1;
@@ -459,7 +459,7 @@ struct P2Geom {
     static constexpr int NGROUPS = HS ? R2 : R2 + 1;
     static constexpr int NTHREADS = NGROUPS * T;
     static constexpr int BUFSTRIDE = P2Buf<N, P>::BUFSTRIDE;
-    static constexpr int TW_LDS = (TwGeom<N, P>::LDS_CF + 1) & ~1;
+    static constexpr int TW_LDS = (TwGeom<N, P>::LDS_ALL + 1) & ~1;
     static constexpr int SETSTRIDE = NGROUPS * BUFSTRIDE;
     static constexpr int NBUF = (!HS && MW_DBUF && (TW_LDS + 2 * SETSTRIDE) * 8 <= 100 * 1024) ? 2 : 1;
     // the whitecap noise term |0.3 n.xz| waits in LDS (R2*N floats) from the slope field to the epilogue instead of
@@ -507,8 +507,10 @@ MW_HD void p2_load_map(int tid, int* r1, int* u1) {
 // PART (slope field with MW_SPLIT_SLOPES only): 0 = the whole load; 1 = G alone, raw; 2 = the assembly x <- (x + kz T1')' on
 // top of part 1.  The sequential-halo kernel issues part 1 of all its virtual threads, then part 2 + stage 0 one virtual
 // thread at a time: the height rows' 2P registers are then live for one virtual thread only.
+// nyq != nullptr: the Nyquist-column term is returned there instead of being added to x[0] (a prefetch must not consume any
+// of its loads: the add's s_waitcnt would wait for all of them, vmcnt being in-order); the caller adds it when it uses x.
 template <int N, int P, int R2, int PART = 0>
-MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P]) {
+MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P], cf* nyq = nullptr) {
     constexpr int T = FftGeom<N, P>::T;
     int r1, u1;
     p2_load_map<N, P, R2>(tid, &r1, &u1);
@@ -571,7 +573,10 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
             x[q] = mir ? cconj(v) : v;
             if (PART == 2 && MW_SLOPE_FENCE_Q && q % MW_SLOPE_FENCE_Q == MW_SLOPE_FENCE_Q - 1) mw_sched_fence();  // cap the height-row loads in flight
         }
-        if (PART != 1 && u1 == 0 && f != 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];  // Nyquist column j = 0
+        if (PART != 1 && f != 0) {  // Nyquist column j = 0
+            if (nyq) *nyq = (u1 == 0) ? A.Cj0[((size_t)step * 3 + f) * N + row] : mk(0.f, 0.f);
+            else if (u1 == 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];
+        }
         return;
     }
 #pragma unroll
@@ -598,7 +603,10 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
             x[q] = v;
         }
     }
-    if (u1 == 0 && f != 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];  // Nyquist column j = 0
+    if (f != 0) {  // Nyquist column j = 0
+        if (nyq) *nyq = (u1 == 0) ? A.Cj0[((size_t)step * 3 + f) * N + row] : mk(0.f, 0.f);
+        else if (u1 == 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + f) * N + row];
+    }
 }
 template <int N, int P, int R2>
 MW_HD void p2_stage0(int tid, cf (&x)[P], cf* lds) {
@@ -860,7 +868,7 @@ MW_HD void p2_hs_finish_slopes(const P2Args& A, const Twiddles& tw, int ab, int 
 
 // halo row a0+R2 of the displacement field, loaded by group 0 in the row-major mapping (thread u: j = u + T q)
 template <int N, int P, int R2>
-MW_HD void p2_hs_halo_fetch(const P2Args& A, int ab, int step, int u, cf (&x)[P]) {
+MW_HD void p2_hs_halo_fetch(const P2Args& A, int ab, int step, int u, cf (&x)[P], cf* nyq = nullptr) {
     constexpr int T = FftGeom<N, P>::T;
     const int row = ab * R2 + R2;
     constexpr int CW = Exch<N>::CW;
@@ -868,7 +876,8 @@ MW_HD void p2_hs_halo_fetch(const P2Args& A, int ab, int step, int u, cf (&x)[P]
     const unsigned voff = (unsigned)((u / CW) * N * CW + (u % CW));
 #pragma unroll
     for (int q = 0; q < P; q++) x[q] = (Ef + (size_t)(T / CW) * q * N * CW)[voff];
-    if (u == 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + 1) * N + row];  // Nyquist column j = 0
+    if (nyq) *nyq = (u == 0) ? A.Cj0[((size_t)step * 3 + 1) * N + row] : mk(0.f, 0.f);
+    else if (u == 0) x[0] = x[0] + A.Cj0[((size_t)step * 3 + 1) * N + row];  // Nyquist column j = 0
 }
 // transformed halo row -> plain hds row in buffer 0
 template <int N, int P, int R2>
@@ -940,6 +949,16 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 #ifndef MW_VT1_4096
 #define MW_VT1_4096 1
 #endif
+// software prefetch level of k_pass2_hs (0 none, 1 displacement rows during the height field, 2 + slope rows during displacement)
+#ifndef MW_PF_4096
+#define MW_PF_4096 1  // 4096^2 (one workgroup per CU): pass 2 -1.5 %; 2048^2 +1 %, 1024^2 +1 % slower with it
+#endif
+#ifndef MW_PF_2048
+#define MW_PF_2048 0
+#endif
+#ifndef MW_PF_1024
+#define MW_PF_1024 0
+#endif
 #ifndef MW_VT1_2048
 #define MW_VT1_2048 1
 #endif
@@ -955,6 +974,7 @@ template <int N> struct Plan {
     // virtual threads per lane of the sequential-halo kernel (k_pass2_hs): 2 = 8 fat waves with a 256-VGPR budget
     static constexpr int VT = (N >= 4096) ? MW_VT_4096 : (N == 2048 ? MW_VT_2048 : MW_VT_1024);
     static constexpr int VT1 = (N >= 4096) ? MW_VT1_4096 : (N == 2048 ? MW_VT1_2048 : 1);  // the same for pass 1
+    static constexpr int PF = (N >= 4096) ? MW_PF_4096 : (N == 2048 ? MW_PF_2048 : MW_PF_1024);
 };
 
 }  // namespace mw

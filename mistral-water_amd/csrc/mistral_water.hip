@@ -96,9 +96,12 @@ __device__ long long g_stamps[2][64][8][32];  // [kernel][block slot][wave][stam
 // LDS layout of both pass kernels: [twiddle tables, if small] [NBUF sets of exchange buffers].  With
 // NBUF == 2 the sets are used ping-pong (every store goes to the set the previous load did NOT read), so
 // one barrier per exchange suffices; with NBUF == 1 a second (WAR) barrier follows every load.
-template <int TOTAL, int NT>
-__device__ __forceinline__ void stage_tables(cf* dst, const cf* __restrict__ src, int tid) {
-    for (int i = tid; i < TOTAL; i += NT) dst[i] = src[i];
+template <int N, int P, int NT>
+__device__ __forceinline__ void stage_twiddles(cf* dst, const cf* __restrict__ src, int tid) {
+    using TG = TwGeom<N, P>;
+    for (int i = tid; i < TG::LDS_CF; i += NT) dst[i] = src[i];
+    if (TG::PW_CF)  // base twiddles of the powers pass: entry 1 of every (P+1)-entry row
+        for (int i = tid; i < TG::PW_CF; i += NT) dst[TG::LDS_CF + i] = src[TG::off_ts(TG::POW_STAGE) + i * (P + 1) + 1];
 }
 
 // VT = virtual threads per lane (see k_pass2_hs): the phase functions are written for 4*T virtual threads (4 spectrum
@@ -115,7 +118,7 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
     int jb = blockIdx.x, step = blockIdx.y;
     if (A.tgroup > 0 && !p1_block_map((int)blockIdx.x, G::GRID_X, A.nsteps, A.tgroup, &jb, &step)) return;
     const float t = times.t[step];
-    if (TwGeom<N, P>::LDS_CF) stage_tables<TwGeom<N, P>::LDS_CF, NT>(lds, A.TW, tid);  // visible after the first barrier
+    if (TwGeom<N, P>::LDS_ALL) stage_twiddles<N, P, NT>(lds, A.TW, tid);  // visible after the first barrier
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     int cur = 0;  // set the next store goes to
@@ -198,7 +201,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
     // the same XCD's L2 instead of a second 128-B line fill across the fabric.
     const int ab = p2_row_block<N / R2>((int)blockIdx.x);
     const int g = tid / T;
-    if (TwGeom<N, P>::LDS_CF) stage_tables<TwGeom<N, P>::LDS_CF, G::NTHREADS>(lds, A.TW, tid);
+    if (TwGeom<N, P>::LDS_ALL) stage_twiddles<N, P, G::NTHREADS>(lds, A.TW, tid);
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     float* noise_lds = reinterpret_cast<float*>(lds + G::NOISE_OFF);
@@ -296,7 +299,7 @@ constexpr int hs_min_waves(int nthreads, int lds_bytes) {
     const int w = nthreads / 64 * wgs / 4;
     return w < 1 ? 1 : (w > 8 ? 8 : w);
 }
-template <int N, int P, int R2, int VT, bool DUMP = false>
+template <int N, int P, int R2, int VT, bool DUMP = false, int PF = 0>
 __global__ __launch_bounds__((P2Geom<N, P, R2, true>::NTHREADS / VT))
 __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS / VT, P2Geom<N, P, R2, true>::LDS_BYTES)))) void k_pass2_hs(P2Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -311,7 +314,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
     const int ab = p2_row_block<N / R2>((int)blockIdx.x);  // neighbouring row blocks (halo rows, shared 128-B lines) on one XCD
 #endif
     const int g0 = wave_uniform<true>(tid0 / T);  // row group of virtual thread 0; virtual thread h is in group g0 + h * NT / T
-    if (TwGeom<N, P>::LDS_CF) stage_tables<TwGeom<N, P>::LDS_CF, NT>(lds, A.TW, tid0);
+    if (TwGeom<N, P>::LDS_ALL) stage_twiddles<N, P, NT>(lds, A.TW, tid0);
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     P2StateHS<P> st[VT];
@@ -322,20 +325,64 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
 #ifndef MW_HS_HALO_EARLY_2048
 #define MW_HS_HALO_EARLY_2048 0  // with the split slope field the 2048^2 kernel has no room for the 32 VGPRs (44 spilled dwords: -12 %)
 #endif
-    constexpr bool HALO_EARLY = (N == 2048 ? (MW_HS_HALO_EARLY_2048 != 0) : (MW_HS_HALO_EARLY != 0)) && VT >= 2;
+#ifndef MW_HS_HALO_EARLY_4096
+#define MW_HS_HALO_EARLY_4096 0  // 4096^2 prefetches the displacement rows during the height field instead (PF = 1): the two together spill
+#endif
+    constexpr bool HALO_EARLY =
+        (N == 2048 ? (MW_HS_HALO_EARLY_2048 != 0) : (N >= 4096 ? (MW_HS_HALO_EARLY_4096 != 0) : (MW_HS_HALO_EARLY != 0))) && VT >= 2;
     cf xh[HALO_EARLY ? P : 1];  // halo row data parked in registers across the displacement transform
     const int tid = tid0;  // MW_STAMP
     MW_STAMP(1, 0);
 #define MW_VT(h) for (int h = 0; h < VT; h++)
 #define MW_VTID(h) (mw_fresh(tid0) + (h) * NT)
+    // PF = 1 (software prefetch; the one-workgroup-per-CU plan, 4096^2): the displacement field's exchange-buffer rows are
+    // requested while the height field -- whose phase holds nothing but x -- is transformed, into a second register set.
+    // Three things make the loads really asynchronous: the height field's own loads are issued first (scheduling fence;
+    // vmcnt is in-order), the Nyquist-column term is added at use (p2_fetch's nyq), and no pass of the transform reads
+    // global memory (TwGeom::PW_CF).  Measured: pass 2 -1.5 % at 4096^2, +1 % at 1024^2 and 2048^2 (off there).  Prefetching the
+    // slope rows during the displacement transform as well (all of them: 17 spilled dwords; one virtual thread's: 243
+    // VGPRs) made the kernel 4-11 % slower: removed.
+    static_assert(PF == 0 || PF == 1, "prefetch level");
+    constexpr bool SPARTS = P2SlopeParts<N, P>::value;
+    cf xn[PF ? VT : 1][PF ? P : 1], xn_nyq[PF ? VT : 1], xh_nyq = mk(0.f, 0.f);
+    (void)xn; (void)xn_nyq;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int f = p2_hs_field(k);
         __syncthreads();  // k = 0: twiddle tables staged; later: the previous phase's LDS reads are done
         MW_STAMP(1, 1 + 8 * k);
-        if (f == 2 && P2SlopeParts<N, P>::value) {  // G of every virtual thread in flight, then height rows + stage 0 one at a time
+        if (PF == 1 && k == 1) {  // compile-time: k is unrolled
+            if constexpr (PF != 0) {
+#pragma unroll
+                MW_VT(h) {
+#pragma unroll
+                    for (int q = 0; q < P; q++) x[h][q] = xn[h][q];
+                    int r1, u1;
+                    p2_load_map<N, P, R2>(MW_VTID(h), &r1, &u1);
+                    if (u1 == 0) x[h][0] = x[h][0] + xn_nyq[h];
+                }
+            }
+        } else if (f == 2 && SPARTS) {  // the slope half of every virtual thread in flight, then height rows + stage 0 one at a time
 #pragma unroll
             MW_VT(h) p2_fetch<N, P, R2, 1>(A, ab, step, MW_VTID(h), f, x[h]);
+        } else {
+#pragma unroll
+            MW_VT(h) p2_fetch<N, P, R2>(A, ab, step, MW_VTID(h), f, x[h]);
+        }
+        if constexpr (PF != 0) {
+            if (k == 0) {
+                mw_sched_fence();
+#pragma unroll
+                MW_VT(h) p2_fetch<N, P, R2>(A, ab, step, MW_VTID(h), p2_hs_field(1), xn[h], &xn_nyq[h]);
+            }
+        }
+        // The halo row's lines are the next row block's own lines: fetched while that block (same XCD, same phase) loads
+        // them too, they are L2 hits; fetched two phases later they have left the L2 and cost a second 128-B fill per
+        // 32-B piece (measured +6 B per grid point).  Needs 2P spare VGPRs across the displacement transform: VT >= 2.
+        if constexpr (HALO_EARLY)
+            if (k == (PF >= 1 ? 0 : 1) && g0 == 0 && ab * R2 + R2 < N)
+                p2_hs_halo_fetch<N, P, R2>(A, ab, step, mw_fresh(tid0) % T, xh, PF >= 1 ? &xh_nyq : nullptr);
+        if (f == 2 && SPARTS) {
 #pragma unroll
             MW_VT(h) {
                 p2_fetch<N, P, R2, 2>(A, ab, step, MW_VTID(h), f, x[h]);
@@ -344,13 +391,8 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
             }
         } else {
 #pragma unroll
-            MW_VT(h) p2_load<N, P, R2>(A, ab, step, MW_VTID(h), f, x[h], set0);
+            MW_VT(h) p2_stage0<N, P, R2>(MW_VTID(h), x[h], set0);
         }
-        // The halo row's lines are the next row block's own lines: fetched NOW, while that block (same XCD, same phase)
-        // loads them too, they are L2 hits; fetched two phases later they have left the L2 and cost a second 128-B fill
-        // per 32-B piece (measured +6 B per grid point).  Needs 2P spare VGPRs across the displacement transform: VT >= 2.
-        if constexpr (HALO_EARLY)
-            if (f == 1 && g0 == 0 && ab * R2 + R2 < N) p2_hs_halo_fetch<N, P, R2>(A, ab, step, mw_fresh(tid0) % T, xh);
         MW_STAMP(1, 2 + 8 * k);
         __syncthreads();
 #pragma unroll
@@ -404,6 +446,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
                 if constexpr (HALO_EARLY) {
 #pragma unroll
                     for (int q = 0; q < P; q++) x[0][q] = xh[q];
+                    if (PF >= 1 && u == 0) x[0][0] = x[0][0] + xh_nyq;
                 } else {
                     p2_hs_halo_fetch<N, P, R2>(A, ab, step, u, x[0]);
                 }
@@ -577,18 +620,18 @@ template <int N, bool DUMP>
 static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     constexpr int P = Plan<N>::P2, R2 = Plan<N>::R2;
     constexpr bool HS = Plan<N>::HS;
-    constexpr int VT = HS ? Plan<N>::VT : 1;
+    constexpr int VT = HS ? Plan<N>::VT : 1, PF = HS ? Plan<N>::PF : 0;
     constexpr int NT = P2Geom<N, P, R2, HS>::NTHREADS / VT, LB = P2Geom<N, P, R2, HS>::LDS_BYTES;
     static AttrOnce attr;
     {
         const void* fn;
-        if constexpr (HS) fn = reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, VT, DUMP>);
+        if constexpr (HS) fn = reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, VT, DUMP, PF>);
         else fn = reinterpret_cast<const void*>(&k_pass2<N, P, R2, DUMP>);
         hipError_t e = attr.set(fn, LB);
         if (e != hipSuccess) return e;
     }
     if constexpr (HS)
-        k_pass2_hs<N, P, R2, VT, DUMP><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
+        k_pass2_hs<N, P, R2, VT, DUMP, PF><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
     else
         k_pass2<N, P, R2, DUMP><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);
     return hipGetLastError();

@@ -353,6 +353,7 @@ template <int SGN> struct DftP<16, SGN> {
 struct Twiddles {
     const cf* TS[4];
     const cf* TF;
+    const cf* PW;  // compact base twiddles of the powers pass (TwGeom::PW_CF entries in LDS) or nullptr
 };
 // one concatenated table [TS1 | TS2 | TS3 | TF] (device global memory).  Its leading sub-tables are copied to LDS up to an
 // 8-KiB budget (`LDS_CF` entries: the whole table when it fits -- every N <= 1024 plan -- else the longest prefix of whole
@@ -383,6 +384,15 @@ struct TwGeom {
 #endif
     static constexpr int POW_STAGE =
         (P >= MW_POW_MIN_P && P <= MW_POW_MAX_P && S >= 2 && off_ts(S - 1) >= LDS_CF && size_ts(S - 1) > LDS_BUDGET_CF) ? S - 1 : 0;
+    // The powers pass reads ONE twiddle per thread, w_k = TS[POW_STAGE][k (P+1) + 1], k < P^POW_STAGE: those P^s values are
+    // gathered into LDS behind the staged prefix (2 KiB at N = 4096), so that no pass of a transform touches global memory
+    // -- a global load in the middle of a transform would make its s_waitcnt (vmcnt is in-order) wait for every
+    // exchange-buffer load prefetched before it (k_pass2_hs, PF).
+#ifndef MW_POW_LDS
+#define MW_POW_LDS 1
+#endif
+    static constexpr int PW_CF = (MW_POW_LDS && POW_STAGE != 0) ? mw_ipow(P, POW_STAGE) : 0;
+    static constexpr int LDS_ALL = LDS_CF + PW_CF;  // cf entries a kernel stages (stage_twiddles)
     // sub-table at offset `off`: the LDS copy when it was staged, else global memory
     static MW_HD const cf* pick(const cf* glob, const cf* lds, int off) { return off < LDS_CF ? lds + off : glob + off; }
     static MW_HD Twiddles view(const cf* glob, const cf* lds) {
@@ -392,9 +402,14 @@ struct TwGeom {
         t.TS[2] = pick(glob, lds, OFF2);
         t.TS[3] = pick(glob, lds, OFF3);
         t.TF = pick(glob, lds, OFFF);
+        t.PW = PW_CF != 0 ? lds + LDS_CF : nullptr;
         return t;
     }
-    static MW_HD Twiddles view(const cf* base) { return view(base, base); }  // host emulation: one flat table
+    static MW_HD Twiddles view(const cf* base) {  // host emulation: one flat table, no PW
+        Twiddles t = view(base, base);
+        t.PW = nullptr;
+        return t;
+    }
 };
 
 // LDS indices are written as (per-thread base) + (compile-time constant) so that every ds_read / ds_write
@@ -480,7 +495,7 @@ MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
 #endif
     if (POWERS) {  // one table read per thread, the other P-2 twiddles as its powers (product tree <= log2 P deep)
         cf w[P];
-        w[1] = row[1];
+        w[1] = tw.PW ? tw.PW[k] : row[1];
 #pragma unroll
         for (int r = 2; r < P; r++) w[r] = cmul(w[r / 2], w[r - r / 2]);
 #pragma unroll
