@@ -387,7 +387,10 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
             MW_VT(h) {
                 p2_fetch<N, P, R2, 2>(A, ab, step, MW_VTID(h), f, x[h]);
                 p2_stage0<N, P, R2>(MW_VTID(h), x[h], set0);
-                mw_sched_fence();
+#ifndef MW_SLOPE_STAGE_FENCE
+#define MW_SLOPE_STAGE_FENCE 1
+#endif
+                if (MW_SLOPE_STAGE_FENCE) mw_sched_fence();
             }
         } else {
 #pragma unroll
