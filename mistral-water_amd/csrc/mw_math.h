@@ -304,14 +304,17 @@ constexpr int mw_ipow(int P, int s) { int m = 1; for (int i = 0; i < s; i++) m *
 //    Every read is then one conflict-free ds_read_b64 (256 B/clk); the build switches off the pairing of DS operations
 //    (-target-feature -load-store-opt) because a paired read of the transposed layout is 2-way conflicted.
 #ifndef MW_LDS_LAYOUT
-#define MW_LDS_LAYOUT 1
+#define MW_LDS_LAYOUT 2
 #endif
+//  * exact, P = 8 (T a multiple of 64): exchange 0 is the 8 x T transpose n -> (n % 8)(T + 4) + n / 8 (reads: lane u at
+//    4 (u % 8) + u / 8 + const); exchange 1 (pass 1 writes n = 64 (u/8) + 8 r + u % 8: two 8-entry runs 64 apart per 16-lane
+//    group) pads 8 entries per 64, n -> n + 8 (n / 64); later exchanges are the identity.
 template <int N, int P>
 struct XLay {
     static constexpr int T = N / P;
-    static constexpr bool EXACT = MW_LDS_LAYOUT && P == 16 && (T % 32) == 0;
-    static constexpr int ROW0 = T + 2;
-    static constexpr int LBUF = EXACT ? P * ROW0 : N + N / P;
+    static constexpr bool EXACT = MW_LDS_LAYOUT && ((P == 16 && (T % 32) == 0) || (P == 8 && (T % 64) == 0 && MW_LDS_LAYOUT >= 2));
+    static constexpr int ROW0 = T + (P == 16 ? 2 : 4);
+    static constexpr int LBUF = !EXACT ? N + N / P : (P == 16 ? P * ROW0 : N + N / 8);
     // entries between the 4 buffers of a workgroup whose lanes interleave them (lane l -> buffer l % 4), LBUF = 0 mod 32:
     // a read of 8 consecutive n from each of 4 buffers wants stride 8 mod 32 (pass 1's final read), a store of 4 consecutive
     // n to each of 4 buffers stride 4 mod 16 (pass 2's stage 0)
@@ -444,6 +447,10 @@ MW_HD void load_slots(cf (&x)[P], int u, const cf* buf, int e) {
             const cf* __restrict__ b = buf + (u & (P - 1)) * XLay<N, P>::ROW0 + (u >> LogP<P>::v);
 #pragma unroll
             for (int q = 0; q < P; q++) x[q] = b[(T / P) * q];
+        } else if (P == 8 && e == 1) {  // n + 8 (n / 64), n = u + T q, T a multiple of 64
+            const cf* __restrict__ b = buf + u + 8 * (u >> 6);
+#pragma unroll
+            for (int q = 0; q < P; q++) x[q] = b[(T + T / 8) * q];
         } else {
             const cf* __restrict__ b = buf + u;
 #pragma unroll
@@ -511,7 +518,7 @@ MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
     return;
 #endif
     if (XLay<N, P>::EXACT) {
-        cf* __restrict__ b = buf + j;
+        cf* __restrict__ b = buf + j + ((P == 8 && s == 1) ? 8 * (j >> 6) : 0);  // P = 8, s = 1: j + 8 r stays inside its 64-block
 #pragma unroll
         for (int r = 0; r < P; r++) b[p * r] = x[r];
         return;

@@ -72,6 +72,31 @@ def test_pipeline_vs_oracle_f64(emul, oracle, N, pts):
         workloads.assert_parity(v[k], n[k], w[k], vf, nf, cf, rest, np.abs(hds).max(), tag=f"N={N} t={t}")
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_lds_exchange_layouts(oracle, layout):
+    """MW_LDS_LAYOUT: 0 = one padded layout for every exchange, 1 = bank-exact layouts for the radix-16 plans only,
+    2 (default) = also for radix 8 (the OceanRenderer passes and 512^2).  Same transforms, same pipeline results as the default build
+    (bit for bit: the layouts only move data), 1-D at every size and the full pipeline at 512^2."""
+    import emul_build
+    e, e1 = emul_build.Emul(defs=(f"MW_LDS_LAYOUT={layout}",)), emul_build.load()
+    rng = np.random.default_rng(layout)
+    for N in (64, 256, 512, 1024, 2048, 4096):
+        x = rng.standard_normal((N, 2)).astype(np.float32)
+        for pts in (8, 16):
+            assert (e.fft1d(x, pts=pts) == e1.fft1d(x, pts=pts)).all(), (N, pts)
+    p = workloads.fftmesh_params(512)
+    h0, h0c = oracle.generate_spectrum(p, 2)
+    for pts in (8, 16):
+        a, b = e.evaluate(p, h0, h0c, [3.25], pts=pts), e1.evaluate(p, h0, h0c, [3.25], pts=pts)
+        assert all((u == v).all() for u, v in zip(a, b)), pts
+    from oracle.oracle import RendererParams
+    rp = RendererParams(resolution=64, length=434.48 / 2, wind_x=14.45, wind_y=12.0, amplitude=0.41)   # M = 512 texels
+    ia, pa = e.or_init(rp, 4)
+    ib, pb = e1.or_init(rp, 4)
+    ra, rb = e.or_step(rp, ia, pa.copy(), 0.02), e1.or_step(rp, ib, pb.copy(), 0.02)
+    assert rp.M == 512 and all((u == v).all() for u, v in zip(ra, rb))
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_slope_field_storage_modes(oracle, mode):
     """MW_SPLIT_SLOPES: the slope field crosses the exchange buffer whole (0), as the kx part G for j <= N/2 with
