@@ -163,6 +163,7 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
 
 // F/OceanNormal.shader + F/WhiteCap.shader in one launch: WhiteCap reads _Bump at its own texel only (:38), so the thread
 // that produced the normal goes straight on to the whitecap (its own global write is visible to itself).
+template <bool NT>
 __global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float* height, const cf* disp, const float* disp_g,
                                                          float* normal, float* white) {
     // XCD-aware: block b runs on XCD b % 8; give each XCD one contiguous band of texel rows, so that the +-1 and +-8 row
@@ -176,8 +177,8 @@ __global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float
         height += toff; disp += toff; disp_g += toff; normal += 3 * toff; white += toff;
     }
     float nxz[2];
-    or_normal_element(c, idx % c.M, idx / c.M, height, disp, disp_g, normal, nxz);
-    or_white_element(c, idx % c.M, idx / c.M, disp, normal, white, nxz);
+    or_normal_element<NT>(c, idx % c.M, idx / c.M, height, disp, disp_g, normal, nxz);
+    or_white_element<NT>(c, idx % c.M, idx / c.M, disp, normal, white, nxz);
 }
 
 __global__ void k_or_pack_rgba(int M, const float* height, const float* height_g, const cf* disp, const float* disp_g,
@@ -300,7 +301,10 @@ static inline mw_status or_generate(OrState& s, float delta_time, float* d_heigh
     if (e != hipSuccess) { g_or_err = std::string("OceanRenderer pass launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
     const size_t MM = (size_t)s.M * s.M, TM = MM * (size_t)s.tiles;
     const unsigned nb = (unsigned)((MM + 255) / 256);
-    k_or_normal_white<<<dim3(nb, s.tiles), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white);
+    if (s.tiles >= MW_OR_STREAM_E_TILES)
+        k_or_normal_white<true><<<dim3(nb, s.tiles), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white);
+    else
+        k_or_normal_white<false><<<dim3(nb, s.tiles), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white);
     if (hipGetLastError() != hipSuccess) { g_or_err = "OceanRenderer normal/white launch failed"; return MW_EDEVICE; }
     s.have_frame = true;
     s.have_imag = s.want_imag;

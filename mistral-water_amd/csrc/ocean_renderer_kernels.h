@@ -206,11 +206,13 @@ MW_HD void or_p2_finish(const OrP2Args& A, const Twiddles& tw, int ab, int tid, 
 
 // F/OceanNormal.shader:39-56 and F/WhiteCap.shader:33-45 for one texel; clamp addressing
 MW_HD int or_clamp(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
-#ifndef MW_OR_NT_STORES
-#define MW_OR_NT_STORES 0  // non-temporal normal/whitecap stores: -2 % frame time, but the textures are consumed right
-                           // away (renderer, mw_ocean_displace_mesh, RGBA packing) and should stay cache-resident: off
-#endif
+// NT: non-temporal normal/whitecap stores.  A single ocean's textures are consumed right away (renderer,
+// mw_ocean_displace_mesh, RGBA packing) and should stay cache-resident: plain stores (NT would be -2 % frame time).  A batched
+// handle's textures together exceed the caches anyway: streamed out from MW_OR_STREAM_E_TILES tiles (4 tiles: 0.59 -> 0.61
+// of the 120-B figure, 8 tiles: 0.54 -> 0.60).  The height / displacement textures stay plain stores in every case: the
+// normal kernel reads them back at once (non-temporal: 103 -> 117 us per 4 frames).
 // normal_xz (optional): the normal's x and z as stored, for the whitecap of the same texel (F/WhiteCap.shader:38)
+template <bool NT = false>
 MW_HD void or_normal_element(const OrConsts& c, int px, int py, const float* height, const cf* disp, const float* disp_g,
                              float* normal, float* normal_xz = nullptr) {
     const int M = c.M;
@@ -229,12 +231,13 @@ MW_HD void or_normal_element(const OrConsts& c, int px, int py, const float* hei
     float nz = (r0 * t1 - r1 * t0) + (t0 * l1 - t1 * l0) + (l0 * b1 - l1 * b0) + (b0 * r1 - b1 * r0);
     const float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
     const float ox = nx * inv, oy = ny * inv, oz = nz * inv;  // :55
-    mw_store_stream<MW_OR_NT_STORES != 0>(&normal[3 * idx], ox);
-    mw_store_stream<MW_OR_NT_STORES != 0>(&normal[3 * idx + 1], oy);
-    mw_store_stream<MW_OR_NT_STORES != 0>(&normal[3 * idx + 2], oz);
+    mw_store_stream<NT>(&normal[3 * idx], ox);
+    mw_store_stream<NT>(&normal[3 * idx + 1], oy);
+    mw_store_stream<NT>(&normal[3 * idx + 2], oz);
     if (normal_xz) { normal_xz[0] = ox; normal_xz[1] = oz; }
 }
 // normal_xz: (n.x, n.z) of this texel when the caller has just computed it, else read from `normal`
+template <bool NT = false>
 MW_HD void or_white_element(const OrConsts& c, int px, int py, const cf* disp, const float* normal, float* white,
                             const float* normal_xz = nullptr) {
     const int M = c.M;
@@ -249,7 +252,7 @@ MW_HD void or_white_element(const OrConsts& c, int px, int py, const cf* disp, c
     const float jac = (1.f + dDdx_x) * (1.f + dDdy_y) - dDdx_y * dDdy_x;                     // :39
     const float turb = fmaxf(0.f, 1.f - jac + sqrtf(n0 * n0 + n1 * n1));                    // :40
     const float t = turb > 1.f ? 1.f : turb;
-    mw_store_stream<MW_OR_NT_STORES != 0>(&white[idx], t * t * (3.f - 2.f * t));             // smoothstep(0,1,turb), :43
+    mw_store_stream<NT>(&white[idx], t * t * (3.f - 2.f * t));             // smoothstep(0,1,turb), :43
 }
 
 
