@@ -222,6 +222,31 @@ def test_single_bins_and_nyquist_lines(mw, oracle):
             workloads.assert_parity(v, n, c, vf, nf, cf, rest, tag=str((i, j, conj)))
 
 
+@pytest.mark.parametrize("N", [512, 1024, 2048, 4096])
+def test_nyquist_lines_only_large_plans(mw, oracle, N):
+    """Only the two self-mirrored lines of the spectrum (row i = 0, column j = 0) and a few single bins are non-zero: the outputs
+    then consist of nothing but the terms a random Phillips spectrum makes negligible -- the i = 0 correction, the Nyquist-column
+    job and its C terms added in pass 2 (deferred to the point of use where the rows are prefetched, 4096^2), and the rebuilt
+    halves of the half-stored height and slope rows (mode 2 at 1024^2 / 2048^2, mode 1 at 4096^2).  One plan per size."""
+    p = workloads.fftmesh_params(N, choppiness=1.0)
+    rng = np.random.default_rng(N)
+    h0 = np.zeros((N, N, 2), np.float32)
+    h0c = np.zeros((N, N, 2), np.float32)
+    sc = 0.05 / N
+    for a in (h0, h0c):
+        a[0, :] = rng.standard_normal((N, 2)) * sc
+        a[:, 0] = rng.standard_normal((N, 2)) * sc
+        for (i, j) in ((N // 2, N // 2), (N // 2 + 1, N // 2 - 2), (1, N - 1), (N - 1, 1), (N // 2, 3), (5, N // 2)):
+            a[i, j] = rng.standard_normal(2) * sc * 8
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        v, n, c = o.evaluate(1.75)
+    vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, 1.75, return_hds=True)
+    assert np.abs(vf - rest).max() > 1e-3      # the lines do produce a sea
+    workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"nyquist lines N={N}")
+
+
 def test_zero_spectrum_flat_and_white_zero(mw, oracle):
     p = workloads.fftmesh_params(128)
     z = np.zeros((128, 128, 2), np.float32)
