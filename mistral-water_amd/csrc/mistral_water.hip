@@ -308,6 +308,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = FftGeom<N, P>::T, NT = G::NTHREADS / VT;  // NT lanes, each running VT virtual threads
     static_assert(G::NTHREADS % VT == 0 && NT % T == 0, "a lane's virtual threads must belong to distinct whole row groups");
+    static_assert(T % 64 == 0, "row groups must be whole waves: the row group of a lane is treated as wave-uniform (512^2 at 16 points fails parity)");
     const int tid0 = threadIdx.x, step = blockIdx.y;
 #ifdef MW_HS_NO_XCD_MAP
     const int ab = blockIdx.x;
