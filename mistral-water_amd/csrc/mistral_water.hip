@@ -325,7 +325,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
 #define MW_HS_HALO_EARLY 1
 #endif
 #ifndef MW_HS_HALO_EARLY_2048
-#define MW_HS_HALO_EARLY_2048 0  // with the split slope field the 2048^2 kernel has no room for the 32 VGPRs (44 spilled dwords: -12 %)
+#define MW_HS_HALO_EARLY_2048 1  // fits (251 VGPRs) since the radix-8 final pass forms its twiddles by powers (MW_TF_POWERS_MIN_RL)
 #endif
 #ifndef MW_HS_HALO_EARLY_4096
 #define MW_HS_HALO_EARLY_4096 0  // 4096^2 prefetches the displacement rows during the height field instead (PF = 1): the two together spill

@@ -532,8 +532,19 @@ MW_HD void final_stage(cf (&x)[P], int u, const cf* __restrict__ TF) {
     constexpr int RL = FftGeom<N, P>::RL, NB = FftGeom<N, P>::NB;
     if (RL == 1) return;
     cf tw[RL];
+#ifndef MW_TF_POWERS_MIN_RL
+#define MW_TF_POWERS_MIN_RL 8  // a radix-8 final pass (N = 2048, 128 at 16 points) loads ONE twiddle, w = e^{SGN 2 pi i u/N}, and
+                               // forms w^2..w^7 by products: 7 loads and 12 VGPRs less -- what lets the 2048^2 pass 2 keep
+                               // the early halo fetch (pass 2 -5.5 %, pass 1 -4 %)
+#endif
+    if (RL >= MW_TF_POWERS_MIN_RL) {
+        tw[1] = TF[FftGeom<N, P>::T + u];
 #pragma unroll
-    for (int r = 1; r < RL; r++) tw[r] = TF[r * FftGeom<N, P>::T + u];
+        for (int r = 2; r < RL; r++) tw[r] = cmul(tw[r / 2], tw[r - r / 2]);
+    } else {
+#pragma unroll
+        for (int r = 1; r < RL; r++) tw[r] = TF[r * FftGeom<N, P>::T + u];
+    }
 #pragma unroll
     for (int m = 0; m < NB; m++) {
 #pragma unroll
