@@ -103,21 +103,41 @@ __global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict_
                                                         float frequency, float steepness) {
     const int64_t nquads = nvec >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquads; qd += stride) {
-        const f4* p = reinterpret_cast<const f4*>(pos) + qd * 3;
+    // A lane owns 4 vertices = 48 contiguous bytes.  Stored straight from the lane, every store instruction writes 16-byte
+    // pieces 48 bytes apart (a third of each line; the L2 has to merge three instructions, and a non-temporal hint on that
+    // pattern is 2.5x slower).  Each wave therefore turns its 64 x 48 B = 3 KiB of results through LDS (wave-local, no
+    // workgroup barrier) so that a store instruction writes 64 consecutive float4 = 1 KiB, and the write-once stream of
+    // nsteps x nverts x 12 B goes out non-temporally.
+#ifndef MW_GERSTNER_NT
+#define MW_GERSTNER_NT 1
+#endif
+    __shared__ f4 tile[256 * 3];
+    const int lane = threadIdx.x & 63;
+    f4* wt = tile + (threadIdx.x - lane) * 3;  // this wave's 192 float4
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); q0 < nquads; q0 += stride) {  // wave-uniform
+        const int64_t qd = q0 + lane;
+        const f4* p = reinterpret_cast<const f4*>(pos) + (qd < nquads ? qd : q0) * 3;  // (idle lanes of the last wave recompute its first quad)
         f4 a = p[0], b = p[1], c = p[2];
         const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
         float sa[4][NW], ca[4][NW];
 #pragma unroll
         for (int k = 0; k < 4; k++) gerstner_position_part<NW>(wv, frequency, v[3 * k], v[3 * k + 2], sa[k], ca[k]);
+        const int nf4 = (int)(nquads - q0 < 64 ? nquads - q0 : 64) * 3;  // valid float4 of this wave's chunk
         for (int step = 0; step < nsteps; step++) {
             float o[12];
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 gerstner_step_vertex<NW>(wv, ph, step, amplitude, steepness, sa[k], ca[k], v[3 * k], v[3 * k + 1], v[3 * k + 2], &o[3 * k]);
-            f4* po = reinterpret_cast<f4*>(out + (size_t)step * nverts * 3) + qd * 3;
             f4 r0 = {o[0], o[1], o[2], o[3]}, r1 = {o[4], o[5], o[6], o[7]}, r2 = {o[8], o[9], o[10], o[11]};
-            po[0] = r0; po[1] = r1; po[2] = r2;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous step's reads of the tile are done
+            __builtin_amdgcn_wave_barrier();
+            wt[lane * 3] = r0; wt[lane * 3 + 1] = r1; wt[lane * 3 + 2] = r2;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            f4* po = reinterpret_cast<f4*>(out + (size_t)step * nverts * 3) + q0 * 3;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (j * 64 + lane < nf4) mw_store_stream<MW_GERSTNER_NT != 0>(&po[j * 64 + lane], wt[j * 64 + lane]);
         }
     }
     for (int64_t vtx = nvec + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vtx < nverts; vtx += stride) {  // see k_gerstner
