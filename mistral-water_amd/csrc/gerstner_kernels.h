@@ -38,22 +38,43 @@ static inline bool mw_aligned16(const void* p) { return (reinterpret_cast<uintpt
 
 // 4 vertices (= 3 x float4) per thread: every load/store is a 16-B access, lanes contiguous.  Vertices [0, nvec) take that
 // path (nvec a multiple of 4; 0 when the buffers are not 16-B aligned), [nvec, nverts) a scalar grid-stride loop.
+// A lane of the vector paths owns 4 vertices = 3 float4 = 48 contiguous bytes.  Stored straight from the lane, each of the three
+// store instructions writes 16-byte pieces 48 bytes apart: a third of every line per instruction, left to the L2 to merge (and
+// with a non-temporal hint 2.5x slower).  wave_store_3f4 turns a wave's 64 x 48 B through LDS (wave-local: LDS operations of one
+// wave execute in order, no workgroup barrier; ds_write_b128 at 48-byte lane stride is conflict-free) so that every store
+// instruction writes 64 consecutive float4 = 1 KiB.  wt: the wave's 192-float4 tile; dst: the chunk's first float4; nf4: its
+// valid float4 (192 except in the last wave).
+template <bool NT>
+__device__ __forceinline__ void wave_store_3f4(f4* wt, int lane, f4 r0, f4 r1, f4 r2, f4* dst, int nf4) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier reads of the tile are done
+    __builtin_amdgcn_wave_barrier();
+    wt[lane * 3] = r0; wt[lane * 3 + 1] = r1; wt[lane * 3 + 2] = r2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        if (j * 64 + lane < nf4) mw_store_stream<NT>(&dst[j * 64 + lane], wt[j * 64 + lane]);
+}
+
 __global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts, int64_t nvec,
                                                   GerstnerWaves wv, int nwaves, float amplitude, float frequency,
                                                   float steepness, float t) {
     const int64_t nquads = nvec >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquads; qd += stride) {
-        const f4* p = reinterpret_cast<const f4*>(pos) + qd * 3;
+    __shared__ f4 tile[256 * 3];
+    const int lane = threadIdx.x & 63;
+    f4* wt = tile + (threadIdx.x - lane) * 3;
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); q0 < nquads; q0 += stride) {  // wave-uniform
+        const int64_t qd = q0 + lane;
+        const f4* p = reinterpret_cast<const f4*>(pos) + (qd < nquads ? qd : q0) * 3;  // (idle lanes of the last wave redo its first quad)
         f4 a = p[0], b = p[1], c = p[2];
         float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
 #pragma unroll
         for (int k = 0; k < 4; k++)
             gerstner_vertex(wv, nwaves, amplitude, frequency, steepness, t, v[3 * k], v[3 * k + 1], v[3 * k + 2], &v[3 * k],
                             &v[3 * k + 1], &v[3 * k + 2]);
-        f4* o = reinterpret_cast<f4*>(out) + qd * 3;
         f4 r0 = {v[0], v[1], v[2], v[3]}, r1 = {v[4], v[5], v[6], v[7]}, r2 = {v[8], v[9], v[10], v[11]};
-        o[0] = r0; o[1] = r1; o[2] = r2;
+        wave_store_3f4<false>(wt, lane, r0, r1, r2, reinterpret_cast<f4*>(out) + q0 * 3, (int)(nquads - q0 < 64 ? nquads - q0 : 64) * 3);
     }
     // the rest (nverts % 4, or everything when the buffers are not 16-B aligned): one vertex per thread and trip
     for (int64_t vtx = nvec + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vtx < nverts; vtx += stride) {
@@ -103,11 +124,7 @@ __global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict_
                                                         float frequency, float steepness) {
     const int64_t nquads = nvec >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // A lane owns 4 vertices = 48 contiguous bytes.  Stored straight from the lane, every store instruction writes 16-byte
-    // pieces 48 bytes apart (a third of each line; the L2 has to merge three instructions, and a non-temporal hint on that
-    // pattern is 2.5x slower).  Each wave therefore turns its 64 x 48 B = 3 KiB of results through LDS (wave-local, no
-    // workgroup barrier) so that a store instruction writes 64 consecutive float4 = 1 KiB, and the write-once stream of
-    // nsteps x nverts x 12 B goes out non-temporally.
+    // stores through wave_store_3f4; the write-once stream of nsteps x nverts x 12 B goes out non-temporally
 #ifndef MW_GERSTNER_NT
 #define MW_GERSTNER_NT 1
 #endif
@@ -129,15 +146,7 @@ __global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict_
             for (int k = 0; k < 4; k++)
                 gerstner_step_vertex<NW>(wv, ph, step, amplitude, steepness, sa[k], ca[k], v[3 * k], v[3 * k + 1], v[3 * k + 2], &o[3 * k]);
             f4 r0 = {o[0], o[1], o[2], o[3]}, r1 = {o[4], o[5], o[6], o[7]}, r2 = {o[8], o[9], o[10], o[11]};
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous step's reads of the tile are done
-            __builtin_amdgcn_wave_barrier();
-            wt[lane * 3] = r0; wt[lane * 3 + 1] = r1; wt[lane * 3 + 2] = r2;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            f4* po = reinterpret_cast<f4*>(out + (size_t)step * nverts * 3) + q0 * 3;
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-                if (j * 64 + lane < nf4) mw_store_stream<MW_GERSTNER_NT != 0>(&po[j * 64 + lane], wt[j * 64 + lane]);
+            wave_store_3f4<MW_GERSTNER_NT != 0>(wt, lane, r0, r1, r2, reinterpret_cast<f4*>(out + (size_t)step * nverts * 3) + q0 * 3, nf4);
         }
     }
     for (int64_t vtx = nvec + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vtx < nverts; vtx += stride) {  // see k_gerstner

@@ -102,20 +102,23 @@ __global__ __launch_bounds__(256) void k_pond(const float* __restrict__ pos, flo
                                               int64_t nverts, int64_t nvec, PondParams P, float t) {
     const int64_t nquads = nvec >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquads; qd += stride) {
-        const f4* p = reinterpret_cast<const f4*>(pos) + qd * 3;
+    __shared__ f4 tile[256 * 3];
+    const int lane = threadIdx.x & 63;
+    f4* wt = tile + (threadIdx.x - lane) * 3;
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); q0 < nquads; q0 += stride) {  // wave-uniform
+        const int64_t qd = q0 + lane;
+        const f4* p = reinterpret_cast<const f4*>(pos) + (qd < nquads ? qd : q0) * 3;  // (idle lanes of the last wave redo its first quad)
         f4 a = p[0], b = p[1], c = p[2];
         float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
         float o[12], n[12];
 #pragma unroll
         for (int k = 0; k < 4; k++) pond_vertex(P, t, v[3 * k], v[3 * k + 1], v[3 * k + 2], &o[3 * k], &n[3 * k]);
-        f4* po = reinterpret_cast<f4*>(out) + qd * 3;
+        const int nf4 = (int)(nquads - q0 < 64 ? nquads - q0 : 64) * 3;
         f4 r0 = {o[0], o[1], o[2], o[3]}, r1 = {o[4], o[5], o[6], o[7]}, r2 = {o[8], o[9], o[10], o[11]};
-        po[0] = r0; po[1] = r1; po[2] = r2;
+        wave_store_3f4<false>(wt, lane, r0, r1, r2, reinterpret_cast<f4*>(out) + q0 * 3, nf4);  // gerstner_kernels.h
         if (NORMALS) {
-            f4* pn = reinterpret_cast<f4*>(nrm) + qd * 3;
             f4 m0 = {n[0], n[1], n[2], n[3]}, m1 = {n[4], n[5], n[6], n[7]}, m2 = {n[8], n[9], n[10], n[11]};
-            pn[0] = m0; pn[1] = m1; pn[2] = m2;
+            wave_store_3f4<false>(wt, lane, m0, m1, m2, reinterpret_cast<f4*>(nrm) + q0 * 3, nf4);
         }
     }
     for (int64_t vtx = nvec + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vtx < nverts; vtx += stride) {
