@@ -504,9 +504,10 @@ MW_HD void p2_load_map(int tid, int* r1, int* u1) {
 
 // global loads of one field's row data (row-interleaved mapping).  Split from the stage-0 pass so that the kernel
 // can issue field k+1's loads before it starts field k's exchanges (software prefetch: twice the bytes in flight).
-// PART (slope field with MW_SPLIT_SLOPES only): 0 = the whole load; 1 = G alone, raw; 2 = the assembly x <- (x + kz T1')' on
-// top of part 1.  The sequential-halo kernel issues part 1 of all its virtual threads, then part 2 + stage 0 one virtual
-// thread at a time: the height rows' 2P registers are then live for one virtual thread only.
+// PART (half-stored slope field only, mw_split_slopes): 0 = the whole load; 1 = the stored half alone, raw (G in mode 1, T3 in
+// mode 2); 2 = the assembly on top of part 1 -- the height-row loads, the kz T1 term and the conjugation of the mirrored
+// slots.  The sequential-halo kernel issues part 1 of all its virtual threads, then part 2 + stage 0 one virtual thread at a
+// time: the height rows' registers are then live for one virtual thread only.
 // nyq != nullptr: the Nyquist-column term is returned there instead of being added to x[0] (a prefetch must not consume any
 // of its loads: the add's s_waitcnt would wait for all of them, vmcnt being in-order); the caller adds it when it uses x.
 template <int N, int P, int R2, int PART = 0>
