@@ -1,4 +1,4 @@
-// MistralWaterNative.cs -- the P/Invoke layer over libmistral_water.so (include/mistral_water.h, MW_ABI_VERSION 2).
+// MistralWaterNative.cs -- the P/Invoke layer over libmistral_water.so (include/mistral_water.h, MW_ABI_VERSION 3).
 //
 // Drop into Assets/Mistral Water/Scripts/ next to the two MonoBehaviours of this folder; the shared object goes to
 // Assets/Plugins/x86_64/libmistral_water.so.  Every extern below mirrors one prototype of the header, argument for
@@ -15,7 +15,7 @@ public static class MistralWaterNative
 {
     const string Lib = "mistral_water";
 
-    public const int AbiVersion = 2;
+    public const int AbiVersion = 3;
     public const int CommIdBytes = 128;
 
     public enum Status { OK = 0, EINVAL = 1, ENOTPOW2 = 2, ENOTCOMMENSURATE = 3, ENOMEM = 4, EDEVICE = 5, ESTATE = 6 }
@@ -57,6 +57,7 @@ public static class MistralWaterNative
 
     // ---- library ------------------------------------------------------------------------------------------------
     [DllImport(Lib)] public static extern int mw_abi_version();
+    [DllImport(Lib)] public static extern IntPtr mw_build_id();
     [DllImport(Lib)] public static extern IntPtr mw_last_error();
     [DllImport(Lib)] public static extern int mw_device_count();
     [DllImport(Lib)] public static extern void mw_params_default(ref Params p, int semantics);
@@ -79,6 +80,8 @@ public static class MistralWaterNative
     [DllImport(Lib)] public static extern Status mw_ocean_get_phase(IntPtr ocean, [Out] float[] phase);
     [DllImport(Lib)] public static extern Status mw_ocean_set_phase(IntPtr ocean, float[] phase);
     [DllImport(Lib)] public static extern Status mw_ocean_set_timer(IntPtr ocean, float timer);
+    [DllImport(Lib)] public static extern float mw_ocean_normal_length(IntPtr ocean);
+    [DllImport(Lib)] public static extern Status mw_ocean_set_normal_length(IntPtr ocean, float normalLength);
     [DllImport(Lib)] public static extern float mw_ocean_timer(IntPtr ocean);
     [DllImport(Lib)] public static extern Status mw_ocean_reset_timer(IntPtr ocean);
 
@@ -115,18 +118,11 @@ public static class MistralWaterNative
     [DllImport(Lib)] public static extern IntPtr mw_tiles_ocean(IntPtr tiles, int localK);
     [DllImport(Lib)] public static extern Status mw_tiles_evaluate(IntPtr tiles, float[] times, int nsteps, uint flags);
     [DllImport(Lib)] public static extern Status mw_tiles_outputs(IntPtr tiles, int localK, out IntPtr dVertices, out IntPtr dNormals, out IntPtr dWhite);
+    [DllImport(Lib)] public static extern Status mw_tiles_generate_texture(IntPtr tiles, float deltaTime);
+    [DllImport(Lib)] public static extern Status mw_tiles_textures(IntPtr tiles, int localK, out IntPtr dHeight, out IntPtr dDispXZ, out IntPtr dNormal, out IntPtr dWhite);
     [DllImport(Lib)] public static extern Status mw_tiles_gather(IntPtr tiles, int step, int root);
     [DllImport(Lib)] public static extern Status mw_tiles_gathered(IntPtr tiles, out IntPtr dGathered, out long floatsPerTile);
     [DllImport(Lib)] public static extern Status mw_tiles_synchronize(IntPtr tiles);
-
-    // ---- measurement and test hooks -----------------------------------------------------------------------------
-    [DllImport(Lib)] public static extern Status mw_ocean_profile_kernels(IntPtr ocean, int nsteps, int iters, [Out] float[] msOut, [Out] IntPtr[] namesOut, out int nkernels);
-    [DllImport(Lib)] public static extern Status mw_debug_omega_t(IntPtr ocean, float t, [Out] float[] outHost);
-    [DllImport(Lib)] public static extern Status mw_debug_evaluate_hds(IntPtr ocean, float t, [Out] Vector3[] vertices, [Out] Vector3[] normals, [Out] Color[] colors, [Out] Vector2[] hds);
-    [DllImport(Lib)] public static extern Status mw_debug_get_omega(IntPtr ocean, [Out] float[] outHost);
-    [DllImport(Lib)] public static extern Status mw_debug_sincos(float[] x, int n, [Out] float[] s, [Out] float[] c);
-    [DllImport(Lib)] public static extern Status mw_debug_sincos_fast(float[] x, int n, [Out] float[] s, [Out] float[] c);
-    [DllImport(Lib)] public static extern Status mw_debug_stream_read(long bytes, int width, int iters);
 
     // ---- pond ---------------------------------------------------------------------------------------------------
     [DllImport(Lib)] public static extern Status mw_gerstner_displace(Vector3[] pos, long nverts, Vector3[] waves, int nwaves, float amplitude, float frequency, float steepness, float t, [Out] Vector3[] outPos, int device);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MW_ABI_VERSION 2
+#define MW_ABI_VERSION 3
 
 typedef struct mw_ocean mw_ocean; /* opaque; one per FFTMesh / OceanRenderer instance */
 
@@ -68,6 +68,10 @@ typedef struct {
 #define MW_OUT_COLOR_RGBA 1u   /* whitecap replicated into a Unity Color (S/FFTMesh.cs:274), 16 B per vertex */
 
 int32_t mw_abi_version(void);
+/* Identity of this build of the library: "<16 hex digits of a hash over the kernel sources and compile flags> <flags tag>".
+ * bench.py prints it and the committed rocprofv3 PMC summaries carry it, so a counter file is only ever quoted next to
+ * numbers of the build it was measured on.                                                                          */
+const char* mw_build_id(void);
 const char* mw_last_error(void);
 int32_t mw_device_count(void);
 void mw_params_default(mw_params* p, int32_t semantics); /* Inspector defaults of the two MonoBehaviours */
@@ -125,6 +129,13 @@ mw_status mw_ocean_reinit_spectrum(mw_ocean* o, float length, float wind_x, floa
 mw_status mw_ocean_get_phase(mw_ocean* o, float* phase);
 mw_status mw_ocean_set_phase(mw_ocean* o, const float* phase);
 mw_status mw_ocean_set_timer(mw_ocean* o, float timer);
+/* OceanRenderer: the length the normal pass divides by.  The reference sets normalMat._Length once in SetParams
+ * (S/OceanRenderer.cs:163) and never again, so after mw_ocean_reinit_spectrum with a new length it differs from the
+ * handle's length.  It is the third piece of an OceanRenderer checkpoint (with initialTexture and the phase): a fresh
+ * handle created with the current length must be given the saved value.  FFTMesh handles return their length and
+ * refuse the setter with MW_ESTATE.                                                                              */
+float mw_ocean_normal_length(const mw_ocean* o);
+mw_status mw_ocean_set_normal_length(mw_ocean* o, float normal_length);
 
 /* GenerateMesh outputs (S/FFTMesh.cs:101-139, S/OceanRenderer.cs:172-207): rest vertices [N*N*3],
  * normals [N*N*3], uvs [N*N*2], triangle indices [(N-1)^2*6].  Any pointer may be NULL.            */
@@ -190,9 +201,11 @@ mw_status mw_ocean_displace_mesh(mw_ocean* o, float* vertices_xyz, float* normal
 mw_status mw_ocean_displace_mesh_device(mw_ocean* o, void* d_vertices_xyz, void* d_normals_xyz, void* d_colors);
 
 /* ---- independent tiles on several devices (BASELINE configs[2]) ------------------------------------
- * FFTMesh-semantics tiles are independent units: tile k is the ocean of `params` with seed params->seed + k on its own
- * device, compute stream and output buffers; there is no data-path collective.  The only exchange is the optional gather
- * of finished outputs to one root device over RCCL (xGMI), issued on per-device SIDE streams behind an event recorded on
+ * Tiles are independent units in both semantics: tile k is the ocean of `params` with seed params->seed + k on its own
+ * device, compute stream and output buffers; there is no data-path collective.  FFTMesh tiles advance up to max_steps
+ * independent time-steps per mw_tiles_evaluate; OceanRenderer tiles (max_steps must be 1: the phase recurrence,
+ * F/FFTCommon.cginc:101-104, serialises time -- only the tile axis shards) one frame per mw_tiles_generate_texture.
+ * The only exchange is the optional gather of finished outputs to one root device over RCCL (xGMI), issued on per-device SIDE streams behind an event recorded on
  * the compute streams -- once per batch, never per step (29.4 MB per 1024^2 tile ~ 190 us on one 153 GB/s link).
  *   single process : mw_tiles_create -- one RCCL rank per distinct device (ncclCommInitAll, rccl.h:236); tiles that share
  *                    a device share its rank.  devices == NULL places tile k on device k % mw_device_count().
@@ -214,32 +227,17 @@ mw_ocean* mw_tiles_ocean(mw_tiles* t, int32_t local_k); /* borrowed handle of a 
 mw_status mw_tiles_evaluate(mw_tiles* t, const float* times, int32_t nsteps, uint32_t flags);
 /* device pointers of local tile k's outputs: [max_steps][N*N*3], [max_steps][N*N*3], [max_steps][N*N*(1|4)] */
 mw_status mw_tiles_outputs(mw_tiles* t, int32_t local_k, void** d_vertices, void** d_normals, void** d_white);
-/* Collect step `step` of EVERY tile on the device of tile `root` (global tile index): asynchronous, on the side streams.
- * mw_tiles_gathered: the root's buffer [ntiles][N*N*3 | N*N*3 | N*N*w] floats (NULL on processes that do not own root). */
+/* OceanRenderer tiles: one GenerateTexture() (S/OceanRenderer.cs:216) on every local tile, asynchronous; the result textures
+ * of local tile k stay in its handle: height [M*M], disp_xz [M*M*2], normal_xyz [M*M*3], white [M*M].                  */
+mw_status mw_tiles_generate_texture(mw_tiles* t, float delta_time);
+mw_status mw_tiles_textures(mw_tiles* t, int32_t local_k, void** d_height, void** d_disp_xz, void** d_normal_xyz, void** d_white);
+/* Collect step `step` of EVERY tile (OceanRenderer: the latest frame, step = 0) on the device of tile `root` (global tile
+ * index): asynchronous, on the side streams.  mw_tiles_gathered: the root's buffer, per tile [N*N*3 | N*N*3 | N*N*w] floats
+ * (OceanRenderer: [M*M | M*M*2 | M*M*3 | M*M]); NULL on processes that do not own root.  All multi-device entry points put
+ * the caller's current HIP device back before they return.                                                           */
 mw_status mw_tiles_gather(mw_tiles* t, int32_t step, int32_t root);
 mw_status mw_tiles_gathered(mw_tiles* t, void** d_gathered, int64_t* floats_per_tile);
 mw_status mw_tiles_synchronize(mw_tiles* t); /* compute and side streams of every local tile */
-
-/* ---- measurement hook (bench.py): times each kernel of one FFTMesh step with hipEvents on the
- * handle's stream.  ms_out[k] = mean duration of kernel k over iters launches of `nsteps` batched
- * time-steps; names_out[k] = static kernel name.  Returns the kernel count through *nkernels.      */
-mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, const char** names_out,
-                                   int32_t* nkernels);
-
-/* ---- test hooks (used by tests/ only; not needed by a host integration) ---------------------------------
- * mw_debug_omega_t: omega(i,j)*t [N*N, idx = i*N + j] exactly as the kernels form it -- the quantised dispersion
- * (S/FFTMesh.cs:146,183) is compared bit for bit with the oracle.  mw_debug_get_omega: the stored table in its
- * transposed [j][i] layout.  mw_debug_sincos: the library's range-reduced sin/cos on n host floats.            */
-mw_status mw_debug_omega_t(mw_ocean* o, float t, float* out_host);
-/* one EvaluateWaves(t) that also returns hds [N*N*2] = (d.x, d.z) of S/FFTMesh.cs:247 as the kernels hold it: the whitecap
- * stage (forward differences, edge rules :258-274, halo rows between workgroups) is then checked bit for bit           */
-mw_status mw_debug_evaluate_hds(mw_ocean* o, float t, float* vertices_xyz, float* normals_xyz, float* colors_rgba, float* hds_xy);
-mw_status mw_debug_get_omega(mw_ocean* o, float* out_host);
-mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host);
-/* the pond kernels' hardware-sine variant (v_sin_f32 / v_cos_f32 after an exact revolution count) */
-mw_status mw_debug_sincos_fast(const float* x_host, int32_t n, float* s_host, float* c_host);
-/* streams `bytes` of device memory through `width`-byte per-lane loads (4, 8 or 16): FETCH_SIZE calibration */
-mw_status mw_debug_stream_read(int64_t bytes, int32_t width, int32_t iters);
 
 /* ---- pond: Gerstner vertex displacement  (W/MistralWaterLib.cginc:71-99,154-180) ---------------
  * pos_xyz/out_xyz [nverts*3] world positions; waves [nwaves*3] = {dir.x, dir.y, speed}; amplitude is

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/mistral_water.h"
+#include "../../include/mistral_water_hooks.h"
 #include "fftmesh_kernels.h"
 #include "direct_kernels.h"
 #include "ocean_renderer_device.h"
@@ -509,6 +510,7 @@ struct mw_ocean {
     DirectState direct;
     // OceanRenderer state
     OrState orr;
+    void graph_invalidate() {}
 };
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -724,6 +726,35 @@ __global__ void k_dbg_stream(const V* __restrict__ src, size_t n, float* sink) {
 extern "C" {
 
 int32_t mw_abi_version(void) { return MW_ABI_VERSION; }
+
+// Identity of this build: FNV-1a 64 of the shared object's own bytes (hipcc is deterministic: same sources and flags ->
+// same file; a comment-only edit keeps the id) + the tag the build gave it (-DMW_BUILD_TAG, "default" for the in-tree .so).
+#ifndef MW_BUILD_TAG
+#define MW_BUILD_TAG "default"
+#endif
+const char* mw_build_id(void) {
+    static std::string id;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        Dl_info info;
+        unsigned long long h = 1469598103934665603ull;
+        bool ok = false;
+        if (dladdr(reinterpret_cast<const void*>(&mw_abi_version), &info) && info.dli_fname) {
+            if (FILE* f = std::fopen(info.dli_fname, "rb")) {
+                std::vector<unsigned char> buf(1 << 20);
+                size_t n;
+                while ((n = std::fread(buf.data(), 1, buf.size(), f)) > 0)
+                    for (size_t i = 0; i < n; i++) { h ^= buf[i]; h *= 1099511628211ull; }
+                std::fclose(f);
+                ok = true;
+            }
+        }
+        char hex[32];
+        std::snprintf(hex, sizeof hex, "%016llx", ok ? h : 0ull);
+        id = std::string(hex) + " " + MW_BUILD_TAG;
+    });
+    return id.c_str();
+}
 const char* mw_last_error(void) { return g_err.c_str(); }
 
 int32_t mw_device_count(void) {
@@ -750,7 +781,8 @@ void mw_params_default(mw_params* p, int32_t semantics) {
 void mw_ocean_destroy(mw_ocean* o) {
     if (!o) return;
     hipSetDevice(o->device);
-    hipStreamSynchronize(o->stream);
+    if (hipStreamSynchronize(o->stream) != hipSuccess) (void)hipGetLastError();  // a dead caller stream has nothing pending
+    o->graph_invalidate();
     hipFree(o->h0); hipFree(o->h0c); hipFree(o->PQt); hipFree(o->Om); hipFree(o->dPQ_i0); hipFree(o->dPQ_j0);
     hipFree(o->TW); hipFree(o->TW2); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white); hipFree(o->scratch);
     direct_free(o->direct);
@@ -836,18 +868,35 @@ mw_status mw_ocean_create(const mw_params* params, mw_ocean** out) { return ocea
 mw_status mw_ocean_create_batch(const mw_params* params, int32_t ntiles, mw_ocean** out) { return ocean_create_impl(params, ntiles, out); }
 int32_t mw_ocean_batch_size(const mw_ocean* o) { return o ? (o->sem == MW_SEM_OCEANRENDERER ? o->orr.tiles : 1) : 0; }
 
+// Drain the stream the handle is leaving.  A caller-owned stream may have been destroyed since (a garbage-collected
+// torch.cuda.Stream): hipErrorInvalidHandle / ContextIsDestroyed then mean "nothing pending" -- the handle must still be able
+// to leave the dead stream (and mw_ocean_destroy to finish).
+static mw_status drain_stream(mw_ocean* o) {
+    const hipError_t e = hipStreamSynchronize(o->stream);
+    if (e == hipSuccess) return MW_OK;
+    if (o->stream != o->own_stream &&
+        (e == hipErrorInvalidHandle || e == hipErrorContextIsDestroyed || e == hipErrorInvalidResourceHandle)) {
+        (void)hipGetLastError();  // clear the sticky error: it described the caller's stream, not this library's work
+        return MW_OK;
+    }
+    return fail(MW_EDEVICE, std::string("hipStreamSynchronize(previous stream): ") + hipGetErrorString(e));
+}
 mw_status mw_ocean_set_stream(mw_ocean* o, void* hip_stream) {
     if (!o) return fail(MW_EINVAL, "NULL handle");
     HIP_TRY(hipSetDevice(o->device));
-    HIP_TRY(hipStreamSynchronize(o->stream));
+    mw_status s = drain_stream(o);
+    if (s != MW_OK) return s;
     o->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = HIP's legacy default stream, like the pond entry points
+    o->graph_invalidate();
     return MW_OK;
 }
 mw_status mw_ocean_use_own_stream(mw_ocean* o) {
     if (!o) return fail(MW_EINVAL, "NULL handle");
     HIP_TRY(hipSetDevice(o->device));
-    HIP_TRY(hipStreamSynchronize(o->stream));
+    mw_status s = drain_stream(o);
+    if (s != MW_OK) return s;
     o->stream = o->own_stream;
+    o->graph_invalidate();
     return MW_OK;
 }
 void* mw_ocean_get_stream(mw_ocean* o) { return o ? reinterpret_cast<void*>(o->stream) : nullptr; }
@@ -939,16 +988,50 @@ mw_status mw_ocean_reinit_spectrum(mw_ocean* o, float length, float wind_x, floa
             return fail(MW_ESTATE, "mw_ocean_reinit_spectrum: the new length moves the grid between the FFT and the direct-sum path; "
                                    "create a new handle");
         const size_t NN = (size_t)N * N;
+        // Transactional: the new spectrum is generated into staging memory and the derived tables (PQt, omega) are built from
+        // there; h0 / h0conj are replaced only once that has succeeded.  On failure the tables are rebuilt from the untouched
+        // old spectrum with the old length, so the handle stays consistent either way.
+        void* buf = nullptr;
+        mw_status s = scratch_reserve(o, 2 * align256(NN * sizeof(cf)), &buf);
+        if (s != MW_OK) return s;
+        cf *n0 = static_cast<cf*>(buf), *n0c = reinterpret_cast<cf*>(static_cast<char*>(buf) + align256(NN * sizeof(cf)));
         hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, o->stream, N, length, wind_x, wind_y,
-                           amplitude, o->p.gravity, seed, o->h0, o->h0c);
+                           amplitude, o->p.gravity, seed, n0, n0c);
         HIP_TRY(hipGetLastError());
         const float old_length = o->p.length;
+        cf *old0 = o->h0, *old0c = o->h0c;
         o->p.length = length;  // run_prep reads it (omega table, S/FFTMesh.cs:141-147)
-        mw_status s = run_prep(o);
-        if (s != MW_OK) { o->p.length = old_length; return s; }
+        o->h0 = n0; o->h0c = n0c;
+        s = run_prep(o);
+        o->h0 = old0; o->h0c = old0c;
+        hipError_t e = hipSuccess;
+        if (s == MW_OK) e = hipMemcpyAsync(o->h0, n0, NN * sizeof(cf), hipMemcpyDeviceToDevice, o->stream);
+        if (s == MW_OK && e == hipSuccess) e = hipMemcpyAsync(o->h0c, n0c, NN * sizeof(cf), hipMemcpyDeviceToDevice, o->stream);
+        if (s == MW_OK && e == hipSuccess) e = hipStreamSynchronize(o->stream);
+        if (s != MW_OK || e != hipSuccess) {
+            o->p.length = old_length;
+            (void)run_prep(o);  // best effort: tables back to (old spectrum, old length)
+            (void)hipStreamSynchronize(o->stream);
+            return s != MW_OK ? s : fail(MW_EDEVICE, std::string("mw_ocean_reinit_spectrum: ") + hipGetErrorString(e));
+        }
     }
     o->p.length = length; o->p.wind_x = wind_x; o->p.wind_y = wind_y; o->p.amplitude = amplitude; o->p.seed = seed;
     HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
+}
+
+// OceanRenderer: the length the normal pass uses (normalMat._Length, set once in SetParams, S/OceanRenderer.cs:163, and
+// never again -- a later length change through mw_ocean_reinit_spectrum leaves it behind).  Part of the checkpoint:
+// restoring (initialTexture, phase) into a fresh handle created with the CURRENT length must also restore this.
+float mw_ocean_normal_length(const mw_ocean* o) {
+    if (!o) return 0.f;
+    return o->sem == MW_SEM_OCEANRENDERER ? o->orr.c.normal_length : o->p.length;
+}
+mw_status mw_ocean_set_normal_length(mw_ocean* o, float normal_length) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_set_normal_length: OceanRenderer semantics only");
+    if (!(normal_length > 0.f)) return fail(MW_EINVAL, "mw_ocean_set_normal_length: must be positive");
+    o->orr.c.normal_length = normal_length;
     return MW_OK;
 }
 
@@ -1219,10 +1302,11 @@ mw_status mw_debug_omega_t(mw_ocean* o, float t, float* out_host) {
     mw_status s = dmalloc(&d, (size_t)N * N);
     if (s != MW_OK) return s;
     hipLaunchKernelGGL(k_omega_t, dim3((N * N + 255) / 256), dim3(256), 0, o->stream, N, o->p.length, o->p.gravity, t, d);
-    hipMemcpyAsync(out_host, d, sizeof(float) * N * N, hipMemcpyDeviceToHost, o->stream);
-    hipError_t e = hipStreamSynchronize(o->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d, sizeof(float) * N * N, hipMemcpyDeviceToHost, o->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(o->stream);
     hipFree(d);
-    return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, "mw_debug_omega_t failed");
+    return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, std::string("mw_debug_omega_t: ") + hipGetErrorString(e));
 }
 
 // test hook: one EvaluateWaves(t) that also returns hds = (d.x, d.z) exactly as the kernels hold it (S/FFTMesh.cs:247), so
@@ -1274,16 +1358,21 @@ mw_status mw_debug_sincos_fast(const float* x_host, int32_t n, float* s_host, fl
     return debug_sincos(x_host, n, s_host, c_host, true);
 }
 static mw_status debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host, bool fast) {
+    if (!x_host || !s_host || !c_host || n < 1) return fail(MW_EINVAL, "mw_debug_sincos: bad argument");
     float *dx = nullptr, *ds = nullptr, *dc = nullptr;
-    if (hipMalloc((void**)&dx, 4 * n) != hipSuccess || hipMalloc((void**)&ds, 4 * n) != hipSuccess ||
-        hipMalloc((void**)&dc, 4 * n) != hipSuccess) return fail(MW_ENOMEM, "hipMalloc");
-    hipMemcpy(dx, x_host, 4 * n, hipMemcpyHostToDevice);
-    if (fast) hipLaunchKernelGGL(k_dbg_sincos_fast, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, ds, dc);
-    else hipLaunchKernelGGL(k_dbg_sincos, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, ds, dc);
-    hipMemcpy(s_host, ds, 4 * n, hipMemcpyDeviceToHost);
-    hipMemcpy(c_host, dc, 4 * n, hipMemcpyDeviceToHost);
+    hipError_t e = hipMalloc((void**)&dx, 4 * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void**)&ds, 4 * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void**)&dc, 4 * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpy(dx, x_host, 4 * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (fast) hipLaunchKernelGGL(k_dbg_sincos_fast, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, ds, dc);
+        else hipLaunchKernelGGL(k_dbg_sincos, dim3((n + 255) / 256), dim3(256), 0, 0, dx, n, ds, dc);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(s_host, ds, 4 * (size_t)n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(c_host, dc, 4 * (size_t)n, hipMemcpyDeviceToHost);
     hipFree(dx); hipFree(ds); hipFree(dc);
-    return MW_OK;
+    return e == hipSuccess ? MW_OK : fail(MW_EDEVICE, std::string("mw_debug_sincos: ") + hipGetErrorString(e));
 }
 mw_status mw_debug_stream_read(int64_t bytes, int32_t width, int32_t iters) {
     void* buf = nullptr;
@@ -1318,6 +1407,30 @@ mw_status mw_debug_get_stamps(long long* out_host) {
 #include "tiles.inc"
 
 // ---- pond -------------------------------------------------------------------------------------
+}  // extern "C" (reopened below)
+// Device staging of the handle-less host-pointer pond entry points: one grow-only buffer per device, held for the whole
+// (synchronous) call -- no hipMalloc / hipFree per frame, like the handle entry points (scratch_reserve).
+struct PondScratch {
+    std::mutex mu[64];
+    void* buf[64] = {};
+    size_t cap[64] = {};
+    struct Lock {
+        PondScratch& s;
+        int d;
+        Lock(PondScratch& s_, int device) : s(s_), d(device & 63) { s.mu[d].lock(); }
+        ~Lock() { s.mu[d].unlock(); }
+        void* reserve(size_t bytes) {
+            if (s.cap[d] < bytes) {
+                if (s.buf[d]) { (void)hipDeviceSynchronize(); (void)hipFree(s.buf[d]); s.buf[d] = nullptr; s.cap[d] = 0; }
+                if (hipMalloc(&s.buf[d], bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+                s.cap[d] = bytes;
+            }
+            return s.buf[d];
+        }
+    };
+};
+static PondScratch g_pond_scratch;
+extern "C" {
 mw_status mw_gerstner_displace_device(const void* d_pos_xyz, int64_t nverts, const float* waves, int32_t nwaves,
                                       float amplitude, float frequency, float steepness, float t, void* d_out_xyz,
                                       void* hip_stream) {
@@ -1361,18 +1474,17 @@ mw_status mw_gerstner_displace(const float* pos_xyz, int64_t nverts, const float
     if (device < 0 || device >= ndev) return fail(MW_EINVAL, "bad device ordinal");
     if (nverts <= 0) return nverts == 0 ? MW_OK : fail(MW_EINVAL, "nverts < 0");
     HIP_TRY(hipSetDevice(device));
-    float *dp = nullptr, *dq = nullptr;
-    const size_t bytes = (size_t)nverts * 3 * sizeof(float);
-    HIP_TRY(hipMalloc((void**)&dp, bytes));
-    if (hipMalloc((void**)&dq, bytes) != hipSuccess) { hipFree(dp); return fail(MW_ENOMEM, "hipMalloc failed"); }
-    mw_status s = MW_OK;
-    if (hipMemcpy(dp, pos_xyz, bytes, hipMemcpyHostToDevice) != hipSuccess) s = fail(MW_EDEVICE, "H2D failed");
-    if (s == MW_OK) s = mw_gerstner_displace_device(dp, nverts, waves, nwaves, amplitude, frequency, steepness, t, dq, nullptr);
-    if (s == MW_OK && hipDeviceSynchronize() != hipSuccess) s = fail(MW_EDEVICE, "gerstner kernel failed");
-    if (s == MW_OK && hipMemcpy(out_xyz, dq, bytes, hipMemcpyDeviceToHost) != hipSuccess) s = fail(MW_EDEVICE, "D2H failed");
-    hipFree(dp);
-    hipFree(dq);
-    return s;
+    const size_t bytes = (size_t)nverts * 3 * sizeof(float), stride = align256(bytes);
+    PondScratch::Lock lk(g_pond_scratch, device);
+    char* base = static_cast<char*>(lk.reserve(2 * stride));
+    if (!base) return fail(MW_ENOMEM, "mw_gerstner_displace: device staging buffer");
+    float *dp = reinterpret_cast<float*>(base), *dq = reinterpret_cast<float*>(base + stride);
+    HIP_TRY(hipMemcpy(dp, pos_xyz, bytes, hipMemcpyHostToDevice));
+    mw_status s = mw_gerstner_displace_device(dp, nverts, waves, nwaves, amplitude, frequency, steepness, t, dq, nullptr);
+    if (s != MW_OK) return s;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(out_xyz, dq, bytes, hipMemcpyDeviceToHost));
+    return MW_OK;
 }
 
 static mw_status pond_params_of(const mw_pond_params* p, PondParams* P, const char* who) {
@@ -1411,20 +1523,18 @@ mw_status mw_pond_displace(const mw_pond_params* p, const float* pos_xyz, int64_
     if (nverts <= 0) return nverts == 0 ? MW_OK : fail(MW_EINVAL, "nverts < 0");
     if (!pos_xyz || !out_xyz) return fail(MW_EINVAL, "mw_pond_displace: NULL argument");
     HIP_TRY(hipSetDevice(device));
-    float *dp = nullptr, *dq = nullptr, *dn = nullptr;
-    const size_t bytes = (size_t)nverts * 3 * sizeof(float);
-    if (hipMalloc((void**)&dp, bytes) != hipSuccess || hipMalloc((void**)&dq, bytes) != hipSuccess ||
-        (out_normal_xyz && hipMalloc((void**)&dn, bytes) != hipSuccess)) {
-        hipFree(dp); hipFree(dq); hipFree(dn);
-        return fail(MW_ENOMEM, "hipMalloc failed");
-    }
-    if (hipMemcpy(dp, pos_xyz, bytes, hipMemcpyHostToDevice) != hipSuccess) s = fail(MW_EDEVICE, "H2D failed");
-    if (s == MW_OK) s = mw_pond_displace_device(p, dp, nverts, t, dq, dn, nullptr);
-    if (s == MW_OK && hipDeviceSynchronize() != hipSuccess) s = fail(MW_EDEVICE, "pond kernel failed");
-    if (s == MW_OK && hipMemcpy(out_xyz, dq, bytes, hipMemcpyDeviceToHost) != hipSuccess) s = fail(MW_EDEVICE, "D2H failed");
-    if (s == MW_OK && dn && hipMemcpy(out_normal_xyz, dn, bytes, hipMemcpyDeviceToHost) != hipSuccess) s = fail(MW_EDEVICE, "D2H failed");
-    hipFree(dp); hipFree(dq); hipFree(dn);
-    return s;
+    const size_t bytes = (size_t)nverts * 3 * sizeof(float), stride = align256(bytes);
+    PondScratch::Lock lk(g_pond_scratch, device);
+    char* base = static_cast<char*>(lk.reserve((out_normal_xyz ? 3 : 2) * stride));
+    if (!base) return fail(MW_ENOMEM, "mw_pond_displace: device staging buffer");
+    float *dp = reinterpret_cast<float*>(base), *dq = reinterpret_cast<float*>(base + stride);
+    float* dn = out_normal_xyz ? reinterpret_cast<float*>(base + 2 * stride) : nullptr;
+    HIP_TRY(hipMemcpy(dp, pos_xyz, bytes, hipMemcpyHostToDevice));
+    if ((s = mw_pond_displace_device(p, dp, nverts, t, dq, dn, nullptr)) != MW_OK) return s;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(out_xyz, dq, bytes, hipMemcpyDeviceToHost));
+    if (dn) HIP_TRY(hipMemcpy(out_normal_xyz, dn, bytes, hipMemcpyDeviceToHost));
+    return MW_OK;
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@ REPO_DIR = os.path.dirname(AMD_DIR)
 CSRC_DIR = os.path.join(AMD_DIR, "csrc")
 LIB_PATH = os.environ.get("MW_LIB") or os.path.join(AMD_DIR, "libmistral_water.so")  # MW_LIB: A/B kernel variants
 HEADER_PATH = os.path.join(REPO_DIR, "include", "mistral_water.h")
+HOOKS_HEADER_PATH = os.path.join(REPO_DIR, "include", "mistral_water_hooks.h")
 
 MW_OK, MW_EINVAL, MW_ENOTPOW2, MW_ENOTCOMMENSURATE, MW_ENOMEM, MW_EDEVICE, MW_ESTATE = range(7)
 MW_SEM_FFTMESH, MW_SEM_OCEANRENDERER = 0, 1
@@ -47,29 +48,40 @@ class MistralWaterError(RuntimeError):
         self.status = status
 
 
-def build_native(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)] + [HEADER_PATH]
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs)):
-        return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-           "-Wno-unused-value",
-           # the SLP vectoriser's v_pk_* packing costs ~300 v_mov per kernel and 50 % more VGPRs (DESIGN.md section 6)
-           "-fno-slp-vectorize",
-           # the 2-virtual-thread kernels are ~20k IR instructions once their field loop is unrolled: above the default cap
-           # (16384) the pragma is ignored, the field index stays dynamic and the state arrays land in scratch
-           "-mllvm", "-pragma-unroll-threshold=1000000",
-           # no pairing of DS operations into ds_read2/ds_write2: the exchange layouts (XLay, mw_math.h) are bank-exact for single
-           # 8-byte reads (256 B/clk); a paired read is served in 16-lane groups at 128 B/clk and is 2-way conflicted on them
-           "-Xclang", "-target-feature", "-Xclang", "-load-store-opt",
-           "-o", LIB_PATH, os.path.join(CSRC_DIR, "mistral_water.hip")]
+BUILD_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-unused-value",
+               # the SLP vectoriser's v_pk_* packing costs ~300 v_mov per kernel and 50 % more VGPRs
+               "-fno-slp-vectorize",
+               # the 2-virtual-thread kernels are ~20k IR instructions once their field loop is unrolled: above the default cap
+               # (16384) the pragma is ignored, the field index stays dynamic and the state arrays land in scratch
+               "-mllvm", "-pragma-unroll-threshold=1000000",
+               # no pairing of DS operations into ds_read2/ds_write2: the exchange layouts (XLay, mw_math.h) are bank-exact for
+               # single 8-byte reads (256 B/clk); a paired read is served in 16-lane groups at 128 B/clk, 2-way conflicted
+               "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
+
+
+def build_native(force: bool = False, verbose: bool = False, out: str | None = None, extra=(), tag: str | None = None,
+                 resource_report: str | None = None) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU).
+    `out` / `extra` / `tag`: an A/B variant (tools/build_variant.sh): other output path, extra -D flags, the tag mw_build_id() carries."""
+    target = out or LIB_PATH
+    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)] + [HEADER_PATH, HOOKS_HEADER_PATH]
+    if (not force and not extra and os.path.exists(target)
+            and all(os.path.getmtime(s) <= os.path.getmtime(target) for s in srcs)):
+        return target
+    cmd = ["hipcc"] + BUILD_FLAGS + list(extra)
+    if tag:
+        cmd.append('-DMW_BUILD_TAG="%s"' % tag)
+    if resource_report:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    cmd += ["-o", target, os.path.join(CSRC_DIR, "mistral_water.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
+    if resource_report:
+        open(resource_report, "w").write(r.stderr)
     if verbose or r.returncode != 0:
-        print(r.stdout, r.stderr)
+        print(r.stdout, r.stderr if not resource_report else r.stderr[-4000:])
     if r.returncode != 0:
         raise RuntimeError("hipcc failed building libmistral_water.so:\n" + r.stderr[-4000:])
-    return LIB_PATH
+    return target
 
 
 _lib = None
@@ -87,6 +99,7 @@ def lib():
     vp, f32p, i32p = C.c_void_p, C.c_void_p, C.c_void_p
     sig = {
         "mw_abi_version": (C.c_int32, []),
+        "mw_build_id": (C.c_char_p, []),
         "mw_last_error": (C.c_char_p, []),
         "mw_device_count": (C.c_int32, []),
         "mw_params_default": (None, [C.POINTER(MwParams), C.c_int32]),
@@ -100,6 +113,8 @@ def lib():
         "mw_ocean_get_phase": (C.c_int, [vp, f32p]),
         "mw_ocean_set_phase": (C.c_int, [vp, f32p]),
         "mw_ocean_set_timer": (C.c_int, [vp, C.c_float]),
+        "mw_ocean_normal_length": (C.c_float, [vp]),
+        "mw_ocean_set_normal_length": (C.c_int, [vp, C.c_float]),
         "mw_comm_unique_id": (C.c_int, [vp]),
         "mw_tiles_create": (C.c_int, [C.POINTER(MwParams), C.c_int32, i32p, C.c_int32, C.POINTER(vp)]),
         "mw_tiles_create_rank": (C.c_int, [C.POINTER(MwParams), C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, C.POINTER(vp)]),
@@ -109,6 +124,8 @@ def lib():
         "mw_tiles_ocean": (vp, [vp, C.c_int32]),
         "mw_tiles_evaluate": (C.c_int, [vp, f32p, C.c_int32, C.c_uint32]),
         "mw_tiles_outputs": (C.c_int, [vp, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "mw_tiles_generate_texture": (C.c_int, [vp, C.c_float]),
+        "mw_tiles_textures": (C.c_int, [vp, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "mw_tiles_gather": (C.c_int, [vp, C.c_int32, C.c_int32]),
         "mw_tiles_gathered": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "mw_tiles_synchronize": (C.c_int, [vp]),
@@ -161,18 +178,28 @@ def lib():
 
 #: every symbol include/mistral_water.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [
-    "mw_abi_version", "mw_last_error", "mw_device_count", "mw_params_default", "mw_ocean_create", "mw_ocean_destroy", "mw_ocean_create_batch", "mw_ocean_batch_size",
+    "mw_abi_version", "mw_build_id", "mw_last_error", "mw_device_count", "mw_params_default", "mw_ocean_create", "mw_ocean_destroy",
+    "mw_ocean_create_batch", "mw_ocean_batch_size",
     "mw_ocean_set_stream", "mw_ocean_use_own_stream", "mw_ocean_get_stream", "mw_ocean_synchronize", "mw_ocean_set_choppiness",
     "mw_ocean_set_spectrum", "mw_ocean_get_spectrum", "mw_ocean_reinit_spectrum", "mw_ocean_get_phase", "mw_ocean_set_phase",
-    "mw_ocean_set_timer", "mw_comm_unique_id", "mw_tiles_create", "mw_tiles_create_rank", "mw_tiles_destroy", "mw_tiles_count",
-    "mw_tiles_local_count", "mw_tiles_ocean", "mw_tiles_evaluate", "mw_tiles_outputs", "mw_tiles_gather", "mw_tiles_gathered",
+    "mw_ocean_set_timer", "mw_ocean_normal_length", "mw_ocean_set_normal_length", "mw_comm_unique_id", "mw_tiles_create",
+    "mw_tiles_create_rank", "mw_tiles_destroy", "mw_tiles_count",
+    "mw_tiles_local_count", "mw_tiles_ocean", "mw_tiles_evaluate", "mw_tiles_outputs", "mw_tiles_generate_texture", "mw_tiles_textures",
+    "mw_tiles_gather", "mw_tiles_gathered",
     "mw_tiles_synchronize", "mw_ocean_rest_mesh", "mw_ocean_index_count",
     "mw_ocean_grid_size", "mw_ocean_evaluate", "mw_ocean_update", "mw_ocean_timer", "mw_ocean_reset_timer",
     "mw_ocean_evaluate_device", "mw_ocean_max_batch", "mw_ocean_generate_texture",
     "mw_ocean_generate_texture_device", "mw_host_register", "mw_host_unregister", "mw_ocean_generate_texture_rgba", "mw_ocean_generate_texture_rgba_device",
-    "mw_ocean_displace_mesh", "mw_ocean_displace_mesh_device", "mw_ocean_profile_kernels", "mw_gerstner_displace",
-    "mw_gerstner_displace_device", "mw_gerstner_displace_steps_device", "mw_gerstner_max_steps", "mw_pond_displace", "mw_pond_displace_device", "mw_debug_omega_t", "mw_debug_evaluate_hds", "mw_debug_get_omega", "mw_debug_sincos", "mw_debug_sincos_fast", "mw_debug_stream_read",
+    "mw_ocean_displace_mesh", "mw_ocean_displace_mesh_device", "mw_gerstner_displace",
+    "mw_gerstner_displace_device", "mw_gerstner_displace_steps_device", "mw_gerstner_max_steps", "mw_pond_displace", "mw_pond_displace_device",
 ]
+#: measurement and test hooks (include/mistral_water_hooks.h): exported, but not part of the drop-in boundary
+HOOK_SYMBOLS = ["mw_ocean_profile_kernels", "mw_debug_omega_t", "mw_debug_evaluate_hds", "mw_debug_get_omega", "mw_debug_sincos",
+                "mw_debug_sincos_fast", "mw_debug_stream_read"]
+
+
+def build_id() -> str:
+    return lib().mw_build_id().decode()
 
 
 def check(status: int):

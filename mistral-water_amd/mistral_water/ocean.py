@@ -116,6 +116,15 @@ class Ocean:
         assert ph.size == self.N * self.N * self.ntiles
         nat.check(nat.lib().mw_ocean_set_phase(self._h, _p(ph)))
 
+    @property
+    def normal_length(self) -> float:
+        """OceanRenderer: normalMat._Length (S/OceanRenderer.cs:163) -- set at creation, not by reinit_spectrum; part of a checkpoint."""
+        return float(nat.lib().mw_ocean_normal_length(self._h))
+
+    @normal_length.setter
+    def normal_length(self, v: float):
+        nat.check(nat.lib().mw_ocean_set_normal_length(self._h, C.c_float(v)))
+
     def set_timer(self, t: float):
         nat.check(nat.lib().mw_ocean_set_timer(self._h, C.c_float(t)))
 
@@ -333,15 +342,18 @@ class OceanRenderer:
 
 
 class Tiles:
-    """Independent FFTMesh-semantics tiles (seed = seed0 + k) on several devices with an RCCL gather of finished outputs
+    """Independent tiles (seed = seed0 + k) on several devices with an RCCL gather of finished outputs
     (include/mistral_water.h, mw_tiles_*).  ``devices`` lists one device ordinal per tile (single-process form); pass
-    ``comm_id``/``rank``/``nranks`` instead for the one-process-per-GPU form."""
+    ``comm_id``/``rank``/``nranks`` instead for the one-process-per-GPU form.  FFTMesh semantics (default): ``evaluate`` /
+    ``outputs``; OceanRenderer semantics (``max_steps`` 1, the tile axis is the only one that shards there):
+    ``generate_texture`` / ``textures``."""
 
     def __init__(self, *, resolution, ntiles=1, devices=None, max_steps=1, unit_width=1.0, length=1.0, wind=(1.0, 1.0), amplitude=1.0,
-                 choppiness=1.0, gravity=9.81, seed=1, comm_id=None, rank=0, nranks=1, device=0):
+                 choppiness=1.0, gravity=9.81, seed=1, comm_id=None, rank=0, nranks=1, device=0, semantics=nat.MW_SEM_FFTMESH,
+                 mult=1.0):
         self._h = C.c_void_p()
         self.params = nat.MwParams(int(resolution), float(unit_width), float(length), float(wind[0]), float(wind[1]),
-                                   float(amplitude), float(choppiness), float(gravity), 1.0, 1.0, int(seed), nat.MW_SEM_FFTMESH, 0)
+                                   float(amplitude), float(choppiness), float(gravity), 1.0, float(mult), int(seed), int(semantics), 0)
         if comm_id is None:
             dv = None if devices is None else (C.c_int32 * ntiles)(*[int(d) for d in devices])
             nat.check(nat.lib().mw_tiles_create(C.byref(self.params), int(ntiles), dv, int(max_steps), C.byref(self._h)))
@@ -349,7 +361,7 @@ class Tiles:
             buf = (C.c_ubyte * nat.MW_COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
             nat.check(nat.lib().mw_tiles_create_rank(C.byref(self.params), int(device), int(max_steps), buf, int(rank), int(nranks),
                                                      C.byref(self._h)))
-        self.N = int(resolution)
+        self.N = int(resolution) * (8 if semantics == nat.MW_SEM_OCEANRENDERER else 1)   # synthesis grid (S/OceanRenderer.cs:136)
         self.max_steps = int(max_steps)
 
     @staticmethod
@@ -406,7 +418,17 @@ class Tiles:
         nat.check(nat.lib().mw_tiles_outputs(self._h, int(k), C.byref(v), C.byref(n), C.byref(w)))
         return v.value, n.value, w.value
 
-    def gather(self, step: int, root: int = 0):
+    def generate_texture(self, delta_time: float):
+        """OceanRenderer tiles: one GenerateTexture() on every local tile (asynchronous)."""
+        nat.check(nat.lib().mw_tiles_generate_texture(self._h, C.c_float(delta_time)))
+
+    def textures(self, k):
+        """OceanRenderer tiles: device pointers (ints) of local tile k's height, disp_xz, normal_xyz, white textures."""
+        h, d, n, w = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nat.check(nat.lib().mw_tiles_textures(self._h, int(k), C.byref(h), C.byref(d), C.byref(n), C.byref(w)))
+        return h.value, d.value, n.value, w.value
+
+    def gather(self, step: int = 0, root: int = 0):
         nat.check(nat.lib().mw_tiles_gather(self._h, int(step), int(root)))
 
     def gathered(self):

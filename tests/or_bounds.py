@@ -77,7 +77,7 @@ def _check(n, w, N_ref, W_ref, bn, bw, tag):
     return float((en / bn).max()), float((ew / bw).max()), float(np.median(bn)), float(np.median(bw))
 
 
-def assert_normal_white(n, w, N_ref, W_ref, length_normal, Dr, Dg, Db, H, got=None, rel=3e-6, tag=""):
+def assert_normal_white(n, w, N_ref, W_ref, length_normal, Dr, Dg, Db, H, got=None, rel=3e-6, tag="", return_bounds=False):
     """END TO END: device normal [M,M,3] / whitecap [M,M] vs the oracle's (computed from the oracle's own textures), each texel
     against its own bound.  `got` = the device's (Dr, Dg, Db, H): delta is then the error actually MEASURED on the transformed
     textures (itself held to `rel` of their maximum); without it delta is the tolerance `rel` itself."""
@@ -88,7 +88,8 @@ def assert_normal_white(n, w, N_ref, W_ref, length_normal, Dr, Dg, Db, H, got=No
         assert measured <= delta, f"{tag} textures: {measured:.3e} > {delta:.3e}"
         delta = max(measured, 2.0 ** -24 * scale)
     bn, bw = normal_white_bounds(length_normal, Dr, Dg, Db, H, delta)
-    return _check(n, w, N_ref, W_ref, bn, bw, tag)
+    r = _check(n, w, N_ref, W_ref, bn, bw, tag)
+    return (r, bn, bw, delta) if return_bounds else r
 
 
 def assert_normal_white_stage(oracle, rp_normal, Ht, Dt, Nt, Wt, tag=""):
@@ -104,3 +105,80 @@ def assert_normal_white_stage(oracle, rp_normal, Ht, Dt, Nt, Wt, tag=""):
                                       N_ref.ctypes.data_as(C.c_void_p), W_ref.ctypes.data_as(C.c_void_p))
     bn, bw = normal_white_bounds(rp_normal.length, dtex[..., 0], dtex[..., 1], dtex[..., 2], hre, 0.0)
     return _check(Nt[..., :3], Wt[..., 0], N_ref, W_ref, bn, bw, tag + " (stage)")
+
+
+# ---- the ocean material's vertex stage (W/TestOcean.shader:61-79, or_mesh_vertex) ----------------------------------------------
+# A mesh vertex samples the four textures bilinearly (tex2Dlod, clamp) and normalises the sampled normal.  Its error budget is
+# therefore that of the texels it touches: a weighted mean of <= 4 texel errors, amplified by 1/|s| in the normalisation
+# (s = the interpolated, not yet normalised normal: short where neighbouring texel normals disagree), plus the float32
+# rounding of the stage itself.  No quantiles: every vertex is held to the bound of its own taps.
+def _mesh_axis(M, res):
+    """Tap indices and weight of the res mesh lines on an M-texel axis, as the kernel forms them (uv in f32, S/OceanRenderer.cs:184)."""
+    u = np.arange(res, dtype=np.float32) / np.float32(res - 1)
+    x = (u * np.float32(M) - np.float32(0.5)).astype(np.float64)
+    fl = np.floor(x)
+    i0 = fl.astype(np.int64)
+    return np.clip(i0, 0, M - 1), np.clip(i0 + 1, 0, M - 1), x - fl
+
+
+def _mesh_sample(tex, M, res, reduce=None):
+    """tex [M, M(, C)] indexed [py, px] sampled at the res x res mesh vertices, vertex (i, j) at index i*res + j (u from i -> px,
+    v from j -> py).  reduce=None: bilinear in f64; reduce=np.maximum: the largest of the four taps (error bounds)."""
+    x0, x1, wx = _mesh_axis(M, res)
+    y0, y1, wy = _mesh_axis(M, res)
+    X0, Y0 = np.meshgrid(x0, y0, indexing="ij")
+    X1, Y1 = np.meshgrid(x1, y1, indexing="ij")
+    a00, a10, a01, a11 = tex[Y0, X0], tex[Y0, X1], tex[Y1, X0], tex[Y1, X1]
+    if reduce is not None:
+        return reduce(reduce(a00, a10), reduce(a01, a11)).reshape((res * res,) + tex.shape[2:])
+    WX, WY = np.meshgrid(wx, wy, indexing="ij")
+    if tex.ndim == 3:
+        WX, WY = WX[..., None], WY[..., None]
+    a0, a1 = a00 + (a10 - a00) * WX, a01 + (a11 - a01) * WX
+    return (a0 + (a1 - a0) * WY).reshape((res * res,) + tex.shape[2:])
+
+
+def _dilate(a):
+    """3 x 3 maximum: a tap index that differs by one between the f32 kernel and this f64 restatement stays covered."""
+    out = a.copy()
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            out = np.maximum(out, _shift(a, dx, dy))
+    return out
+
+
+ULP = 2.0 ** -24
+
+
+def assert_mesh_stage_alone(mesh_ref, got, N_tex, res, tag=""):
+    """THE STAGE ALONE: device mesh (v, n, c) vs the oracle's f64 vertex stage evaluated on the DEVICE's own textures
+    (mesh_ref): float32 rounding of the bilinear taps, of the /8 and of the normalisation only."""
+    (V, Nn, Cc), (v, n, c) = mesh_ref, got
+    M = N_tex.shape[0]
+    s = np.maximum(np.linalg.norm(_mesh_sample(np.asarray(N_tex, np.float64), M, res), axis=-1), 1e-30)
+    bv = 8 * ULP * (np.abs(V) + 1e-3)
+    assert (np.abs(v - V) <= bv).all(), f"{tag} mesh vertices (stage): worst ratio {float((np.abs(v - V) / bv).max()):.2f}"
+    bn = np.minimum(16 * ULP / s + 4 * ULP, 2.0)
+    en = np.abs(n - Nn).max(-1)
+    assert (en <= bn).all(), f"{tag} mesh normals (stage): {int((en > bn).sum())} vertices above their bound, worst ratio {float((en / bn).max()):.2f}"
+    bc = 8 * ULP * np.maximum(1.0, np.abs(Cc))
+    assert (np.abs(c - Cc) <= bc).all(), f"{tag} mesh colours (stage): worst ratio {float((np.abs(c - Cc) / bc).max()):.2f}"
+    return float((en / bn).max()), float(np.median(bn))
+
+
+def assert_mesh_end_to_end(mesh_ref, got, N_ref_tex, bn_tex, bw_tex, delta, res, tag=""):
+    """END TO END: device mesh vs the oracle's mesh from the oracle's own textures.  bn_tex / bw_tex: the per-texel bounds of
+    the normal / whitecap textures (normal_white_bounds), delta: the absolute error of the height / displacement textures."""
+    (V, Nn, Cc), (v, n, c) = mesh_ref, got
+    M = N_ref_tex.shape[0]
+    s = np.maximum(np.linalg.norm(_mesh_sample(np.asarray(N_ref_tex, np.float64), M, res), axis=-1), 1e-30)
+    bv = delta / 8.0 + 8 * ULP * (np.abs(V) + 1e-3)
+    assert (np.abs(v - V) <= bv).all(), f"{tag} mesh vertices: worst ratio {float((np.abs(v - V) / bv).max()):.2f}"
+    tn = _mesh_sample(_dilate(bn_tex), M, res, reduce=np.maximum)
+    bn = np.minimum(2.0 * np.sqrt(3.0) * tn / s + 16 * ULP / s + 4 * ULP, 2.0)
+    en = np.abs(n - Nn).max(-1)
+    assert (en <= bn).all(), f"{tag} mesh normals: {int((en > bn).sum())} vertices above their bound, worst ratio {float((en / bn).max()):.2f}"
+    bc = _mesh_sample(_dilate(bw_tex), M, res, reduce=np.maximum) + 8 * ULP
+    ec = np.abs(c - Cc)
+    assert (ec <= bc).all(), f"{tag} mesh colours: {int((ec > bc).sum())} vertices above their bound, worst ratio {float((ec / bc).max()):.2f}"
+    return float((en / bn).max()), float((ec / bc).max()), float(np.median(bn)), float(np.median(bc))

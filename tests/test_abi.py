@@ -10,27 +10,48 @@ import pytest
 from conftest import REPO, has_gpu
 
 HEADER = os.path.join(REPO, "include", "mistral_water.h")
+HOOKS_HEADER = os.path.join(REPO, "include", "mistral_water_hooks.h")
 
 
-def declared_symbols():
-    txt = open(HEADER).read()
+def declared_symbols(path=HEADER):
+    txt = open(path).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(mw_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol(mw):
     from mistral_water import _native
-    syms = declared_symbols()
+    syms, hooks = declared_symbols(), declared_symbols(HOOKS_HEADER)
     assert len(syms) >= 25
     L = C.CDLL(_native.LIB_PATH)
-    for s in syms:
-        assert hasattr(L, s), f"{s} declared in include/mistral_water.h but not exported"
+    for s in syms + hooks:
+        assert hasattr(L, s), f"{s} declared in include/*.h but not exported"
     assert sorted(_native.ABI_SYMBOLS) == syms, "python binding list out of date with the header"
+    assert sorted(_native.HOOK_SYMBOLS) == hooks, "python hook list out of date with mistral_water_hooks.h"
+
+
+def test_hooks_are_not_part_of_the_boundary():
+    """Measurement / test hooks live in their own header: the drop-in boundary (and the C# import table, test_csharp_binding)
+    carries none of them."""
+    pub = declared_symbols()
+    assert not [s for s in pub if s.startswith("mw_debug_") or s == "mw_ocean_profile_kernels"]
+    assert all(s.startswith("mw_debug_") or s == "mw_ocean_profile_kernels" for s in declared_symbols(HOOKS_HEADER))
+
+
+def test_build_id_names_this_shared_object(mw):
+    from mistral_water import _native
+    bid = _native.build_id()
+    h, tag = bid.split(" ", 1)
+    assert len(h) == 16 and int(h, 16) != 0 and tag
+    x = 1469598103934665603
+    for b in open(_native.LIB_PATH, "rb").read():
+        x = ((x ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert h == "%016x" % x
 
 
 def test_header_is_plain_c():
     # the boundary must be consumable from C (and therefore from P/Invoke / cgo / JNI / ctypes)
-    src = '#include "mistral_water.h"\nint main(void){ mw_params p; mw_params_default(&p, MW_SEM_FFTMESH); return (int)sizeof(p) == 0; }\n'
+    src = '#include "mistral_water.h"\n#include "mistral_water_hooks.h"\nint main(void){ mw_params p; mw_params_default(&p, MW_SEM_FFTMESH); return (int)sizeof(p) == 0; }\n'
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.dirname(HEADER),
                         "-x", "c", "-"], input=src, text=True, capture_output=True)
     assert r.returncode == 0, r.stderr
@@ -47,7 +68,7 @@ def test_params_struct_layout(mw):
 
 
 def test_abi_version_and_error_string(mw):
-    assert mw.lib().mw_abi_version() == 2
+    assert mw.lib().mw_abi_version() == 3
     assert isinstance(mw.lib().mw_last_error(), bytes)
 
 

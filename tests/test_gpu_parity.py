@@ -405,11 +405,18 @@ def test_golden_pond_and_renderer_fixtures(mw):
                            choppiness=float(pr[5]), gravity=float(pr[6]), mult=float(pr[7]))
     or_bounds.assert_normal_white_stage(O, rpz, H, D, Nn, W, tag="golden renderer frame")
     Dz, Hz = z["disp_rgba"].astype(np.float64), z["height_rgba"].astype(np.float64)
-    or_bounds.assert_normal_white(Nn[..., :3], W[..., 0], z["normal_rgba"][..., :3].astype(np.float64), z["white_rgba"][..., 0].astype(np.float64),
-                                  float(pr[1]), Dz[..., 0], Dz[..., 1], Dz[..., 2], Hz[..., 0], got=(D[..., 0], D[..., 1], D[..., 2], H[..., 0]),
-                                  tag="golden renderer frame")
-    assert np.abs(v - z["mesh_vertices"]).max() < 1e-5
-    assert np.quantile(np.abs(n - z["mesh_normals"]), 0.98) < 1e-4 and np.quantile(np.abs(c - z["mesh_colors"]), 0.98) < 1e-4
+    _, bn, bw, delta = or_bounds.assert_normal_white(Nn[..., :3], W[..., 0], z["normal_rgba"][..., :3].astype(np.float64),
+                                                     z["white_rgba"][..., 0].astype(np.float64), float(pr[1]), Dz[..., 0], Dz[..., 1], Dz[..., 2],
+                                                     Hz[..., 0], got=(D[..., 0], D[..., 1], D[..., 2], H[..., 0]),
+                                                     tag="golden renderer frame", return_bounds=True)
+    # the vertex stage, every vertex against its own bound: alone (oracle's f64 stage on the device's textures), then end to end
+    # against the committed mesh with the bounds of the texels each vertex samples
+    res, uw = int(pr[0]), float(z["unit_width"]) if "unit_width" in z else 1.0
+    stage_ref = O.renderer_mesh_vertex_stage_f64(rpz, uw, H[..., 0], D[..., [0, 2]], Nn[..., :3], W[..., 0])
+    or_bounds.assert_mesh_stage_alone(stage_ref, (v, n, c), Nn[..., :3], res, tag="golden renderer frame")
+    or_bounds.assert_mesh_end_to_end((z["mesh_vertices"].astype(np.float64), z["mesh_normals"].astype(np.float64), z["mesh_colors"].astype(np.float64)),
+                                     (v, n, c), z["normal_rgba"][..., :3].astype(np.float64), bn, bw, delta + 2.0 ** -22 * np.abs(Hz).max(), res,
+                                     tag="golden renderer frame")
 
 
 def test_gerstner_pond(mw, oracle):

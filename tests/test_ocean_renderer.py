@@ -103,17 +103,23 @@ def _rgba_checks(tex, want, rp, oracle):
     M = Ht.shape[0]                                      # the bound is not vacuous: ~1e-3 at the shipped 1024^2 scale, where
     assert mn < 2e-3 * max(1.0, M / 1024.0) ** 2, mn     # float32 differences of a ~10 m swell on a 0.42 m texel lose that much
     # (2) end to end against the oracle's textures: the measured texture error times each texel's condition
-    or_bounds.assert_normal_white(Nt[..., :3], Wt[..., 0], NT[..., :3], WT[..., 0], rp.length, DT[..., 0], DT[..., 1], DT[..., 2],
-                                  HT[..., 0], got=(Dt[..., 0], Dt[..., 1], Dt[..., 2], Ht[..., 0]), tag="rgba")
+    _, bn, bw, delta = or_bounds.assert_normal_white(Nt[..., :3], Wt[..., 0], NT[..., :3], WT[..., 0], rp.length, DT[..., 0], DT[..., 1],
+                                                     DT[..., 2], HT[..., 0], got=(Dt[..., 0], Dt[..., 1], Dt[..., 2], Ht[..., 0]),
+                                                     tag="rgba", return_bounds=True)
+    return bn, bw, delta
 
 
-def _mesh_checks(got, want, hscale):
-    (v, n, c), (V, Nn, Cc) = got, want
-    assert np.abs(v - V).max() < 4e-6 * max(hscale, 1.0) + 4e-6 * np.abs(V).max()
-    en = np.abs(n - Nn).max(-1)
-    assert np.quantile(en, 0.99) < 1e-4 and en.max() < 1e-2
-    ec = np.abs(c - Cc)
-    assert np.quantile(ec, 0.99) < 1e-4 and ec.max() < 1e-2
+def _mesh_checks(oracle, rp, uw, got, dev_tex, want_tex, bounds):
+    """The vertex stage (W/TestOcean.shader:61-79), every vertex against its own bound (tests/or_bounds.py): (1) the stage alone
+    -- the oracle's f64 stage on the DEVICE's textures, float32 rounding only; (2) end to end against the oracle's mesh from the
+    oracle's textures, each vertex with the bound of the texels it samples."""
+    (h, d_rb, n, w), (HT, DT, NT, WT), (bn, bw, delta) = dev_tex, want_tex, bounds
+    res = rp.resolution
+    stage_ref = oracle.renderer_mesh_vertex_stage_f64(rp, uw, h, d_rb, n, w)
+    or_bounds.assert_mesh_stage_alone(stage_ref, got, n, res, tag="mesh")
+    ref = oracle.renderer_mesh_vertex_stage_f64(rp, uw, HT[..., 0], DT[..., [0, 2]], NT[..., :3], WT[..., 0])
+    rn, rc, mn, mc = or_bounds.assert_mesh_end_to_end(ref, got, NT[..., :3], bn, bw, delta, res, tag="mesh")
+    assert mn < 2e-2 and mc < 2e-2, (mn, mc)     # the bounds are not vacuous: the median vertex is held to < 2e-2 (unit normal / [0,1] colour)
 
 
 def test_emulated_rgba_textures_and_mesh_vertex_stage(emul, oracle):
@@ -128,12 +134,10 @@ def test_emulated_rgba_textures_and_mesh_vertex_stage(emul, oracle):
     for dt in (0.016, 0.3):
         h, d, n, w, g, hg, da = emul.or_step(rp, initT, phaseT, dt, imag=True)
         want = oracle.renderer_textures_f64(rp, init4, ph, dt)
-        _rgba_checks(emul.or_pack_rgba(h, hg, d, g, da, n, w), want, rp, oracle)
-    HT, DT, NT, WT = want
+        bounds = _rgba_checks(emul.or_pack_rgba(h, hg, d, g, da, n, w), want, rp, oracle)
     for uw in (1.0, 0.37):
         got = emul.or_displace_mesh(M, rp.resolution, uw, h, d, n, w)
-        ref = oracle.renderer_mesh_vertex_stage_f64(rp, uw, HT[..., 0], DT[..., [0, 2]], NT[..., :3], WT[..., 0])
-        _mesh_checks(got, ref, np.abs(HT[..., 0]).max() / 8)
+        _mesh_checks(oracle, rp, uw, got, (h, d, n, w), want, bounds)
     # corner vertices sample the clamped corner texels: uv = 0 -> texel 0, uv = 1 -> texel M-1
     v = got[0]
     res = rp.resolution
@@ -159,11 +163,11 @@ def test_gpu_rgba_textures_and_mesh_vertex_stage(mw, oracle, resolution):
     for dt in (0.033, 0.3):
         tex = o.generate_texture_rgba(dt)
         want = oracle.renderer_textures_f64(rp, init4, ph, dt)
-        _rgba_checks(tex, want, rp, oracle)
+        bounds = _rgba_checks(tex, want, rp, oracle)
     HT, DT, NT, WT = want
     got = o.displace_mesh()
-    ref = oracle.renderer_mesh_vertex_stage_f64(rp, uw, HT[..., 0], DT[..., [0, 2]], NT[..., :3], WT[..., 0])
-    _mesh_checks(got, ref, np.abs(HT[..., 0]).max() / 8)
+    Ht, Dt, Nt, Wt = tex
+    _mesh_checks(oracle, rp, uw, got, (Ht[..., 0], Dt[..., [0, 2]], Nt[..., :3], Wt[..., 0]), want, bounds)
     rest = o.rest_mesh()[0]
     assert np.abs(got[0][:, [0, 2]] - rest[:, [0, 2]]).max() <= np.abs(DT[..., [0, 2]]).max() / 8 * 1.001
     o.close()
