@@ -40,7 +40,7 @@ BYTES_PASS1 = 16 + 24      # read (P,Q) + write 3 packed complex fields
 BYTES_PASS2 = 24 + 28      # read 3 packed complex fields + write vertex 12 + normal 12 + whitecap 4
 BYTES_POND = 24            # read position 12 + write position 12
 BYTES_RENDERER = 120       # see renderer()
-PROFILE_ROUND = "r02"      # profiles/<round>_<workload>_b<B>_pmc.json carry the counters of THIS build
+PROFILE_ROUND = "r03"      # profiles/<round>_<workload>_b<B>_pmc.json carry the counters of ONE build (its build_id inside)
 
 
 def parse():
@@ -55,10 +55,12 @@ def parse():
                          "timed region starts at steady clocks (the first ~5 ms after idle run ~25 %% slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--latency", action="store_true",
-                    help="also measure one time-step per enqueue (200 single-step enqueues, untimed region); off by default so that "
-                         "the default command launches full batches only and its rocprofv3 per-kernel averages are those of the "
-                         "timed launches")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the frame-at-a-time figures (one time-step per enqueue on device pointers; FFTMesh.Update through host "
+                         "pointers): the rocprofv3 counter passes use it so that every launch of a kernel has the same size")
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "steps"],
+                    help="N > 1: 'tiles' = one independent ocean per rank (BASELINE configs[2], weak scaling); 'steps' = ONE ocean, "
+                         "contiguous blocks of the K time-steps per rank (SURVEY 8e axis 2, strong scaling)")
     ap.add_argument("--tiles", type=int, default=1,
                     help="renderer1024: independent oceans per GenerateTexture() (mw_ocean_create_batch); the phase recurrence "
                          "forbids batching in time, the tile axis is what fills the device")
@@ -84,18 +86,52 @@ def host_cores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
-def pmc_traffic(workload, B, kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/prof_workload.sh ->
-    profiles/<round>_<workload>_b<B>_pmc.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, i.e. with the gfx950 correction the
-    micro-architecture guide prescribes (FETCH_SIZE counts 128-B requests at 64 B).  Counters cannot be read from
-    inside this process, so this is the value measured by the same command under the profiler; None if absent."""
+def pmc_traffic(workload, B, kernel, build_id):
+    """HBM-side bytes per launch of `kernel` (a substring; several kernels: their sum) from the committed rocprofv3 PMC passes
+    (tools/prof_workload.sh -> profiles/<round>_<workload>_b<B>_pmc.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, i.e. with the gfx950
+    correction the micro-architecture guide prescribes (FETCH_SIZE counts 128-B requests at 64 B).  Counters cannot be read from
+    inside this process: this is the value measured by the same command under the profiler -- and it is only quoted when the
+    counter file was taken on THIS build of the library (the bench line stored in it carries mw_build_id())."""
     path = os.path.join(REPO, "profiles", f"{PROFILE_ROUND}_{workload}_b{B}_pmc.json")
+    rel = os.path.relpath(path, REPO)
     try:
-        d = json.load(open(path))["pmc_mean_per_launch"]
-        k = [v for name, v in d.items() if kernel in name][0]
-        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0, f"rocprofv3 --pmc, {os.path.relpath(path, REPO)}"
+        j = json.load(open(path))
     except Exception:
-        return None, f"no committed PMC pass for this workload/batch ({os.path.relpath(path, REPO)})"
+        return None, f"no committed PMC pass for this workload/batch ({rel})"
+    theirs = (j.get("bench_line") or {}).get("build_id")
+    if theirs != build_id:
+        return None, f"{rel} was measured on build {theirs!r}, this run is build {build_id!r}: not quoted"
+    ks = [v for name, v in j["pmc_mean_per_launch"].items() if kernel in name]
+    if not ks or any("FETCH_SIZE" not in k or "WRITE_SIZE" not in k for k in ks):
+        return None, f"{rel} has no FETCH_SIZE / WRITE_SIZE for {kernel}"
+    return sum((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 for k in ks), f"rocprofv3 --pmc, {rel} (same build)"
+
+
+_hip = None
+
+
+def d2h(ptr, shape, dtype=np.float32):
+    """Copy a raw device pointer (an int handed out by the C ABI) into a new host array."""
+    global _hip
+    import ctypes as C
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    out = np.empty(shape, dtype)
+    rc = _hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 2)
+    assert rc == 0, f"hipMemcpy D2H failed ({rc})"
+    return out
+
+
+def batch_plan(K, max_batch):
+    """How K timed steps are enqueued: whole enqueues of B steps (+ one shorter one only when K has no usable divisor).
+    B = the largest divisor of K up to max_batch when that is >= 16 or K itself fits one enqueue, else max_batch."""
+    if K <= max_batch:
+        return K, [K]
+    div = max(d for d in range(1, max_batch + 1) if K % d == 0)
+    B = div if div >= 16 else max_batch
+    sizes = [B] * (K // B) + ([K % B] if K % B else [])
+    return B, sizes
 
 
 def preheat(enqueue, torch, ms):
@@ -214,15 +250,24 @@ def main():
     if a.workload == "renderer1024":
         return renderer(a, mw, torch, dev, stream, barrier, dist, rank, world)
 
+    from mistral_water import parallel as par
+    from mistral_water import _native as nat
     N = {"ocean1024": 1024, "ocean4096": 4096, "ocean2048": 2048, "ocean512": 512, "ocean256": 256}[a.workload]
     NN = N * N
-    p = workloads.fftmesh_params(N)
-    seed = 1 + rank
+    p = workloads.fftmesh_config2(N)      # SURVEY 8d config 2 / 4, literally: amplitude 0.41, choppiness 0.46, wind (14.45, 12)
+    shard_steps = (a.shard == "steps" and world > 1)
+    seed = 1 if shard_steps else par.tile_seed(1, rank)     # --shard steps: every rank holds the SAME ocean
     kw = dict(resolution=N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude,
               choppiness=p.choppiness, gravity=p.gravity)
+    build_id = nat.build_id()
+    # K timed steps: --shard tiles -> every rank runs all K on its own tile (weak); --shard steps -> rank r runs the
+    # contiguous block [lo, hi) of the K steps of the one ocean (strong)
+    lo, hi = par.shard_steps(a.steps, world, rank) if shard_steps else (0, a.steps)
+    k_local = hi - lo
     # MW_BENCH_FORCE_TILES=1 (test hook): the tile API path with a one-rank communicator on a 1-GPU box
-    use_tiles = (world > 1 and not same_device) or os.environ.get("MW_BENCH_FORCE_TILES") == "1"
+    use_tiles = ((world > 1 and not same_device) or os.environ.get("MW_BENCH_FORCE_TILES") == "1") and not shard_steps
     tiles = ocean = None
+    B, sizes = batch_plan(max(k_local, 1), 32)
     if use_tiles:
         # the product's tile API: the LIBRARY owns the RCCL communicator; torch.distributed only carries its 128-byte id
         box = [None]
@@ -240,7 +285,6 @@ def main():
             # Create the tiles in a worker thread with a deadline, agree on the outcome over torch.distributed, and fall
             # back to plain per-rank handles (still one tile per GPU, no collective) if any rank did not make it.
             import threading
-            B = max(1, min(a.batch, 32))
             made = {}
 
             def _make():
@@ -271,7 +315,6 @@ def main():
     if not use_tiles:
         ocean = mw.Ocean(seed=seed, device=local_rank, **kw)
         ocean.set_stream(stream.cuda_stream)
-        B = max(1, min(a.batch, ocean.max_batch))
         dv = torch.empty((B, NN, 3), dtype=torch.float32, device=dev)
         dn = torch.empty((B, NN, 3), dtype=torch.float32, device=dev)
         dw = torch.empty((B, NN), dtype=torch.float32, device=dev)
@@ -287,88 +330,109 @@ def main():
             tiles.synchronize()
         torch.cuda.synchronize()
 
-    # ---- parity gate before any timing (same run, same inputs): rank 0, N = 1 path ---------------------
+    # ---- parity gate before any timing (same run, same inputs), rank 0, on whichever path is timed: the single handle, or
+    # the rank's tile THROUGH the tile API (its spectrum, its output buffers) -------------------------------------------------
     parity, gpu_step, h0 = None, None, None
-    if not a.no_parity and rank == 0 and not use_tiles:
-        h0, h0c = ocean.get_spectrum()
-        ocean.evaluate_device([1.0], dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
-        ocean.synchronize()
+    if not a.no_parity and rank == 0:
+        if use_tiles:
+            h0, h0c = tiles.get_spectrum(0)
+            tiles.evaluate([1.0])
+            tiles.synchronize()
+            pv, pn, pw = tiles.outputs(0)
+            gpu_step = (d2h(pv, (NN, 3)), d2h(pn, (NN, 3)))
+            gw = d2h(pw, (NN,))
+        else:
+            h0, h0c = ocean.get_spectrum()
+            ocean.evaluate_device([1.0], dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+            ocean.synchronize()
+            gpu_step = (dv[0].cpu().numpy(), dn[0].cpu().numpy())
+            gw = dw[0].cpu().numpy()
         vf, nf, cf, hds = O.eval_fft_f64(p, h0, h0c, 1.0, return_hds=True)
-        gpu_step = (dv[0].cpu().numpy(), dn[0].cpu().numpy())
-        workloads.assert_parity(gpu_step[0], gpu_step[1], dw[0].cpu().numpy()[:, None], vf, nf,
+        workloads.assert_parity(gpu_step[0], gpu_step[1], gw[:, None], vf, nf,
                                 cf[:, :1], O.rest_mesh(p)[0], np.abs(hds).max(), tag="bench parity gate")
-        parity = "ok (vs oracle f64, tol workloads.REL_TOL)"
-        del vf, nf, cf, hds
+        parity = "ok (vs oracle f64, tol workloads.REL_TOL" + (", through mw_tiles_*)" if use_tiles else ")")
+        del vf, nf, cf, hds, gw
 
     gathers = [0]
 
-    def run(nsteps, k0, gather=False):
+    def run(sz, k0, gather=False):
+        """Enqueue the batches `sz` (a list of enqueue sizes) starting at time-step index k0."""
         k = k0
-        while k < k0 + nsteps:
-            nb = min(B, k0 + nsteps - k)
-            enqueue([(kk + 1) / 60.0 for kk in range(k, k + nb)])
+        for nb in sz:
+            enqueue(par.step_times(k, k + nb))
             if gather:      # the previous batch's tiles travel on the side stream while this batch computes
                 tiles.gather(step=nb - 1, root=0)
                 gathers[0] += 1
             k += nb
+    warm_sizes = [B] * max(1, -(-a.warmup // B)) if a.warmup > 0 else []     # whole batches, >= W steps
 
     barrier()   # rank 0 may have spent seconds in the parity gate: line the ranks up BEFORE warming the clocks
-    preheat_ms = preheat(lambda: run(B, 0), torch, a.preheat_ms)
-    run(a.warmup, 0)
+    preheat_ms = preheat(lambda: run([B], 0), torch, a.preheat_ms)
+    run(warm_sizes, 0)
     sync()
     barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    run(a.steps, a.warmup)
+    if not use_tiles:
+        ev0.record(stream)
+    run(sizes, lo)
+    if not use_tiles:
+        ev1.record(stream)
+        while not ev1.query():      # spin on the closing event: a blocking synchronize adds its wake-up latency (tens of
+            pass                    # microseconds) to a timed region that is a fraction of a millisecond at the driver's K = 20
     sync()
     el = time.perf_counter() - t0
+    el_events = ev0.elapsed_time(ev1) * 1e-3 if not use_tiles else None      # the same K steps by HIP events on the launch stream
     barrier()
     el_gather = None
     if a.gather and use_tiles:      # the same K steps again, now with the per-batch gather to rank 0 overlapped
-        run(a.warmup, 0, gather=True)
+        run(warm_sizes, 0, gather=True)
         sync()
         barrier()
         t1 = time.perf_counter()
-        run(a.steps, a.warmup, gather=True)
+        run(sizes, lo, gather=True)
         sync()
         el_gather = time.perf_counter() - t1
         barrier()
-    if dist is not None:
-        tt = torch.tensor([el, el_gather or 0.0], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt[0].item())
-        el_gather = float(tt[1].item()) if el_gather is not None else None
+    el = par.max_over_ranks(el, dist, red_dev)                   # the job took as long as its slowest rank
+    if el_gather is not None:
+        el_gather = par.max_over_ranks(el_gather, dist, red_dev)
+    if el_events is not None and dist is not None:
+        el_events = par.max_over_ranks(el_events, dist, red_dev)
 
     # ---- kernel-level timing with HIP events on the launch stream (rank 0) ----------------------------
     prof = tiles_ocean = None
+    import ctypes as C
     if use_tiles:
         # the tile's own mw_ocean handle (borrowed) runs the in-situ profile on the tile's compute stream
         tiles_ocean = mw.Ocean.__new__(mw.Ocean)
-        import ctypes as C
         tiles_ocean._h = C.c_void_p(mw.lib().mw_tiles_ocean(tiles._h, 0))
         prof = tiles_ocean
     else:
         prof = ocean
-    preheat(lambda: run(B, 0), torch, a.preheat_ms)     # the all-reduce above may have let the clocks drop
-    kern = prof.profile_kernels(nsteps=B, iters=100)     # in situ: pass1/pass2 alternate as in the timed loop
+    preheat(lambda: run([B], 0), torch, a.preheat_ms)     # the all-reduce above may have let the clocks drop
+    kern = prof.profile_kernels(nsteps=B, iters=100)       # in situ: pass1/pass2 alternate as in the timed loop, SAME batch size
+    tgroup = int(mw.lib().mw_debug_pass1_time_group(prof._h, B))
     if tiles_ocean is not None:
         tiles_ocean._h = None                            # borrowed: the tiles own it
     k2_ms = kern[1][1]
     roof_ach = BYTES_PASS2 * NN * B / (k2_ms * 1e-3)
-    traffic, traffic_note = pmc_traffic(a.workload, B, "k_pass2")
-    traffic1, _ = pmc_traffic(a.workload, B, "k_pass1")
+    traffic, traffic_note = pmc_traffic(a.workload, B, "k_pass2", build_id)
+    traffic1, _ = pmc_traffic(a.workload, B, "k_pass1", build_id)
     roofline = {"bound": "hbm", "kernel": "k_pass2", "achieved": roof_ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": roof_ach / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
                 "real_frac": (traffic / (k2_ms * 1e-3) / HBM_PEAK) if traffic else None,
                 "physical_bytes_per_point": (traffic / (NN * B)) if traffic else None,
                 "bytes_per_launch": BYTES_PASS2 * NN * B, "algorithmic_bytes_per_point": BYTES_PASS2, "launch_us": k2_ms * 1e3,
+                "steps_per_launch": B,
                 "kernels": [{"name": nm, "us_per_launch": ms * 1e3,
                              "algorithmic_GBps": (BYTES_PASS1 if i == 0 else BYTES_PASS2) * NN * B / (ms * 1e-3) / 1e9,
                              "physical_GBps": (tr / (ms * 1e-3) / 1e9) if tr else None}
                             for i, ((nm, ms), tr) in enumerate(zip(kern, (traffic1, traffic)))]}
 
-    # one step per enqueue (what a frame-at-a-time host sees; the headline value is batched THROUGHPUT): untimed region
-    single_us = None
-    if a.latency and not use_tiles and rank == 0:
+    # ---- the frame-at-a-time path (what FFTMesh.Update, S/FFTMesh.cs:60-73, drives): untimed region, rank 0 ------------
+    frame = None
+    if not a.no_latency and not use_tiles and rank == 0:
         for _ in range(20):
             enqueue([1.0])
         torch.cuda.synchronize()
@@ -377,27 +441,57 @@ def main():
             enqueue([(k + 1) / 60.0])
         torch.cuda.synchronize()
         single_us = (time.perf_counter() - t2) / 200 * 1e6
+        hv, hn, hc = (np.empty((NN, 3), np.float32), np.empty((NN, 3), np.float32), np.empty((NN, 4), np.float32))
 
-    value = world * a.steps * NN / el
+        def host_frames(n):
+            ocean.evaluate_into(1.0, hv, hn, hc)
+            t3 = time.perf_counter()
+            for k in range(n):
+                ocean.evaluate_into((k + 1) / 60.0, hv, hn, hc)
+            return (time.perf_counter() - t3) / n * 1e3
+        reps = 10 if N <= 1024 else 2
+        ms_pageable = host_frames(reps)
+        for arr in (hv, hn, hc):
+            mw.host_register(arr)
+        ms_registered = host_frames(reps)
+        for arr in (hv, hn, hc):
+            mw.host_unregister(arr)
+        frame = {"device_us_per_step": single_us, "device_points_per_s": NN / (single_us * 1e-6),
+                 "device_frac_of_hbm_roofline": NN * BYTES_PER_POINT / (single_us * 1e-6) / HBM_PEAK,
+                 "host_ms_per_frame_pageable": ms_pageable, "host_ms_per_frame_registered": ms_registered,
+                 "what": "one time-step per call: device pointers, 200 calls back to back (mw_ocean_evaluate_device, nsteps = 1); "
+                         "host pointers = mw_ocean_evaluate into Vector3[] / Vector3[] / Color[] arrays (40 B per point over PCIe), "
+                         "pageable and page-locked once with mw_host_register"}
+
+    k_total = a.steps if shard_steps else world * a.steps
+    value = k_total * NN / el
+    per_gpu = value / world
     phys_pt = ((traffic or 0) + (traffic1 or 0)) / (NN * B) if (traffic and traffic1) else None
     out = {
         "metric": BASELINE_METRIC if N == 1024
         else f"ocean grid-points/sec (full spectrum->IFFT->disp->Jacobian), {N}^2 grid",
         "value": value, "unit": "grid-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "preheat_ms": preheat_ms,
-        "config": {"workload": f"FFTMesh-semantics ocean tile {N}x{N}, height+choppy+normals+Jacobian whitecap, "
+        "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard_steps else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "preheat_ms": preheat_ms, "build_id": build_id,
+        "event_ms_per_step": (el_events / a.steps * 1e3) if el_events is not None else None,
+        "config": {"workload": f"SURVEY 8d config {2 if N == 1024 else 4 if N == 4096 else '2 at another N'}, literally: "
+                               f"FFTMesh-semantics ocean {N}x{N}, height+choppy+normals+Jacobian whitecap, "
                                f"unit_width {p.unit_width:g}, length {p.length:g}, wind ({p.wind_x:g}, {p.wind_y:g}), "
-                               f"amplitude {p.amplitude:.3g} (1.5e-8 (1024/N)^2: wave heights O(1 m) at every N; SURVEY 8d's "
-                               f"0.41 saturates normals and whitecap and is a parity case, tests/test_gpu_parity.py), "
-                               f"choppiness {p.choppiness:g}, t_k = k/60 s, one independent tile per GPU (seed = 1 + rank); "
-                               f"throughput of {B} independent time-steps per enqueue, not a per-frame latency",
-                   "grid": N, "steps_per_enqueue": B, "tiles": world, "semantics": "MW_SEM_FFTMESH",
-                   "parallelism": f"tile{world}", "api": "mw_tiles_* (library-owned RCCL communicator)" if use_tiles
+                               f"amplitude {p.amplitude:g}, choppiness {p.choppiness:g}, t_k = k/60 s, "
+                               + ("ONE ocean, the K time-steps sharded over the ranks in contiguous blocks; " if shard_steps
+                                  else "one independent tile per GPU (seed = 1 + rank); ")
+                               + f"the timed region is {len(sizes)} enqueue(s) of {sorted(set(sizes), reverse=True)} time-steps "
+                                 f"(whole batches; a throughput figure -- the per-frame figures are in `frame_at_a_time`)",
+                   "grid": N, "steps_per_enqueue": B, "enqueue_sizes_timed": sizes if len(sizes) <= 4 else [sizes[0], "...", sizes[-1]],
+                   "enqueues_timed": len(sizes), "warmup_steps_run": sum(warm_sizes), "pass1_time_group": tgroup,
+                   "tiles": 1 if shard_steps else world, "semantics": "MW_SEM_FFTMESH",
+                   "parallelism": (f"steps{world}" if shard_steps else f"tile{world}"),
+                   "api": "mw_tiles_* (library-owned RCCL communicator)" if use_tiles
                    else ("mw_ocean_*" + (f" (tile API unavailable: {tiles_note})" if tiles_note else ""))},
-        "single_step_us": single_us,     # one time-step per enqueue, back to back (two launches of 1/32 of the batched grid)
-        "hbm_roofline_frac_whole_step": value / world * BYTES_PER_POINT / HBM_PEAK,
-        "hbm_real_frac_whole_step": (value / world * phys_pt / HBM_PEAK) if phys_pt else None,
+        "frame_at_a_time": frame,
+        "single_step_us": frame["device_us_per_step"] if frame else None,
+        "hbm_roofline_frac_whole_step": per_gpu * BYTES_PER_POINT / HBM_PEAK,
+        "hbm_real_frac_whole_step": (per_gpu * phys_pt / HBM_PEAK) if phys_pt else None,
         "physical_bytes_per_point_whole_step": phys_pt,
         "roofline": roofline,
         "parity": parity,
@@ -468,17 +562,23 @@ def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):
                          f"(+ numpy fft2 for the Stockham blits), {elc:.2f} s per frame; host has {os.cpu_count()} cores"}
     if rank == 0:
         v = world * a.steps * M * M * T / el
+        from mistral_water import _native as nat2
+        build_id = nat2.build_id()
+        traffic, traffic_note = pmc_traffic("renderer1024", T, "k_or_", build_id)     # the frame's three kernels together
         print(json.dumps({
             "metric": "OceanRenderer-semantics texels/sec (dispersion+spectrum -> 2-D Stockham -> normal -> whitecap), 1024^2",
             "value": v, "unit": "texels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "config": {"workload": "OceanRenderer GenerateTexture(), 1024x1024 textures, shipped demo parameters "
+            "data": "synthetic", "build_id": build_id,
+            "config": {"workload": "OceanRenderer GenerateTexture(), 1024x1024 textures, shipped demo parameters "
                                                         "(length 434.48, wind (14.45, 12), amplitude 0.41, choppiness 0.46); "
                                                         f"{T} independent ocean(s) (seed + k) per call, one frame of each per step",
                                             "semantics": "MW_SEM_OCEANRENDERER", "tiles_per_call": T,
                                             "us_per_tile_frame": el / a.steps / T * 1e6},
             "roofline": {"bound": "hbm", "kernel": "whole frame (3 kernels)", "achieved": v * BYTES_RENDERER / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": v * BYTES_RENDERER / HBM_PEAK, "traffic": None}, "cpu_baseline": cpu}))
+                         "unit": "GB/s", "frac": v * BYTES_RENDERER / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_what": f"HBM-side bytes of one call = {T} tile-frame(s), all three kernels",
+                         "physical_bytes_per_texel": (traffic / (M * M * T)) if traffic else None}, "cpu_baseline": cpu}))
     o.close()
 
 
@@ -576,14 +676,17 @@ def pond(a, mw, torch, dev, stream, barrier, dist, rank, world):
                "all_cores": {"value": nv / eln, "unit": "vertices/s", "cores": bestn,
                              "what": f"the same split over host threads; best of {cands} on the {cores}-core host"}}
     if rank == 0:
+        build_id = nat.build_id()
+        traffic, traffic_note = pmc_traffic("pond", B, "k_gerstner", build_id)
         print(json.dumps({
-            "metric": "pond Gerstner vertices/sec (1M vertices, 8 waves)", "value": world * a.steps * nv / el,
+            "metric": "pond Gerstner vertices/sec (1M vertices, 8 waves)", "value": world * a.steps * nv / el, "build_id": build_id,
             "unit": "vertices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "pond: 1000x1000 vertex lattice, 8 Gerstner waves (SURVEY.md 8d config 5), t_k = k/60 s",
                        "steps_per_launch": B},
             "roofline": {"bound": "hbm", "kernel": "k_gerstner_steps<8>" if B > 1 else "k_gerstner",
-                         "achieved": real / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": real / HBM_PEAK, "traffic": None,
+                         "achieved": real / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": real / HBM_PEAK, "traffic": traffic,
+                         "traffic_note": traffic_note, "physical_bytes_per_vertex_step": (traffic / (nv * B)) if traffic else None,
                          "us_per_step": step_us,
                          "note": f"one launch of {B} time values moves 12 B/vertex of positions once and 12 B/vertex per step of "
                                  f"results: (12/{B} + 12) B/vertex/step is what the kernel must and does move"},

@@ -20,6 +20,9 @@ extern "C" {
 mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, const char** names_out,
                                    int32_t* nkernels);
 
+/* time-steps of one pass-1 column job kept on one XCD when an enqueue carries nsteps time-steps (0 = plain grid) */
+int32_t mw_debug_pass1_time_group(mw_ocean* o, int32_t nsteps);
+
 /* ---- test hooks (used by tests/ only; not needed by a host integration) ---------------------------------
  * mw_debug_omega_t: omega(i,j)*t [N*N, idx = i*N + j] exactly as the kernels form it -- the quantised dispersion
  * (S/FFTMesh.cs:146,183) is compared bit for bit with the oracle.  mw_debug_get_omega: the stored table in its

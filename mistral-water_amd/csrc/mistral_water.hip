@@ -656,15 +656,20 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
         default: return fail(MW_EINVAL, "unsupported FFT size"); \
     }
 
+// time-steps of one pass-1 column job issued back to back on one XCD (p1_block_map): the largest divisor of nsteps up to
+// the handle's p1_tgroup (8), any divisor -- a 20-step enqueue groups by 5 --, 0 = plain 2-D grid
+static int p1_time_group(const mw_ocean* o, int nsteps) {
+    for (int g = o->p1_tgroup; g > 1; g--)
+        if (nsteps % g == 0) return g;
+    return 0;
+}
 static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipStream_t st) {
     P1Args A;
     A.PQt = o->PQt; A.dPQ_i0 = o->dPQ_i0; A.dPQ_j0 = o->dPQ_j0; A.Om = o->Om; A.TW = o->TW;
     A.E = o->E; A.Cj0 = o->Cj0;
     A.c = consts_of(o);
     A.nsteps = nsteps;
-    A.tgroup = 0;
-    for (int g = o->p1_tgroup; g > 1; g >>= 1)
-        if (nsteps % g == 0) { A.tgroup = g; break; }
+    A.tgroup = p1_time_group(o, nsteps);
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass1_n<NN>(A, tm, nsteps, st));
     if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pass1 launch: ") + hipGetErrorString(e));
@@ -1339,6 +1344,11 @@ mw_status mw_debug_evaluate_hds(mw_ocean* o, float t, float* vertices_xyz, float
     HIP_TRY(hipMemcpyAsync(hds_xy, dh, NN * sizeof(cf), hipMemcpyDeviceToHost, o->stream));
     HIP_TRY(hipStreamSynchronize(o->stream));
     return MW_OK;
+}
+
+// measurement hook: the pass-1 time group an enqueue of nsteps uses (bench.py prints what it timed)
+int32_t mw_debug_pass1_time_group(mw_ocean* o, int32_t nsteps) {
+    return (o && o->sem == MW_SEM_FFTMESH && o->use_fft && nsteps >= 1 && nsteps <= MW_MAX_BATCH) ? p1_time_group(o, nsteps) : 0;
 }
 
 // test hooks: the stored omega table and the device sincos

@@ -161,6 +161,7 @@ def lib():
         "mw_gerstner_max_steps": (C.c_int32, [C.c_int32]),
         "mw_pond_displace": (C.c_int, [C.POINTER(MwPondParams), f32p, C.c_int64, C.c_float, f32p, f32p, C.c_int32]),
         "mw_pond_displace_device": (C.c_int, [C.POINTER(MwPondParams), vp, C.c_int64, C.c_float, vp, vp, vp]),
+        "mw_debug_pass1_time_group": (C.c_int32, [vp, C.c_int32]),
         "mw_debug_omega_t": (C.c_int, [vp, C.c_float, f32p]),
         "mw_debug_evaluate_hds": (C.c_int, [vp, C.c_float, f32p, f32p, f32p, f32p]),
         "mw_debug_get_omega": (C.c_int, [vp, f32p]),
@@ -194,7 +195,7 @@ ABI_SYMBOLS = [
     "mw_gerstner_displace_device", "mw_gerstner_displace_steps_device", "mw_gerstner_max_steps", "mw_pond_displace", "mw_pond_displace_device",
 ]
 #: measurement and test hooks (include/mistral_water_hooks.h): exported, but not part of the drop-in boundary
-HOOK_SYMBOLS = ["mw_ocean_profile_kernels", "mw_debug_omega_t", "mw_debug_evaluate_hds", "mw_debug_get_omega", "mw_debug_sincos",
+HOOK_SYMBOLS = ["mw_ocean_profile_kernels", "mw_debug_pass1_time_group", "mw_debug_omega_t", "mw_debug_evaluate_hds", "mw_debug_get_omega", "mw_debug_sincos",
                 "mw_debug_sincos_fast", "mw_debug_stream_read"]
 
 

@@ -150,13 +150,18 @@ def _dilate(a):
 ULP = 2.0 ** -24
 
 
-def assert_mesh_stage_alone(mesh_ref, got, N_tex, res, tag=""):
+def _tap_magnitude(tex_mag, M, res):
+    """Largest |height| / |displacement| texel among each vertex's taps: the bilinear taps are float32 sums of those."""
+    return _mesh_sample(_dilate(np.asarray(tex_mag, np.float64)), M, res, reduce=np.maximum)[:, None]
+
+
+def assert_mesh_stage_alone(mesh_ref, got, N_tex, res, tex_mag, tag=""):
     """THE STAGE ALONE: device mesh (v, n, c) vs the oracle's f64 vertex stage evaluated on the DEVICE's own textures
     (mesh_ref): float32 rounding of the bilinear taps, of the /8 and of the normalisation only."""
     (V, Nn, Cc), (v, n, c) = mesh_ref, got
     M = N_tex.shape[0]
     s = np.maximum(np.linalg.norm(_mesh_sample(np.asarray(N_tex, np.float64), M, res), axis=-1), 1e-30)
-    bv = 8 * ULP * (np.abs(V) + 1e-3)
+    bv = 8 * ULP * (np.abs(V) + _tap_magnitude(tex_mag, M, res) / 8.0 + 1e-3)   # rest + lerp(texels) / 8: ulps of the TAPS, not of the sum
     assert (np.abs(v - V) <= bv).all(), f"{tag} mesh vertices (stage): worst ratio {float((np.abs(v - V) / bv).max()):.2f}"
     bn = np.minimum(16 * ULP / s + 4 * ULP, 2.0)
     en = np.abs(n - Nn).max(-1)
@@ -166,13 +171,13 @@ def assert_mesh_stage_alone(mesh_ref, got, N_tex, res, tag=""):
     return float((en / bn).max()), float(np.median(bn))
 
 
-def assert_mesh_end_to_end(mesh_ref, got, N_ref_tex, bn_tex, bw_tex, delta, res, tag=""):
+def assert_mesh_end_to_end(mesh_ref, got, N_ref_tex, bn_tex, bw_tex, delta, res, tex_mag, tag=""):
     """END TO END: device mesh vs the oracle's mesh from the oracle's own textures.  bn_tex / bw_tex: the per-texel bounds of
     the normal / whitecap textures (normal_white_bounds), delta: the absolute error of the height / displacement textures."""
     (V, Nn, Cc), (v, n, c) = mesh_ref, got
     M = N_ref_tex.shape[0]
     s = np.maximum(np.linalg.norm(_mesh_sample(np.asarray(N_ref_tex, np.float64), M, res), axis=-1), 1e-30)
-    bv = delta / 8.0 + 8 * ULP * (np.abs(V) + 1e-3)
+    bv = delta / 8.0 + 8 * ULP * (np.abs(V) + _tap_magnitude(tex_mag, M, res) / 8.0 + 1e-3)
     assert (np.abs(v - V) <= bv).all(), f"{tag} mesh vertices: worst ratio {float((np.abs(v - V) / bv).max()):.2f}"
     tn = _mesh_sample(_dilate(bn_tex), M, res, reduce=np.maximum)
     bn = np.minimum(2.0 * np.sqrt(3.0) * tn / s + 16 * ULP / s + 4 * ULP, 2.0)

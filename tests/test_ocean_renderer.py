@@ -116,9 +116,10 @@ def _mesh_checks(oracle, rp, uw, got, dev_tex, want_tex, bounds):
     (h, d_rb, n, w), (HT, DT, NT, WT), (bn, bw, delta) = dev_tex, want_tex, bounds
     res = rp.resolution
     stage_ref = oracle.renderer_mesh_vertex_stage_f64(rp, uw, h, d_rb, n, w)
-    or_bounds.assert_mesh_stage_alone(stage_ref, got, n, res, tag="mesh")
+    mag = np.maximum(np.abs(h), np.abs(d_rb).max(-1))
+    or_bounds.assert_mesh_stage_alone(stage_ref, got, n, res, mag, tag="mesh")
     ref = oracle.renderer_mesh_vertex_stage_f64(rp, uw, HT[..., 0], DT[..., [0, 2]], NT[..., :3], WT[..., 0])
-    rn, rc, mn, mc = or_bounds.assert_mesh_end_to_end(ref, got, NT[..., :3], bn, bw, delta, res, tag="mesh")
+    rn, rc, mn, mc = or_bounds.assert_mesh_end_to_end(ref, got, NT[..., :3], bn, bw, delta, res, mag, tag="mesh")
     assert mn < 2e-2 and mc < 2e-2, (mn, mc)     # the bounds are not vacuous: the median vertex is held to < 2e-2 (unit normal / [0,1] colour)
 
 

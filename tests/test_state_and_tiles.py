@@ -284,3 +284,198 @@ def test_batched_oceanrenderer_handle_equals_single_handles(mw, oracle):
     with pytest.raises(mw.MistralWaterError) as e:              # FFTMesh batches in time, not in tiles
         mw.Ocean(resolution=64, length=64.0, ntiles=2)
     assert e.value.status == mw.MW_EINVAL
+
+
+def test_normal_length_is_part_of_the_oceanrenderer_checkpoint(mw):
+    """After a length change (S/OceanRenderer.cs:98-109) the normal pass keeps the length of SetParams (:163): a checkpoint
+    restored into a fresh handle created with the CURRENT length resumes bit for bit only with mw_ocean_set_normal_length."""
+    old = shipped()
+    with make_or(mw, old) as a:
+        a.generate_texture(0.1)
+        assert a.normal_length == np.float32(old.length)
+        a.reinit_spectrum(length=83.5)
+        assert a.normal_length == np.float32(old.length)        # not updated by the parameter-change branch
+        a.generate_texture(0.05)
+        h0, h0c, ph, nl = *a.get_spectrum(), a.get_phase(), a.normal_length
+        want = a.generate_texture(0.02)
+    new = dataclasses.replace(old, length=83.5)
+    with make_or(mw, new, seed=99) as b:
+        b.set_spectrum(h0, h0c)
+        b.set_phase(ph)
+        wrong = b.generate_texture(0.02)
+        assert (wrong[0] == want[0]).all() and not (wrong[2] == want[2]).all()   # textures resume, normals do not ...
+        b.set_phase(ph)
+        b.normal_length = nl
+        got = b.generate_texture(0.02)
+    for x, y in zip(got, want):                                  # ... until the third piece of the checkpoint is restored
+        assert (x == y).all()
+    with mw.Ocean(resolution=64, length=64.0) as f:
+        assert f.normal_length == 64.0
+        with pytest.raises(mw.MistralWaterError) as e:
+            f.normal_length = 3.0
+        assert e.value.status == mw.MW_ESTATE
+
+
+def test_handle_can_leave_a_destroyed_caller_stream(mw):
+    """A caller-owned stream that was destroyed (a garbage-collected torch.cuda.Stream) must not trap the handle."""
+    hip = C.CDLL("libamdhip64.so")
+    s = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(s)) == 0
+    p = workloads.fftmesh_params(64)
+    with mw.Ocean(resolution=p.N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude) as o:
+        v0 = o.evaluate(1.0)[0]
+        o.set_stream(s.value)
+        v1 = o.evaluate(1.0)[0]
+        assert hip.hipStreamDestroy(s) == 0
+        o.set_stream(None)                                       # leaves the dead stream: "nothing pending", not MW_EDEVICE
+        v2 = o.evaluate(1.0)[0]
+        assert (v0 == v1).all() and (v0 == v2).all()
+
+
+def test_reinit_spectrum_fftmesh_regenerates_in_place(mw, oracle):
+    p = workloads.fftmesh_params(128)
+    with mw.Ocean(resolution=p.N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude,
+                  choppiness=p.choppiness, seed=3) as o:
+        a = o.evaluate(0.5)
+        o.reinit_spectrum(seed=4)
+        b = o.evaluate(0.5)
+        with mw.Ocean(resolution=p.N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude,
+                      choppiness=p.choppiness, seed=4) as f:
+            c = f.evaluate(0.5)
+            g = f.get_spectrum()
+        assert not (a[0] == b[0]).all()
+        for x, y in zip(b, c):
+            assert (x == y).all()
+        for x, y in zip(o.get_spectrum(), g):
+            assert (x == y).all()
+        with pytest.raises(mw.MistralWaterError) as e:           # would move the grid off the FFT path: refused, handle intact
+            o.reinit_spectrum(length=p.length * 1.01)
+        assert e.value.status == mw.MW_ESTATE
+        for x, y in zip(o.evaluate(0.5), c):
+            assert (x == y).all()
+
+
+@pytest.mark.parametrize("ntiles", [1, 2])
+def test_oceanrenderer_tiles_and_rccl_gather(mw, ntiles):
+    """OceanRenderer semantics behind mw_tiles_* (tile axis only: the phase recurrence F/FFTCommon.cginc:101-104 serialises
+    time): tile k is, bit for bit, the single handle of seed + k, frame after frame, and the gathered buffer carries the four
+    result textures of every tile."""
+    rp = shipped(resolution=16, length=60.0)
+    MM = rp.M * rp.M
+    kw = dict(resolution=rp.resolution, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude, choppiness=rp.choppiness,
+              gravity=rp.gravity, mult=rp.mult, semantics=mw.MW_SEM_OCEANRENDERER)
+    with pytest.raises(mw.MistralWaterError) as e:
+        mw.Tiles(ntiles=1, devices=[0], max_steps=2, seed=5, **kw)             # time does not batch in this semantics
+    assert e.value.status == mw.MW_EINVAL
+    singles = [mw.Ocean(seed=5 + k, **kw) for k in range(ntiles)]
+    with mw.Tiles(ntiles=ntiles, devices=[0] * ntiles, max_steps=1, seed=5, **kw) as t:
+        assert t.count == ntiles and t.N == rp.M
+        with pytest.raises(mw.MistralWaterError) as e:
+            t.gather()                                                          # no frame yet
+        assert e.value.status == mw.MW_ESTATE
+        with pytest.raises(mw.MistralWaterError) as e:
+            t.evaluate([1.0])                                                   # the FFTMesh entry point refuses OceanRenderer tiles
+        assert e.value.status == mw.MW_ESTATE
+        for dt in (0.016, 0.3):
+            t.generate_texture(dt)
+            want = [o.generate_texture(dt) for o in singles]
+        t.gather(root=ntiles - 1)
+        t.synchronize()
+        ptr, fpt = t.gathered()
+        assert ptr and fpt == MM * 7
+        got = _d2h(ptr, ntiles * fpt).reshape(ntiles, fpt)
+        for k in range(ntiles):
+            h, d, n, w = want[k]
+            assert (got[k, :MM] == h.ravel()).all() and (got[k, MM:3 * MM] == d.ravel()).all(), k
+            assert (got[k, 3 * MM:6 * MM] == n.ravel()).all() and (got[k, 6 * MM:] == w.ravel()).all(), k
+            ph, pd, pn, pw = t.textures(k)
+            assert (_d2h(pn, 3 * MM) == n.ravel()).all()
+    for o in singles:
+        o.close()
+
+
+def test_tiles_on_two_devices_restore_the_callers_device(mw):
+    """Real multi-device gather (skipped on the 1-GPU box): one tile per device, root = the second device; every tile equals
+    Ocean(seed + k) bit for bit, and the entry points put the caller's current HIP device back."""
+    if mw.lib().mw_device_count() < 2:
+        pytest.skip("needs two devices")
+    hip = C.CDLL("libamdhip64.so")
+    p = workloads.fftmesh_params(128)
+    NN = 128 * 128
+    kw = dict(resolution=p.N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude,
+              choppiness=p.choppiness)
+    dev = C.c_int(-1)
+    assert hip.hipSetDevice(0) == 0
+    with mw.Tiles(ntiles=2, devices=[0, 1], max_steps=2, seed=11, **kw) as t:
+        t.evaluate([0.5, 1.5])
+        t.gather(step=1, root=1)
+        t.synchronize()
+        assert hip.hipGetDevice(C.byref(dev)) == 0 and dev.value == 0
+        ptr, fpt = t.gathered()
+        assert hip.hipSetDevice(1) == 0
+        got = _d2h(ptr, 2 * fpt).reshape(2, fpt)
+        assert hip.hipSetDevice(0) == 0
+    for k in range(2):
+        with mw.Ocean(seed=11 + k, device=k, **kw) as o:
+            v, n, c = o.evaluate(1.5)
+        assert (got[k, :NN * 3].reshape(NN, 3) == v).all() and (got[k, NN * 6:] == c[:, 0]).all(), k
+
+
+def _run_bench(args, env_extra, nproc=1, timeout=600):
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable]
+    if nproc > 1:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(repo, "bench.py"), "--gpus", str(nproc)] + args
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"exactly ONE JSON line, from rank 0 only: got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def test_bench_two_rank_control_flow_on_one_device():
+    """The N > 1 control flow of bench.py as the driver launches it (torch.distributed.run, 2 processes), on the 1-GPU box:
+    gloo carries barriers / reductions, both ranks drive cuda:0 (an RCCL communicator cannot hold one device twice, so the
+    tile API agrees on its fallback and says so).  Rank 0 alone prints; value is the whole-job aggregate over MAX-of-ranks time."""
+    d = _run_bench(["--steps", "64", "--warmup", "32", "--no-cpu-baseline", "--preheat-ms", "20"],
+                   {"MW_BENCH_BACKEND": "gloo", "MW_BENCH_SAME_DEVICE": "1"}, nproc=2)
+    NN = 1024 * 1024
+    assert d["n_gpus"] == 2 and d["steps"] == 64 and d["scaling"] == "weak" and d["config"]["tiles"] == 2
+    assert d["config"]["steps_per_enqueue"] == 32 and d["config"]["enqueues_timed"] == 2 and d["config"]["pass1_time_group"] == 8
+    assert abs(d["value"] - 2 * 64 * NN / (d["ms_per_step"] * 1e-3 * 64)) < 1e-6 * d["value"]
+    assert d["parity"].startswith("ok") and d["cpu_baseline"] is None
+    assert "amplitude 0.41" in d["config"]["workload"] and d["build_id"]
+    # --shard steps: ONE ocean, the K steps split in contiguous blocks (SURVEY 8e axis 2): strong scaling, K steps in total
+    s = _run_bench(["--steps", "64", "--warmup", "32", "--no-cpu-baseline", "--preheat-ms", "20", "--shard", "steps"],
+                   {"MW_BENCH_BACKEND": "gloo", "MW_BENCH_SAME_DEVICE": "1"}, nproc=2)
+    assert s["n_gpus"] == 2 and s["scaling"] == "strong" and s["config"]["tiles"] == 1 and s["config"]["parallelism"] == "steps2"
+    assert s["config"]["steps_per_enqueue"] == 32 and s["config"]["enqueues_timed"] == 1          # each rank: its 32 of the 64 steps
+    assert abs(s["value"] - 64 * NN / (s["ms_per_step"] * 1e-3 * 64)) < 1e-6 * s["value"]
+
+
+def test_bench_times_what_it_prints_and_gates_the_tile_path():
+    """The driver's command line (--steps 20 --warmup 5): ONE 20-step enqueue, pass-1 time group 5, roofline from 20-step
+    launches, literal config-2 parameters, frame-at-a-time figures present; and the tile-API path keeps the parity gate."""
+    d = _run_bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline"], {})
+    c = d["config"]
+    assert c["steps_per_enqueue"] == 20 and c["enqueues_timed"] == 1 and c["enqueue_sizes_timed"] == [20] and c["pass1_time_group"] == 5
+    assert d["roofline"]["steps_per_launch"] == 20 and d["roofline"]["bytes_per_launch"] == 52 * 1024 * 1024 * 20
+    assert "amplitude 0.41" in c["workload"] and d["parity"].startswith("ok")
+    assert abs(d["event_ms_per_step"] - d["ms_per_step"]) < 0.25 * d["ms_per_step"]
+    f = d["frame_at_a_time"]
+    assert f["device_us_per_step"] > 0 and f["host_ms_per_frame_registered"] <= f["host_ms_per_frame_pageable"] * 1.2
+    assert d["single_step_us"] == f["device_us_per_step"]
+    t = _run_bench(["--steps", "32", "--warmup", "32", "--no-cpu-baseline"], {"MW_BENCH_FORCE_TILES": "1"})
+    assert t["config"]["api"].startswith("mw_tiles_") and "through mw_tiles_" in t["parity"]

@@ -10,6 +10,14 @@ def fftmesh_params(N: int, choppiness: float = 0.46) -> Params:
                   amplitude=1.5e-8 * (1024.0 / N) ** 2, choppiness=choppiness, gravity=9.81)
 
 
+def fftmesh_config2(N: int = 1024) -> Params:
+    """SURVEY.md 8d config 2 (N = 1024) / config 4 (N = 4096), literally: commensurate grid length = N, the shipped OceanRenderer
+    wind, amplitude 0.41 and choppiness 0.46 (D/Ocean Demo.unity:299-302).  FFTMesh semantics does not divide the amplitude by
+    10000 (S/FFTMesh.cs:165), so this sea is hundreds of metres high and its whitecap saturates: it is what bench.py times
+    (the work does not depend on the amplitude) and what test_fftmesh_survey_config2_literal_parameters gates."""
+    return Params(N=N, unit_width=1.0, length=float(N), wind_x=14.45, wind_y=12.0, amplitude=0.41, choppiness=0.46, gravity=9.81)
+
+
 def random_fftmesh_cases(count: int, seed: int, sizes=(64, 128, 256)):
     """Seeded random Inspector settings on commensurate grids: size, unit width, wind, amplitude, choppiness, gravity, time.
     The amplitude is chosen so that wave heights stay O(unit width), i.e. the choppy mesh folds here and there."""
