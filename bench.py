@@ -267,7 +267,7 @@ def main():
     # MW_BENCH_FORCE_TILES=1 (test hook): the tile API path with a one-rank communicator on a 1-GPU box
     use_tiles = ((world > 1 and not same_device) or os.environ.get("MW_BENCH_FORCE_TILES") == "1") and not shard_steps
     tiles = ocean = None
-    B, sizes = batch_plan(max(k_local, 1), 32)
+    B, sizes = batch_plan(max(k_local, 1), max(1, min(a.batch, 32)))
     if use_tiles:
         # the product's tile API: the LIBRARY owns the RCCL communicator; torch.distributed only carries its 128-byte id
         box = [None]
@@ -349,7 +349,7 @@ def main():
             gw = dw[0].cpu().numpy()
         vf, nf, cf, hds = O.eval_fft_f64(p, h0, h0c, 1.0, return_hds=True)
         workloads.assert_parity(gpu_step[0], gpu_step[1], gw[:, None], vf, nf,
-                                cf[:, :1], O.rest_mesh(p)[0], np.abs(hds).max(), tag="bench parity gate")
+                                cf[:, :1], O.rest_mesh(p)[0], np.abs(hds).max(), tag="bench parity gate", hds=hds)
         parity = "ok (vs oracle f64, tol workloads.REL_TOL" + (", through mw_tiles_*)" if use_tiles else ")")
         del vf, nf, cf, hds, gw
 

@@ -347,6 +347,14 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
     // VGPRs) made the kernel 4-11 % slower: removed.
     static_assert(PF == 0 || PF == 1, "prefetch level");
     constexpr bool SPARTS = P2SlopeParts<N, P>::value;
+    // EARLY_SLOPES (experiment, off; profiles/r03_ab_notes.md): the slope field's stored half requested BEFORE the vertex stores
+    // -- gfx950 counts stores in vmcnt, in order with loads -- and parked in x while the Jacobians are formed.  Measured: 4096^2
+    // pass 2 7 % SLOWER (6173 -> 6629 us per 32 steps, 5 spilled dwords), 1024^2 40 % slower (256 VGPRs: one wave per SIMD):
+    // the drain of the stores is not what the slope loads wait for.
+#ifndef MW_EARLY_SLOPES_MIN_N
+#define MW_EARLY_SLOPES_MIN_N 8192
+#endif
+    constexpr bool EARLY_SLOPES = SPARTS && N >= MW_EARLY_SLOPES_MIN_N;
     cf xn[PF ? VT : 1][PF ? P : 1], xn_nyq[PF ? VT : 1], xh_nyq = mk(0.f, 0.f);
     (void)xn; (void)xn_nyq;
 #pragma unroll
@@ -366,8 +374,10 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
                 }
             }
         } else if (f == 2 && SPARTS) {  // the slope half of every virtual thread in flight, then height rows + stage 0 one at a time
+            if constexpr (!EARLY_SLOPES) {
 #pragma unroll
-            MW_VT(h) p2_fetch<N, P, R2, 1>(A, ab, step, MW_VTID(h), f, x[h]);
+                MW_VT(h) p2_fetch<N, P, R2, 1>(A, ab, step, MW_VTID(h), f, x[h]);
+            }
         } else {
 #pragma unroll
             MW_VT(h) p2_fetch<N, P, R2>(A, ab, step, MW_VTID(h), f, x[h]);
@@ -422,6 +432,11 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
         MW_STAMP(1, 7 + 8 * k);
         if (f != 1) continue;
         // ---- displacement done: vertices, halo row, Jacobian ----
+        if constexpr (EARLY_SLOPES) {
+#pragma unroll
+            MW_VT(h) p2_fetch<N, P, R2, 1>(A, ab, step, MW_VTID(h), 2, x[h]);
+            mw_sched_fence();
+        }
 #pragma unroll
         MW_VT(h) p2_vertices<N, P, R2>(A, ab, step, MW_VTID(h), st[h]);
         MW_STAMP(1, 24);
@@ -448,30 +463,31 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
         MW_STAMP(1, 25);
         if (has_halo) {  // group 0 = virtual thread 0 of the lanes below T
             const int u = mw_fresh(tid0) % T;
+            cf xq[P];  // the halo row in registers of its own: the allocator no longer ties it to x[0] (248 -> 219 VGPRs at 1024^2)
             if (g0 == 0) {
                 if constexpr (HALO_EARLY) {
 #pragma unroll
-                    for (int q = 0; q < P; q++) x[0][q] = xh[q];
-                    if (PF >= 1 && u == 0) x[0][0] = x[0][0] + xh_nyq;
+                    for (int q = 0; q < P; q++) xq[q] = xh[q];
+                    if (PF >= 1 && u == 0) xq[0] = xq[0] + xh_nyq;
                 } else {
-                    p2_hs_halo_fetch<N, P, R2>(A, ab, step, u, x[0]);
+                    p2_hs_halo_fetch<N, P, R2>(A, ab, step, u, xq);
                 }
-                stage0_store<N, P, +1>(x[0], u, set0);
+                stage0_store<N, P, +1>(xq, u, set0);
             }
             __syncthreads();
 #pragma unroll
             for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                if (g0 == 0) load_slots<N, P>(x[0], u, set0, s - 1);
+                if (g0 == 0) load_slots<N, P>(xq, u, set0, s - 1);
                 __syncthreads();
-                if (g0 == 0) stage_store<N, P, +1>(x[0], u, set0, tw, s);
+                if (g0 == 0) stage_store<N, P, +1>(xq, u, set0, tw, s);
                 __syncthreads();
             }
             if (g0 == 0) {
-                load_last<N, P>(x[0], u, set0);
-                final_stage<N, P, +1>(x[0], u, tw.TF);
+                load_last<N, P>(xq, u, set0);
+                final_stage<N, P, +1>(xq, u, tw.TF);
             }
             __syncthreads();
-            if (g0 == 0) p2_hs_halo_publish<N, P, R2>(ab, u, x[0], set0);
+            if (g0 == 0) p2_hs_halo_publish<N, P, R2>(ab, u, xq, set0);
             __syncthreads();
         }
         MW_STAMP(1, 26);

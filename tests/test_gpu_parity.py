@@ -92,7 +92,7 @@ def test_fftmesh_survey_config2_literal_parameters(mw, oracle, N):
             v, n, c = o.evaluate(t)
             vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, t, return_hds=True)
             assert np.abs(vf[:, 1]).max() > 50.0     # it really is the saturated regime
-            workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"config literal {N}^2, t={t}")
+            workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"config literal {N}^2, t={t}", hds=hds)
 
 
 @pytest.mark.parametrize("N,u,L", [(64, 1.0, 64.0), (256, 0.5, 128.0), (512, 1.0, 512.0), (1024, 1.0, 1024.0), (2048, 1.0, 2048.0),
