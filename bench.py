@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", default="ocean1024", choices=["ocean1024", "ocean4096", "ocean2048", "ocean512", "ocean256", "pond", "renderer1024"])
+    ap.add_argument("--workload", default="ocean1024", choices=["ocean1024", "ocean4096", "ocean2048", "ocean512", "ocean256", "pond", "renderer1024", "direct"])
+    ap.add_argument("--direct-n", type=int, default=1000,
+                    help="direct: grid size of the non-FFT FFTMesh case (50 = the Inspector default S/FFTMesh.cs:13, 100, 1000)")
     ap.add_argument("--batch", type=int, default=32, help="time-steps per enqueue (FFTMesh steps are independent in t)")
     ap.add_argument("--preheat-ms", type=float, default=150.0,
                     help="untimed: keep the device busy with the workload this long before the W warm-up steps, so the "
@@ -249,6 +251,8 @@ def main():
         return pond(a, mw, torch, dev, stream, barrier, dist, rank, world)
     if a.workload == "renderer1024":
         return renderer(a, mw, torch, dev, stream, barrier, dist, rank, world)
+    if a.workload == "direct":
+        return direct(a, mw, torch, dev, stream, barrier, dist, rank, world)
 
     from mistral_water import parallel as par
     from mistral_water import _native as nat
@@ -516,6 +520,105 @@ def main():
     emit(out if rank == 0 else None)
     if hung:            # a worker thread is still blocked inside the communicator bootstrap: do not wait for it at exit
         os._exit(0)
+
+
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, v_mfma_f32_32x32x2_f32 = the f32 vector rate (MI355X_MICROARCH.md)
+
+
+def direct(a, mw, torch, dev, stream, barrier, dist, rank, world):
+    """FFTMesh grids the FFT cannot express (non-power-of-two N, unit_width != length / N: the reference's
+    shipped scene and its Inspector defaults) through the separable direct sum as matrix products on v_mfma_f32_32x32x2_f32.
+    One step = one EvaluateWaves(t) of an N x N grid; algorithmic work 60 N^3 flop per step (csrc/direct_kernels.h): compute-
+    bound, so the roofline object is against the dense f32 MFMA peak.  N = 50: the Inspector defaults (resolution 50, length 1,
+    unitWidth 1, wind (1,1), amplitude 1); otherwise the config-2 sea on an N-point grid of length N (N not a power of two)."""
+    from oracle import oracle as O
+    import workloads
+    from mistral_water import _native as nat
+    N = a.direct_n
+    if N == 50:
+        p = O.Params(N=50, unit_width=1.0, length=1.0, wind_x=1.0, wind_y=1.0, amplitude=1.0, choppiness=1.0, gravity=9.81)
+    else:
+        p = O.Params(N=N, unit_width=1.0, length=float(N), wind_x=14.45, wind_y=12.0, amplitude=1.5e-8 * (1024.0 / N) ** 2, choppiness=0.46)
+    NN = N * N
+    o = mw.Ocean(resolution=N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude,
+                 choppiness=p.choppiness, gravity=p.gravity, seed=1 + rank, device=dev.index)
+    assert o.max_batch == 1, "this grid is FFT-expressible: not the direct path"
+    o.set_stream(stream.cuda_stream)
+    dv = torch.empty((NN, 3), dtype=torch.float32, device=dev)
+    dn = torch.empty((NN, 3), dtype=torch.float32, device=dev)
+    dw = torch.empty((NN,), dtype=torch.float32, device=dev)
+
+    def step(k):
+        o.evaluate_device([(k + 1) / 60.0], dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+    parity = None
+    h0 = h0c = None
+    if rank == 0 and not a.no_parity:
+        h0, h0c = o.get_spectrum()
+        o.evaluate_device([1.0], dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+        o.synchronize()
+        vd, nd, cd, hds = O.eval_matmul_f64(p, h0, h0c, 1.0, return_hds=True)
+        workloads.assert_parity(dv.cpu().numpy(), dn.cpu().numpy(), dw.cpu().numpy()[:, None], vd, nd, cd[:, :1], O.rest_mesh(p)[0],
+                                rel=2e-5, tag="bench parity gate (direct)", hds=hds)
+        parity = "ok (vs oracle f64 matmul form, rel 2e-5)"
+    barrier()
+    preheat(lambda: [step(k) for k in range(4)], torch, a.preheat_ms)
+    for k in range(a.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(a.warmup + k)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        from mistral_water import parallel as par
+        el = par.max_over_ranks(el, dist, dev if dist.get_backend() == "nccl" else torch.device("cpu"))
+    kern = o.profile_kernels(nsteps=1, iters=50)
+    gemm_ms = kern[0][1]
+    flops = 60.0 * N ** 3
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        if h0 is None:
+            h0, h0c = o.get_spectrum()
+        rng = np.random.default_rng(0)
+        probe = rng.choice(NN, 4, replace=False).astype(np.int32)
+        t1 = time.perf_counter()
+        O.displacement_subset_f32(p, h0, h0c, 1.0, probe)
+        per_vertex = (time.perf_counter() - t1) / probe.size
+        count = int(max(8, min(NN, 12.0 / per_vertex)))
+        idx = np.sort(rng.choice(NN, count, replace=False)).astype(np.int32)
+        t1 = time.perf_counter()
+        O.displacement_subset_f32(p, h0, h0c, 1.0, idx)
+        elc = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        O.eval_matmul_f64(p, h0, h0c, 1.0)
+        elm = time.perf_counter() - t1
+        cpu = {"value": count / elc, "unit": "grid-points/s", "cores": 1, "kind": "port",
+               "sample": f"{count} of {NN} vertices of one {N}x{N} step through the literal O(N^4) FFTMesh.Displacement restatement "
+                         f"(oracle/fftmesh_oracle.c), {elc:.1f} s; host has {os.cpu_count()} cores",
+               "separable_f64_blas": {"value": NN / elm, "unit": "grid-points/s", "cores": host_cores(),
+                                      "what": "the same step as two complex128 matrix products through numpy/BLAS (oracle.eval_matmul_f64), all host cores"}}
+    if rank == 0:
+        v = world * a.steps * NN / el
+        emit({
+            "metric": f"FFTMesh direct-sum grid-points/sec (non-FFT grid, spectrum -> separable sum -> disp -> Jacobian), {N}^2 grid",
+            "value": v, "unit": "grid-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "build_id": nat.build_id(),
+            "config": {"workload": f"FFTMesh-semantics grid {N}x{N}, unit_width {p.unit_width:g}, length {p.length:g}, wind ({p.wind_x:g}, {p.wind_y:g}), "
+                                   f"amplitude {p.amplitude:.3g}, choppiness {p.choppiness:g}: not FFT-expressible, one step per call "
+                                   f"(SURVEY 8f rank 2; N = 50 is the reference's Inspector default, S/FFTMesh.cs:13-19)",
+                       "grid": N, "padded_grid": (N + 63) // 64 * 64, "semantics": "MW_SEM_FFTMESH", "path": "direct sum as 4 MFMA GEMM launches"},
+            "roofline": {"bound": "mfma", "kernel": "k_gemm_f32_mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": flops / (gemm_ms * 1e-3) / MFMA_F32_PEAK, "traffic": None,
+                         "flop_per_launch_group": flops, "algorithmic_flop_per_point": 60.0 * N, "launch_group_us": gemm_ms * 1e3,
+                         "executed_flop_padded": 60.0 * ((N + 63) // 64 * 64) ** 3,
+                         "kernels": [{"name": nm, "us_per_step": ms * 1e3} for nm, ms in kern],
+                         "note": "achieved = 60 N^3 algorithmic flop of one step / the mean duration of that step's four GEMM launches "
+                                 "(HIP events on the launch stream); the GEMMs execute the zero-padded size"},
+            "parity": parity, "cpu_baseline": cpu})
+    o.close()
 
 
 def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):

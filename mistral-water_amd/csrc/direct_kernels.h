@@ -1,34 +1,56 @@
-// direct_kernels.h -- separable direct-sum evaluation of FFTMesh.EvaluateWaves for grids the FFT cannot
-// express: non-power-of-two N, N < 64, or unit_width != length/N (the SHIPPED scene: N=12, unitWidth=1,
-// length=12.39, D/FFT Mesh.unity:147-150).  O(N^3) instead of the reference's O(N^4) by
-//   sum_ij F(i,j) e^{i(kx_i x_a + kz_j z_b)} = sum_i e^{i kx_i x_a} [ sum_j F(i,j) e^{i kz_j z_b} ]
-// (S/FFTMesh.cs:199-217).  Not a throughput path; correctness for the literal drop-in only.
+// direct_kernels.h -- separable direct-sum evaluation of FFTMesh.EvaluateWaves for grids the FFT cannot express:
+// non-power-of-two N, N < 64, or unit_width != length/N -- the SHIPPED scene (N = 12, unitWidth 1, length 12.39,
+// D/FFT Mesh.unity:147-150) and the Inspector defaults (resolution 50, length 1, unitWidth 1, S/FFTMesh.cs:13-19).
+//
+// O(N^3) instead of the reference's O(N^4) by
+//   sum_ij F(i,j) e^{i(kx_i x_a + kz_j z_b)} = sum_i e^{i kx_i x_a} [ sum_j F(i,j) e^{i kz_j z_b} ]        (S/FFTMesh.cs:199-217)
+// and the two sums are dense matrix products -- the one place on this path where the matrix cores apply (80 N^3 flop against
+// O(N^2) bytes).  With E[j][b] = e^{i k_j pos_b} (phase formed in f64, fixed per handle) and the five multiplier spectra F_f:
+//   step 1 (z sum)   T_f = F_f E           complex (N x N)(N x N), as two REAL products with K = 2N:
+//                      Tr_f = [Fr_f | Fi_f] [Er ; -Ei]      Ti_f = [Fr_f | Fi_f] [Ei ; Er]
+//   step 2 (x sum)   only ONE real component of each output is used (:211-218: H = Re, Dx Dz Sx Sz = Im), so it is a real
+//                    product with K = 2N:   Re: [Er^T | -Ei^T] [Tr_f ; Ti_f]      Im: [Ei^T | Er^T] [Tr_f ; Ti_f]
+// = 60 N^3 flop per step on v_mfma_f32_32x32x2_f32 (exact f32: the result is an fmaf chain in k order), instead of five
+// complex accumulators per thread walking global memory.  All operands are zero-padded to Np = a multiple of 64, so the
+// GEMM has no bounds checks and only aligned 16-byte loads.  E and the step-2 left factors are built ONCE per handle
+// (they do not depend on t); per step: the spectrum kernel, 4 GEMM launches, one assembly kernel, the whitecap kernel.
 #pragma once
 #include "fftmesh_kernels.h"
 
 namespace mw {
 
 struct DirectState {
-    cf* spec = nullptr;   // [5][N*N]  H, Dx, Dz, Sx, Sz spectra
-    cf* tmp = nullptr;    // [5][N*N]  after the z-sum, indexed [f][i][b]
-    cf* etab = nullptr;   // [N*N]     e^{i k_j pos_b}, phase formed in double
-    cf* hds = nullptr;    // [N*N]
-    int N = 0;
+    int N = 0, Np = 0;
+    float* A1 = nullptr;     // [5][Np][2Np]   (Fr_f | Fi_f), rebuilt every step
+    float* T = nullptr;      // [5][2Np][Np]   (Tr_f ; Ti_f)
+    float* B1re = nullptr;   // [2Np][Np]      [Er ; -Ei]
+    float* B1im = nullptr;   // [2Np][Np]      [Ei ;  Er]
+    float* A2re = nullptr;   // [Np][2Np]      [Er^T | -Ei^T]
+    float* A2im = nullptr;   // [Np][2Np]      [Ei^T |  Er^T]
+    float* out = nullptr;    // [5][Np][Np]    H, Dx, Dz, Sx, Sz
+    cf* hds = nullptr;       // [N*N]
+    float table_length = -1.f, table_unit_width = -1.f;  // what the E tables were built for
 };
 
 #if defined(__HIPCC__)
-__global__ void k_direct_etab(int N, float length, float unit_width, cf* etab) {
+// e^{i k_j pos_b}, S/FFTMesh.cs:201-208 (phase in f64), scattered into the four fixed GEMM operands
+__global__ void k_direct_tables(int N, int Np, float length, float unit_width, float* B1re, float* B1im, float* A2re, float* A2im) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * N) return;
-    int j = idx / N, b = idx % N;
-    double k = (double)wave_k(N, length, j), pos = (double)rest_coord(N, unit_width, b);
+    const int j = idx / N, b = idx % N;
+    const double k = (double)wave_k(N, length, j), pos = (double)rest_coord(N, unit_width, b);
     double s, c;
     sincos(k * pos, &s, &c);
-    etab[idx] = mk((float)c, (float)s);
+    const float er = (float)c, ei = (float)s;
+    B1re[(size_t)j * Np + b] = er;  B1re[(size_t)(Np + j) * Np + b] = -ei;
+    B1im[(size_t)j * Np + b] = ei;  B1im[(size_t)(Np + j) * Np + b] = er;
+    // step 2 contracts over i with E[i][a]: here (j, b) plays (i, a)
+    A2re[(size_t)b * 2 * Np + j] = er;  A2re[(size_t)b * 2 * Np + Np + j] = -ei;
+    A2im[(size_t)b * 2 * Np + j] = ei;  A2im[(size_t)b * 2 * Np + Np + j] = er;
 }
 
-// S/FFTMesh.cs:178-190 htilde + the five multiplier spectra of :211-215
-__global__ void k_direct_spec(OceanConsts C, const cf* h0, const cf* h0c, float t, cf* spec) {
+// S/FFTMesh.cs:178-190 htilde + the five multiplier spectra of :211-215, written as the left factors of step 1
+__global__ void k_direct_spec(OceanConsts C, int Np, const cf* h0, const cf* h0c, float t, float* A1) {
     const int N = C.N;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * N) return;
@@ -41,41 +63,73 @@ __global__ void k_direct_spec(OceanConsts C, const cf* h0, const cf* h0c, float 
     float kl = sqrtf(kx * kx + kz * kz);
     float ux = 0.f, uzn = 0.f;
     if (!(kl < MW_EPS_F)) { ux = kx / kl; uzn = -kz / kl; }  // :213-215
-    const size_t NN = (size_t)N * N;
-    spec[idx] = h;
-    spec[NN + idx] = cscale(h, ux);
-    spec[2 * NN + idx] = cscale(h, uzn);
-    spec[3 * NN + idx] = cscale(h, kx);
-    spec[4 * NN + idx] = cscale(h, kz);
-}
-
-__global__ void k_direct_zsum(int N, const cf* spec, const cf* etab, cf* tmp) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * N) return;
-    int i = idx / N, b = idx % N;
-    const size_t NN = (size_t)N * N;
-    cf acc[5];
-    for (int f = 0; f < 5; f++) acc[f] = mk(0.f, 0.f);
-    for (int j = 0; j < N; j++) {
-        cf e = etab[(size_t)j * N + b];
-        for (int f = 0; f < 5; f++) acc[f] = acc[f] + cmul(spec[f * NN + (size_t)i * N + j], e);
+    const float mul[5] = {1.f, ux, uzn, kx, kz};
+    const size_t plane = (size_t)Np * 2 * Np, row = (size_t)i * 2 * Np;
+#pragma unroll
+    for (int f = 0; f < 5; f++) {
+        A1[f * plane + row + j] = h.x * mul[f];
+        A1[f * plane + row + Np + j] = h.y * mul[f];
     }
-    for (int f = 0; f < 5; f++) tmp[f * NN + idx] = acc[f];
 }
 
-__global__ void k_direct_xsum(OceanConsts C, const cf* tmp, const cf* etab, cf* hds, float* vertices, float* normals) {
+// C[z] = A[z] B[z]: real f32, row-major, every dimension a multiple of the tile (operands are zero-padded), on
+// v_mfma_f32_32x32x2_f32.  64 x 64 tile per 256-thread workgroup, one 32 x 32 accumulator per wave, K in steps of 16 through
+// LDS with the next step's global loads in flight behind the current step's 8 MFMAs per wave.
+//   A operand of the MFMA: lane l holds A[i = l & 31][k = l >> 5]; B: B[k = l >> 5][j = l & 31];
+//   D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)          (cdna_hip_programming.md section 3)
+// LDS tiles are k-major (As[k][m], Bs[k][n]) so that both operand reads are 32 consecutive dwords per half-wave: conflict-free
+// ds_read_b32.  Row strides: As 66 (the transposing ds_write_b32 of a staged A fragment hits rows 4 q + c: 4 * 66 = 8 mod 32
+// spreads the four q of a 32-lane group over distinct banks), Bs 68 (rows stay 16-byte aligned for the ds_write_b128).
+typedef float f16v __attribute__((ext_vector_type(16)));
+#define MW_GEMM_BM 64
+#define MW_GEMM_BN 64
+#define MW_GEMM_BK 16
+__global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                       int K, int lda, int ldb, int ldc, long long sA, long long sB, long long sC) {
+    constexpr int BM = MW_GEMM_BM, BN = MW_GEMM_BN, BK = MW_GEMM_BK;
+    __shared__ float As[2][BK][BM + 2];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    A += (size_t)blockIdx.z * sA + (size_t)m0 * lda;
+    B += (size_t)blockIdx.z * sB + n0;
+    C += (size_t)blockIdx.z * sC + (size_t)m0 * ldc + n0;
+    // global -> register staging: A tile 64 x 16 (thread: row t / 4, four k), B tile 16 x 64 (thread: k t / 16, four n)
+    const int ar = t >> 2, ak = (t & 3) * 4, bk = t >> 4, bn = (t & 15) * 4;
+    const f4* Ag = reinterpret_cast<const f4*>(A + (size_t)ar * lda + ak);
+    const f4* Bg = reinterpret_cast<const f4*>(B + (size_t)bk * ldb + bn);
+    f4 ra = Ag[0], rb = Bg[0];
+    f16v acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    const int wm = (w >> 1) * 32, wn = (w & 1) * 32, li = lane & 31, lk = lane >> 5;
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        As[buf][ak + 0][ar] = ra.x; As[buf][ak + 1][ar] = ra.y; As[buf][ak + 2][ar] = ra.z; As[buf][ak + 3][ar] = ra.w;
+        *reinterpret_cast<f4*>(&Bs[buf][bk][bn]) = rb;
+        __syncthreads();  // one barrier per step: the other buffer is only rewritten after the NEXT barrier
+        if (kt + 1 < nk) {
+            ra = *reinterpret_cast<const f4*>(reinterpret_cast<const float*>(Ag) + (size_t)(kt + 1) * BK);
+            rb = *reinterpret_cast<const f4*>(reinterpret_cast<const float*>(Bg) + (size_t)(kt + 1) * BK * ldb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][kk + lk][wm + li], Bs[buf][kk + lk][wn + li], acc, 0, 0, 0);
+    }
+    float* Cw = C + (size_t)wm * ldc + wn + li;
+#pragma unroll
+    for (int r = 0; r < 16; r++) Cw[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lk) * ldc] = acc[r];
+}
+
+// vertices / normals / hds from the five real output planes (S/FFTMesh.cs:218, 243-247)
+__global__ void k_direct_assemble(OceanConsts C, int Np, const float* out, cf* hds, float* vertices, float* normals) {
     const int N = C.N;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * N) return;
     int a = idx / N, b = idx % N;
-    const size_t NN = (size_t)N * N;
-    cf acc[5];
-    for (int f = 0; f < 5; f++) acc[f] = mk(0.f, 0.f);
-    for (int i = 0; i < N; i++) {
-        cf e = etab[(size_t)i * N + a];
-        for (int f = 0; f < 5; f++) acc[f] = acc[f] + cmul(tmp[f * NN + (size_t)i * N + b], e);
-    }
-    const float h = acc[0].x, dx = acc[1].y, dz = acc[2].y, sx = acc[3].y, sz = acc[4].y;
+    const size_t plane = (size_t)Np * Np, o = (size_t)a * Np + b;
+    const float h = out[o], dx = out[plane + o], dz = out[2 * plane + o], sx = out[3 * plane + o], sz = out[4 * plane + o];
     const float mag = sqrtf(sx * sx + 1.0f + sz * sz);  // up - n, S/FFTMesh.cs:218
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (mag > 1e-5f) { nx = sx / mag; ny = 1.0f / mag; nz = sz / mag; }
@@ -97,27 +151,58 @@ __global__ void k_direct_white(int N, const cf* hds, const float* normals, float
     else { white[4 * idx] = xx; white[4 * idx + 1] = xx; white[4 * idx + 2] = xx; white[4 * idx + 3] = xx; }
 }
 
-static inline int direct_alloc(DirectState& d, int N) {
+static inline void direct_free(DirectState& d) {
+    hipFree(d.A1); hipFree(d.T); hipFree(d.B1re); hipFree(d.B1im); hipFree(d.A2re); hipFree(d.A2im); hipFree(d.out); hipFree(d.hds);
+    d = DirectState();
+}
+static inline int direct_alloc(DirectState& d, int N, hipStream_t st) {
     d.N = N;
-    const size_t NN = (size_t)N * N;
-    if (hipMalloc((void**)&d.spec, sizeof(cf) * 5 * NN) != hipSuccess) return 4;
-    if (hipMalloc((void**)&d.tmp, sizeof(cf) * 5 * NN) != hipSuccess) return 4;
-    if (hipMalloc((void**)&d.etab, sizeof(cf) * NN) != hipSuccess) return 4;
-    if (hipMalloc((void**)&d.hds, sizeof(cf) * NN) != hipSuccess) return 4;
+    d.Np = (N + 63) / 64 * 64;
+    const size_t P2 = (size_t)d.Np * d.Np;
+    struct { float** p; size_t n; } bufs[] = {{&d.A1, 10 * P2}, {&d.T, 10 * P2}, {&d.B1re, 2 * P2}, {&d.B1im, 2 * P2},
+                                              {&d.A2re, 2 * P2}, {&d.A2im, 2 * P2}, {&d.out, 5 * P2}};
+    for (auto& b : bufs) {
+        if (hipMalloc((void**)b.p, sizeof(float) * b.n) != hipSuccess) { direct_free(d); return 4; }
+        // the zero padding, ordered on the handle's stream: the table / spectrum kernels that fill the live part run there later
+        // (a null-stream hipMemset is not ordered with a non-blocking stream)
+        if (hipMemsetAsync(*b.p, 0, sizeof(float) * b.n, st) != hipSuccess) { direct_free(d); return 4; }
+    }
+    if (hipMalloc((void**)&d.hds, sizeof(cf) * (size_t)N * N) != hipSuccess) { direct_free(d); return 4; }
+    d.N = N;
     return 0;
 }
-static inline void direct_free(DirectState& d) {
-    hipFree(d.spec); hipFree(d.tmp); hipFree(d.etab); hipFree(d.hds);
-    d.spec = d.tmp = d.etab = d.hds = nullptr;
+// flop of one step as the GEMMs execute it (padded), and algorithmically (60 N^3)
+static inline double direct_flops_padded(const DirectState& d) { return 60.0 * (double)d.Np * d.Np * d.Np; }
+
+static inline hipError_t direct_gemm(const float* A, const float* B, float* C, int M, int Nc, int K, int lda, int ldb, int ldc,
+                                     long long sA, long long sB, long long sC, int batch, hipStream_t st) {
+    k_gemm_f32_mfma<<<dim3(Nc / MW_GEMM_BN, M / MW_GEMM_BM, batch), dim3(256), 0, st>>>(A, B, C, K, lda, ldb, ldc, sA, sB, sC);
+    return hipGetLastError();
 }
+
+// ev (measurement hook, mw_ocean_profile_kernels): three events recorded before the spectrum kernel, before and after the GEMMs
 static inline hipError_t direct_evaluate(DirectState& d, OceanConsts C, const cf* h0, const cf* h0c, float t, float* dv,
-                                         float* dn, float* dw, int white_stride, hipStream_t st) {
-    const int N = C.N;
+                                         float* dn, float* dw, int white_stride, hipStream_t st, hipEvent_t* ev = nullptr) {
+    const int N = C.N, Np = d.Np;
     const unsigned nb = (unsigned)(((size_t)N * N + 127) / 128);
-    hipLaunchKernelGGL(k_direct_etab, dim3(nb), dim3(128), 0, st, N, C.length, C.unit_width, d.etab);
-    hipLaunchKernelGGL(k_direct_spec, dim3(nb), dim3(128), 0, st, C, h0, h0c, t, d.spec);
-    hipLaunchKernelGGL(k_direct_zsum, dim3(nb), dim3(128), 0, st, N, d.spec, d.etab, d.tmp);
-    hipLaunchKernelGGL(k_direct_xsum, dim3(nb), dim3(128), 0, st, C, d.tmp, d.etab, d.hds, dv, dn);
+    const long long P2 = (long long)Np * Np;
+    if (d.table_length != C.length || d.table_unit_width != C.unit_width) {  // E does not depend on t: once per handle / length
+        hipLaunchKernelGGL(k_direct_tables, dim3(nb), dim3(128), 0, st, N, Np, C.length, C.unit_width, d.B1re, d.B1im, d.A2re, d.A2im);
+        d.table_length = C.length;
+        d.table_unit_width = C.unit_width;
+    }
+    if (ev) hipEventRecord(ev[0], st);
+    hipLaunchKernelGGL(k_direct_spec, dim3(nb), dim3(128), 0, st, C, Np, h0, h0c, t, d.A1);
+    if (ev) hipEventRecord(ev[1], st);
+    hipError_t e;
+    // step 1: Tr_f = A1_f B1re, Ti_f = A1_f B1im   (5 fields per launch; T_f = [Tr_f ; Ti_f])
+    if ((e = direct_gemm(d.A1, d.B1re, d.T, Np, Np, 2 * Np, 2 * Np, Np, Np, 2 * P2, 0, 2 * P2, 5, st)) != hipSuccess) return e;
+    if ((e = direct_gemm(d.A1, d.B1im, d.T + P2, Np, Np, 2 * Np, 2 * Np, Np, Np, 2 * P2, 0, 2 * P2, 5, st)) != hipSuccess) return e;
+    // step 2: H = A2re T_0;  Dx, Dz, Sx, Sz = A2im T_1..4
+    if ((e = direct_gemm(d.A2re, d.T, d.out, Np, Np, 2 * Np, 2 * Np, Np, Np, 0, 0, 0, 1, st)) != hipSuccess) return e;
+    if ((e = direct_gemm(d.A2im, d.T + 2 * P2, d.out + P2, Np, Np, 2 * Np, 2 * Np, Np, Np, 0, 2 * P2, P2, 4, st)) != hipSuccess) return e;
+    if (ev) hipEventRecord(ev[2], st);
+    hipLaunchKernelGGL(k_direct_assemble, dim3(nb), dim3(128), 0, st, C, Np, d.out, d.hds, dv, dn);
     hipLaunchKernelGGL(k_direct_white, dim3(nb), dim3(128), 0, st, N, d.hds, dn, dw, white_stride);
     return hipGetLastError();
 }

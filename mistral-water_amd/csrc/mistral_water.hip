@@ -862,7 +862,7 @@ static mw_status ocean_create_impl(const mw_params* params, int tiles, mw_ocean*
                 mw_ocean_destroy(o); return s;
             }
         } else {
-            if (direct_alloc(o->direct, N) != 0) { mw_ocean_destroy(o); return fail(MW_ENOMEM, "direct path alloc failed"); }
+            if (direct_alloc(o->direct, N, o->stream) != 0) { mw_ocean_destroy(o); return fail(MW_ENOMEM, "direct path alloc failed"); }
         }
         hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, o->stream, N, params->length,
                            params->wind_x, params->wind_y, params->amplitude, params->gravity, params->seed, o->h0, o->h0c);
@@ -1254,10 +1254,36 @@ mw_status mw_ocean_displace_mesh(mw_ocean* o, float* vertices_xyz, float* normal
 mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, const char** names_out,
                                    int32_t* nkernels) {
     if (!o || !ms_out || !nkernels || iters < 1) return fail(MW_EINVAL, "mw_ocean_profile_kernels: bad argument");
-    if (o->sem != MW_SEM_FFTMESH || !o->use_fft) return fail(MW_ESTATE, "mw_ocean_profile_kernels: FFT path only");
+    if (o->sem != MW_SEM_FFTMESH) return fail(MW_ESTATE, "mw_ocean_profile_kernels: FFTMesh semantics only");
     if (nsteps < 1 || nsteps > MW_MAX_BATCH) return fail(MW_EINVAL, "nsteps out of range");
     HIP_TRY(hipSetDevice(o->device));
     HIP_TRY(hipStreamSynchronize(o->stream));
+    if (!o->use_fft) {  // direct-sum path: kernel 0 = the four GEMM launches of one step, kernel 1 = spectrum + assembly + whitecap
+        if (nsteps != 1) return fail(MW_EINVAL, "mw_ocean_profile_kernels: the direct-sum path evaluates one step per enqueue");
+        static const char* dnames[2] = {"k_gemm_f32_mfma (4 launches: z sum, x sum)", "k_direct_spec + k_direct_assemble + k_direct_white"};
+        hipEvent_t ev[4];
+        for (auto& e : ev) hipEventCreate(&e);
+        hipError_t he = hipSuccess;
+        for (int w = 0; w < 5 && he == hipSuccess; w++)
+            he = direct_evaluate(o->direct, consts_of(o), o->h0, o->h0c, 1.0f, o->s_vert, o->s_norm, o->s_white, 1, o->stream);
+        double acc[2] = {0.0, 0.0};
+        for (int it = 0; it < iters && he == hipSuccess; it++) {
+            he = direct_evaluate(o->direct, consts_of(o), o->h0, o->h0c, 1.0f + (float)it / 60.f, o->s_vert, o->s_norm, o->s_white, 1, o->stream, ev);
+            hipEventRecord(ev[3], o->stream);
+            hipEventSynchronize(ev[3]);
+            float a = 0.f, g = 0.f, b = 0.f;
+            hipEventElapsedTime(&a, ev[0], ev[1]);
+            hipEventElapsedTime(&g, ev[1], ev[2]);
+            hipEventElapsedTime(&b, ev[2], ev[3]);
+            acc[0] += g;
+            acc[1] += a + b;
+        }
+        for (auto& e : ev) hipEventDestroy(e);
+        if (he != hipSuccess) return fail(MW_EDEVICE, std::string("direct-sum profile: ") + hipGetErrorString(he));
+        for (int k = 0; k < 2; k++) { ms_out[k] = (float)(acc[k] / iters); if (names_out) names_out[k] = dnames[k]; }
+        *nkernels = 2;
+        return MW_OK;
+    }
     mw_status s = ensure_exchange(o, nsteps);
     if (s != MW_OK) return s;
     const size_t NN = (size_t)o->N * o->N;

@@ -179,6 +179,25 @@ def transform_fft_f64(p: Params, fields):
     return y * post[None, :, None] * post[None, None, :]
 
 
+def transform_matmul_f64(p: Params, fields):
+    """The reference's direct sum  sum_ij F(i,j) e^{i(kx_i x_a + kz_j z_b)}  (S/FFTMesh.cs:199-217) for ANY grid (odd N, N not a
+    power of two, unit_width != length / N) as two dense products in complex128: E^T (F E) with E[j][b] = e^{i k_j pos_b},
+    k_j = 2 pi (j - N/2) / length (:201,204), pos_b the rest coordinate of grid line b (:107-112).  The same arithmetic as
+    orc_transform_direct_f64, through BLAS: the checker for large non-FFT grids (N = 1000 in seconds instead of minutes)."""
+    N = p.N
+    j = np.arange(N, dtype=np.float64)
+    k = 2.0 * np.pi * (j - N / 2.0) / float(np.float32(p.length))
+    pos = (j - N // 2) * float(np.float32(p.unit_width)) + (float(np.float32(p.unit_width)) / 2.0 if N % 2 == 0 else 0.0)
+    E = np.exp(1j * np.outer(k, pos))
+    return np.stack([E.T @ (f @ E) for f in fields])
+
+
+def eval_matmul_f64(p: Params, h0, h0c, t: float, return_hds: bool = False):
+    """f64 evaluation of any grid through transform_matmul_f64 (checked against orc_eval_f64 in tests/test_oracle.py)."""
+    v, n, c, hds = assemble_f64(p, transform_matmul_f64(p, htilde_fields_f64(p, h0, h0c, t)))
+    return (v, n, c, hds) if return_hds else (v, n, c)
+
+
 def eval_fft_f64(p: Params, h0, h0c, t: float, return_hds: bool = False):
     """f64 evaluation with numpy's FFT (commensurate grids only) -- the large-N checker."""
     spatial = transform_fft_f64(p, htilde_fields_f64(p, h0, h0c, t))

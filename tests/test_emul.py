@@ -206,7 +206,8 @@ def test_gerstner_vs_oracle(emul, oracle):
     assert np.abs(want - np.stack([ox, oy, oz], 1)).max() < 1e-6
 
 
-@pytest.mark.parametrize("gx,nsteps,tgroup", [(257, 32, 8), (257, 8, 4), (17, 4, 2), (65, 16, 8), (1025, 2, 2)])
+@pytest.mark.parametrize("gx,nsteps,tgroup", [(257, 32, 8), (257, 8, 4), (17, 4, 2), (65, 16, 8), (1025, 2, 2),
+                                              (257, 20, 5), (257, 21, 7), (129, 18, 6), (17, 9, 3), (1025, 25, 5)])
 def test_pass1_time_group_block_map_is_a_bijection(emul, gx, nsteps, tgroup):
     blocks = emul.p1_block_map(gx, nsteps, tgroup)
     live = [b for b in blocks if b is not None]

@@ -366,6 +366,57 @@ def test_direct_path_other_grids(mw, oracle, N):
     workloads.assert_parity(v, n, c, vd, nd, cd, rest, rel=4e-5, tag=f"direct N={N}")
 
 
+def test_direct_path_inspector_defaults(mw, oracle):
+    """S/FFTMesh.cs:13-19: a fresh FFTMesh component has resolution 50, length 1, unitWidth 1, wind (1, 1), amplitude 1 -- not
+    commensurate (50 * 1 != 1): the MFMA direct-sum path.  mw_params_default carries exactly these values."""
+    import ctypes as C
+    from mistral_water import _native
+    d = _native.MwParams()
+    mw.lib().mw_params_default(C.byref(d), mw.MW_SEM_FFTMESH)
+    p = oracle.Params(N=d.resolution, unit_width=d.unit_width, length=d.length, wind_x=d.wind_x, wind_y=d.wind_y, amplitude=d.amplitude,
+                      choppiness=d.choppiness, gravity=d.gravity)
+    assert (p.N, p.length, p.unit_width) == (50, 1.0, 1.0)
+    h0, h0c = oracle.generate_spectrum(p, 1)
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        assert o.max_batch == 1                                   # direct path: one step per enqueue
+        g0, g0c = o.get_spectrum()
+        sc = np.abs(h0).max()
+        assert np.abs(g0 - h0).max() < 4e-6 * sc
+        o.set_spectrum(h0, h0c)
+        # On this grid (k up to 157 rad/m on positions up to 25 m) a phase k.x reaches ~3900 rad: the float32 k of the reference
+        # (S/FFTMesh.cs:201, PI = 3.1415926536f) and its float32 dot product (:206) are off by ~2^-24 * 3900 = 2e-4 rad per term.
+        # Measured distances (float32 restatement of csrc/direct_kernels.h, relative to max |displacement|): device to the f64
+        # oracle (exact pi, f64 k) 1.4-3.3e-5, device to the literal float32 loop 4-9e-5, literal to f64 4-9e-5.  Stated
+        # tolerance: 2e-4 against the f64 oracle, 3e-4 against the literal loop (as test_fftmesh_1024_vs_literal_f32_sample).
+        for t in (0.0, 1.0 / 60.0, 7.5):
+            v, n, c = o.evaluate(t)
+            vd, nd, cd, hds = oracle.eval_matmul_f64(p, h0, h0c, t, return_hds=True)
+            workloads.assert_parity(v, n, c, vd, nd, cd, rest, rel=2e-4, tag=f"Inspector defaults t={t}", hds=hds)
+            vl, nl, cl = oracle.eval_literal_f32(p, h0, h0c, t)
+            sc = max(float(np.abs(vd - rest).max()), 1e-30)
+            assert np.abs(v - vl).max() < 3e-4 * sc and np.abs(n - nl).max() < 3e-4, (t, np.abs(v - vl).max() / sc, np.abs(n - nl).max())
+
+
+@pytest.mark.parametrize("N,u,L", [(1000, 1.0, 1000.0), (200, 1.0, 212.5), (65, 0.5, 40.0)])
+def test_direct_path_large_and_odd_grids(mw, oracle, N, u, L):
+    """Grids the FFT cannot express, through the GEMM form of the separable sum (zero-padded to multiples of 64): N = 1000 (not
+    a power of two), a non-commensurate even grid, an odd grid one past a tile edge.  Checker: oracle.eval_matmul_f64."""
+    p = oracle.Params(N=N, unit_width=u, length=L, wind_x=14.45, wind_y=12.0, amplitude=1.5e-8 * (1024.0 / N) ** 2 * (L / N) ** 2, choppiness=0.46)
+    h0, h0c = oracle.generate_spectrum(p, 4)
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        for t in (0.5, 16.0):
+            v, n, c = o.evaluate(t)
+            vd, nd, cd, hds = oracle.eval_matmul_f64(p, h0, h0c, t, return_hds=True)
+            # a float32 sum of 2N terms per output (an fmaf chain in k order on the matrix cores): ~sqrt(2N) * 2^-24 relative
+            workloads.assert_parity(v, n, c, vd, nd, cd, rest, rel=2e-5, tag=f"direct N={N} t={t}", hds=hds)
+        v2, n2, c2 = o.evaluate(0.5)                              # the fixed tables are reused, the result is reproducible
+        v1, n1, c1 = o.evaluate(0.5)
+        assert (v1 == v2).all() and (c1 == c2).all()
+
+
 def test_golden_fixture_n16(mw):
     import os
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fftmesh_n16_t1p5.npz"))

@@ -223,3 +223,16 @@ def test_cpu_fft_baseline_matches_oracle(oracle, N, threads):
     assert (v1 == v).all() and (n1 == n).all() and (c1 == c).all()
     with pytest.raises(ValueError):
         oracle.cpu_fft_step_f32(workloads.shipped_fftmesh_scene(), *oracle.generate_spectrum(workloads.shipped_fftmesh_scene(), 1), 1.0)
+
+
+@pytest.mark.parametrize("N,u,L", [(12, 1.0, 12.39), (33, 0.9, 33.0), (50, 1.0, 1.0), (64, 1.0, 64.0)])
+def test_matmul_form_equals_the_direct_f64_sum(oracle, N, u, L):
+    """oracle.eval_matmul_f64 (BLAS form of S/FFTMesh.cs:199-217 for any grid: the checker of the large non-FFT cases) against
+    orc_eval_f64, the statement-by-statement f64 restatement: the shipped scene, an odd grid, the Inspector defaults
+    (S/FFTMesh.cs:13-19: resolution 50, length 1, unitWidth 1) and a commensurate grid."""
+    p = oracle.Params(N=N, unit_width=u, length=L, wind_x=1.0, wind_y=1.0, amplitude=1.0 if L == 1.0 else 1e-3, choppiness=1.0)
+    h0, h0c = oracle.generate_spectrum(p, 9)
+    a = oracle.eval_f64(p, h0, h0c, 1.25)
+    b = oracle.eval_matmul_f64(p, h0, h0c, 1.25)
+    for x, y in zip(a, b):
+        assert np.abs(x - y).max() <= 1e-11 * max(1.0, float(np.abs(x).max()))

@@ -93,11 +93,15 @@ def assert_parity(v, n, w, vf, nf, cf, rest, hds_max=None, rel=REL_TOL, tag="", 
     dn = np.abs(n - nf).max(-1)
     assert (dn <= bn).all(), (f"{tag} normals: {int((dn > bn).sum())} vertices above their bound, worst ratio "
                               f"{float((dn / bn).max()):.2f} (slope scale {smax:.3g})")
-    wv = w[..., 0] if w.ndim == cf.ndim and w.shape[-1] != cf.shape[-1] else w
-    cfv = cf[..., 0] if cf.shape != wv.shape else cf
+    # whitecap: a scalar per vertex however it is packed ([NN], [NN, 1] or a Unity Color [NN, 4] of four equal channels).  Both sides
+    # are reduced to ONE dimension before anything is compared: an [NN, 1] array against an [NN] bound would broadcast to NN x NN.
+    wv = np.asarray(w).reshape(len(w), -1)[:, 0]
+    cfv = np.asarray(cf).reshape(len(cf), -1)[:, 0]
+    assert wv.shape == cfv.shape == (len(vf),), (wv.shape, cfv.shape)
     dw = np.abs(wv - cfv)
     if hds is not None:
         bw = whitecap_bounds(hds, rel, bn)
+        assert bw.shape == dw.shape
         assert (dw <= bw).all(), (f"{tag} whitecap: {int((dw > bw).sum())} vertices above their bound, worst ratio "
                                   f"{float((dw / bw).max()):.2f}; {100.0 * float((bw < 1e-2).mean()):.1f} % of the vertices are held below 1e-2")
         return
