@@ -662,7 +662,7 @@ MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int 
             const float sg = post_sign(a, b);
             const float sx = sg * x[q].x, sz = sg * x[q].y;
             // Vector3.Normalize(up - n): |(sx,1,sz)| >= 1, so Unity's 1e-5 zero-guard never fires
-            const float inv = mw_rsqrt(sx * sx + 1.0f + sz * sz);
+            const float inv = mw_rsqrt(__builtin_fmaf(sz, sz, __builtin_fmaf(sx, sx, 1.0f)));  // FMAs written out: the same bits in every instantiation
             const float nx = sx * inv, ny = inv, nz = sz * inv;
             mw_store_stream<mw_nt_results(N)>(&nq[noff + 0], nx);
             mw_store_stream<mw_nt_results(N)>(&nq[noff + 1], ny);
@@ -856,7 +856,7 @@ MW_HD void p2_hs_finish_slopes(const P2Args& A, const Twiddles& tw, int ab, int 
         float* nq = nblk + (size_t)T * q * 3;
         const float sg = post_sign(a, b);
         const float sx = sg * x[q].x, sz = sg * x[q].y;
-        const float inv = mw_rsqrt(sx * sx + 1.0f + sz * sz);
+        const float inv = mw_rsqrt(__builtin_fmaf(sz, sz, __builtin_fmaf(sx, sx, 1.0f)));  // FMAs written out: the same bits in every instantiation
         const float nx = sx * inv, ny = inv, nz = sz * inv;
         mw_store_stream<mw_nt_results(N)>(&nq[noff + 0], nx);
         mw_store_stream<mw_nt_results(N)>(&nq[noff + 1], ny);

@@ -639,6 +639,9 @@ static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nstep
         k_pass1<N, P, VT><<<dim3(GX, nsteps), dim3(NT), LB, st>>>(A, tm);
     return hipGetLastError();
 }
+#ifndef MW_LATENCY_PLAN
+#define MW_LATENCY_PLAN 1
+#endif
 template <int N, bool DUMP>
 static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     constexpr int P = Plan<N>::P2, R2 = Plan<N>::R2;
@@ -652,6 +655,19 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
         else fn = reinterpret_cast<const void*>(&k_pass2<N, P, R2, DUMP>);
         hipError_t e = attr.set(fn, LB);
         if (e != hipSuccess) return e;
+    }
+    // Frame-at-a-time plan (FFTMesh.Update, S/FFTMesh.cs:60-73: ONE step per call): 256 row blocks of two fat waves leave half
+    // of the device's 1024 SIMDs without a wave.  The same kernel with one virtual thread per lane (VT = 1: one wave per row,
+    // four waves per workgroup) puts a wave on every SIMD; the arithmetic of a row does not depend on the lane mapping, so the
+    // results are the bit patterns of the batched plan.
+    if constexpr (HS && N == 1024 && VT == 2 && !DUMP && MW_LATENCY_PLAN) {
+        if (nsteps == 1) {
+            static AttrOnce attr1;
+            hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, 1, false, 0>), LB);
+            if (e != hipSuccess) return e;
+            k_pass2_hs<N, P, R2, 1, false, 0><<<dim3(N / R2, 1), dim3(P2Geom<N, P, R2, true>::NTHREADS), LB, st>>>(A);
+            return hipGetLastError();
+        }
     }
     if constexpr (HS)
         k_pass2_hs<N, P, R2, VT, DUMP, PF><<<dim3(N / R2, nsteps), dim3(NT), LB, st>>>(A);

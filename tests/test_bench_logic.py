@@ -1,0 +1,56 @@
+"""CPU tier: the parts of bench.py that decide WHAT is timed and WHICH counter file may be quoted -- no GPU needed.
+
+VERDICT r2 item 2: the timed region is whole batches and the line prints the real enqueue sizes; a rocprofv3 counter summary
+is quoted as `roofline.traffic` only next to numbers of the build it was measured on."""
+import json
+import os
+
+import pytest
+
+import bench
+
+
+@pytest.mark.parametrize("K,maxb,B,sizes", [
+    (20, 32, 20, [20]),                    # the driver's command line: ONE 20-step enqueue
+    (32, 32, 32, [32]),
+    (640, 32, 32, [32] * 20),
+    (4000, 32, 32, [32] * 125),            # bench.py's default
+    (1000, 32, 25, [25] * 40),             # largest divisor <= 32 (>= 16): whole batches, no remainder
+    (100, 32, 25, [25] * 4),
+    (101, 32, 32, [32, 32, 32, 5]),        # prime: full batches + one shorter enqueue, printed as such
+    (7, 32, 7, [7]),
+    (64, 20, 16, [16] * 4),                # --batch 20
+    (1, 32, 1, [1]),
+])
+def test_batch_plan_times_exactly_k_steps_in_whole_batches(K, maxb, B, sizes):
+    b, s = bench.batch_plan(K, maxb)
+    assert (b, s) == (B, sizes)
+    assert sum(s) == K and max(s) <= maxb
+
+
+def test_counter_file_is_only_quoted_for_the_build_it_was_measured_on(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    path = tmp_path / "profiles" / f"{bench.PROFILE_ROUND}_ocean1024_b32_pmc.json"
+    rec = {"bench_line": {"build_id": "0123456789abcdef default"},
+           "pmc_mean_per_launch": {"void k_pass2_hs<1024, 16, 4, 2, false, 0>": {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 3000.0},
+                                   "void k_pass1<1024, 16, 1>": {"FETCH_SIZE": 10.0, "WRITE_SIZE": 30.0}}}
+    path.write_text(json.dumps(rec))
+    t, note = bench.pmc_traffic("ocean1024", 32, "k_pass2", "0123456789abcdef default")
+    assert t == (2 * 1000.0 + 3000.0) * 1024.0 and "same build" in note     # FETCH_SIZE counts 128-B requests at 64 B: doubled
+    t, note = bench.pmc_traffic("ocean1024", 32, "k_pass2", "fedcba9876543210 default")
+    assert t is None and "not quoted" in note                                # another build: refused, and the note says why
+    t, note = bench.pmc_traffic("ocean1024", 32, "k_pass", "0123456789abcdef default")
+    assert t == (2 * 1010.0 + 3030.0) * 1024.0                               # several kernels of one call: their sum
+    t, note = bench.pmc_traffic("ocean1024", 20, "k_pass2", "0123456789abcdef default")
+    assert t is None and "no committed PMC pass" in note                     # another batch size: another file
+    rec["bench_line"] = None                                                 # a round-2 style file without a build id
+    path.write_text(json.dumps(rec))
+    t, note = bench.pmc_traffic("ocean1024", 32, "k_pass2", "0123456789abcdef default")
+    assert t is None and "not quoted" in note
+
+
+def test_metric_and_bytes_are_baselines():
+    base = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "BASELINE.json")))
+    assert bench.BASELINE_METRIC == base["metric"]
+    assert bench.BYTES_PER_POINT == 92 and bench.BYTES_PASS1 + bench.BYTES_PASS2 == 92      # SURVEY.md 8d canonical figure

@@ -11,10 +11,11 @@ pmc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        if any(t in k for t in ("k_pass", "gerstner", "k_or_", "k_pond")):
+        if any(t in k for t in ("k_pass", "gerstner", "k_or_", "k_pond", "k_gemm", "k_direct")):
             pmc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
             pmc[k]["_dur_ns_" + row["Counter_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-out = {"source": src, "bench_line": json.loads(bench_line[-1]) if bench_line else None, "pmc_mean_per_launch": {}}
+line = json.loads(bench_line[-1]) if bench_line else None
+out = {"source": src, "build_id": (line or {}).get("build_id"), "bench_line": line, "pmc_mean_per_launch": {}}
 for k, d in pmc.items():
     # drop the short warm-up launches: keep launches within 15 % of the median duration of that counter pass
     o = {}
