@@ -264,6 +264,7 @@ struct P1Args {
     OceanConsts c;
     int tgroup;        // > 0: 1-D grid, `tgroup` time-steps of one column job kept on one XCD (p1_block_map)
     int nsteps;
+    int field_split = 0;  // 1: grid (column jobs, 3), blockIdx.y = the one field this workgroup transforms (single-step enqueues)
 };
 
 // Pass-1 block -> (column job, time-step).  All time-steps of a batch read the same PQt/Om rows, so the tgroup

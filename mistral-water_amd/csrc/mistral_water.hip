@@ -25,6 +25,9 @@
 #include "gerstner_kernels.h"
 #include "pond_kernels.h"
 
+#ifndef MW_LATENCY_PLAN
+#define MW_LATENCY_PLAN 1  // single-step enqueues at 1024^2: one field per pass-1 workgroup, one wave per pass-2 row (launch_pass*_n)
+#endif
 #ifndef MW_WAVES_P1
 #define MW_WAVES_P1 6  // min waves per SIMD the register allocator must leave room for (measured best)
 #endif
@@ -118,7 +121,17 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
     static_assert(G::NTHREADS % VT == 0 && (VT == 1 || NT % T == 0), "a lane's virtual threads must belong to whole columns");
     const int tid = threadIdx.x;
     int jb = blockIdx.x, step = blockIdx.y;
-    if (A.tgroup > 0 && !p1_block_map((int)blockIdx.x, G::GRID_X, A.nsteps, A.tgroup, &jb, &step)) return;
+    // Frame-at-a-time plan (A.field_split, single-step enqueues): grid (column jobs, 3) -- one FIELD per workgroup instead of
+    // the three one after the other, each workgroup re-forming the (cheap) animated spectrum.  A step is 257 workgroups at
+    // 1024^2 where the device has 1024 slots, so its latency is that of ONE workgroup: a third of the work each cuts it
+    // accordingly.  The arithmetic of a field does not depend on which workgroup runs it: same bits as the batched plan.
+    int f_lo = 0, f_hi = 3;
+    if (A.field_split) {
+        f_lo = (int)blockIdx.y;
+        f_hi = f_lo + 1;
+        step = 0;
+        if (!p1_field_active(N, jb, f_lo, G::CW)) return;  // block-uniform, before any barrier
+    } else if (A.tgroup > 0 && !p1_block_map((int)blockIdx.x, G::GRID_X, A.nsteps, A.tgroup, &jb, &step)) return;
     const float t = times.t[step];
     if (TwGeom<N, P>::LDS_ALL) stage_twiddles<N, P, NT>(lds, A.TW, tid);  // visible after the first barrier
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
@@ -135,6 +148,7 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
     MW_STAMP(0, 1);
 #pragma unroll
     for (int f = 0; f < 3; f++) {
+        if (f < f_lo || f >= f_hi) continue;              // block-uniform: the frame-at-a-time plan runs one field per workgroup
         if (!p1_field_active(N, jb, f, G::CW)) continue;  // block-uniform: height needs columns j <= N/2 only
 #pragma unroll
         MW_VT(h) p1_build<N, P>(A, jb, tid + h * NT, f, st[h], x[h]);
@@ -633,15 +647,14 @@ static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nstep
         if (e != hipSuccess) return e;
     }
     constexpr int NT = P1Geom<N, P>::NTHREADS / VT, LB = P1Geom<N, P>::LDS_BYTES, GX = P1Geom<N, P>::GRID_X;
-    if (A.tgroup > 0)
+    if (A.field_split)
+        k_pass1<N, P, VT><<<dim3(GX, 3), dim3(NT), LB, st>>>(A, tm);
+    else if (A.tgroup > 0)
         k_pass1<N, P, VT><<<dim3(p1_grid_blocks(GX, nsteps, A.tgroup)), dim3(NT), LB, st>>>(A, tm);
     else
         k_pass1<N, P, VT><<<dim3(GX, nsteps), dim3(NT), LB, st>>>(A, tm);
     return hipGetLastError();
 }
-#ifndef MW_LATENCY_PLAN
-#define MW_LATENCY_PLAN 1
-#endif
 template <int N, bool DUMP>
 static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     constexpr int P = Plan<N>::P2, R2 = Plan<N>::R2;
@@ -702,6 +715,7 @@ static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipS
     A.c = consts_of(o);
     A.nsteps = nsteps;
     A.tgroup = p1_time_group(o, nsteps);
+    A.field_split = (MW_LATENCY_PLAN && nsteps == 1 && o->N == 1024) ? 1 : 0;  // the frame-at-a-time plan (k_pass1)
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass1_n<NN>(A, tm, nsteps, st));
     if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pass1 launch: ") + hipGetErrorString(e));
