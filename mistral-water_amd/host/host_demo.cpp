@@ -12,7 +12,7 @@ int main() {
         for (int f = 0; f < 3; f++) m.Update(1.f / 60.f);
         double hmax = 0;
         for (auto& v : m.mesh.vertices) hmax = hmax > (v.y < 0 ? -v.y : v.y) ? hmax : (v.y < 0 ? -v.y : v.y);
-        std::printf("FFTMesh 256^2: timer = %.4f, max|height| = %.4f, colour[0] = %.4f\n", m.timer(), hmax, m.mesh.colors[0].r);
+        std::printf("FFTMesh 256^2: timer = %.9g, max|height| = %.9g, colour[0] = %.9g\n", m.timer(), hmax, m.mesh.colors[0].r);
         OceanRenderer r;
         r.resolution = 16; r.length = 60.f; r.amplitude = 0.41f; r.choppiness = 0.46f; r.mult = 1.5f; r.wind = {14.45f, 12.f};
         r.Awake();

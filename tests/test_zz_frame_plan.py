@@ -31,3 +31,28 @@ def test_single_step_plan_equals_batched_plan_bit_for_bit_1024(mw):
             assert (bv[k] == v).all(), k
             assert (bn[k] == n).all(), k
             assert (bw[k] == c[:, 0]).all(), k
+
+
+def test_cpp_host_mirror_runs_and_agrees_with_the_python_mirror(mw):
+    """mistral-water_amd/host/FFTMesh.hpp -- the compiled host side above the C ABI (the reference's host language, C#, has no
+    toolchain in the image): host_demo drives FFTMesh.Awake() / Update() x 3, an OceanRenderer frame with the RGBA targets and
+    the mesh vertex stage, and the pond material.  Its FFTMesh numbers must be those of the Python mirror with the same
+    Inspector fields (same seed rule, same float32 timer arithmetic, S/FFTMesh.cs:60-73)."""
+    import os
+    import re
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mistral-water_amd", "host")
+    subprocess.run(["make", "-C", host, "-s"], check=True)
+    r = subprocess.run([os.path.join(host, "host_demo")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"FFTMesh 256\^2: timer = (\S+), max\|height\| = (\S+), colour\[0\] = (\S+)", r.stdout)
+    assert m and "OceanRenderer 128^2" in r.stdout and "pond Gerstner" in r.stdout, r.stdout
+    f = mw.FFTMesh()
+    f.resolution, f.unitWidth, f.length, f.amplitude, f.choppiness = 256, 1.0, 256.0, 2.4e-7, 0.46
+    f.wind = mw.Vector2(14.45, 12.0)
+    f.Awake()
+    for _ in range(3):
+        f.Update(1.0 / 60.0)
+    hmax = float(np.abs(f.mesh.vertices[:, 1]).max())
+    assert abs(float(m.group(1)) - f.timer) < 1e-7
+    assert abs(float(m.group(2)) - hmax) <= 1e-6 * hmax and abs(float(m.group(3)) - float(f.mesh.colors[0, 0])) <= 1e-6
