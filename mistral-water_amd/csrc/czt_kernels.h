@@ -1,0 +1,120 @@
+// czt_kernels.h -- chirp-z (Bluestein) form of the separable sum for grids the FFT cannot express, O(N^2 log N).
+//
+// The reference's basis (S/FFTMesh.cs:107-112, 199-208) on ANY grid is bilinear in the two indices:
+//     k_i x_a = theta (i - c)(a - c'),   theta = 2 pi unit_width / length,  c = N/2,  c' = (N - 1)/2
+// (even N: x_a = (a - N/2 + 1/2) u; odd N: x_a = (a - (N-1)/2) u -- the same c' either way).  With
+//     (i - c)(a - c') = 1/2 [ (i - c)^2 + (a - c')^2 - (i - a + delta)^2 ],   delta = c' - c = -1/2
+// one axis of the sum is a chirp-modulated CONVOLUTION
+//     out[a] = w2[a] * sum_i (x[i] w1[i]) g[i - a],   w1[i] = e^{i theta (i-c)^2/2},  w2[a] = e^{i theta (a-c')^2/2},
+//                                                      g[d]  = e^{-i theta (d+delta)^2/2}
+// evaluated by two LDS-staged Stockham transforms of size M >= 2N - 1 (the passes of mw_math.h, the same code the FFT path
+// runs): forward transform of the zero-padded x w1, product with the precomputed transform of the wrapped kernel, inverse
+// transform, post-chirp (the 1/M of the unnormalised inverse folded into w2).  The 2-D sum is this along j, then along i;
+// every launch stores its result transposed, so both launches read contiguous rows and the second one lands in [a][b].
+// All chirps and the kernel's transform are formed in f64 on the host once per handle (they do not depend on t).
+//
+// Phase functions are MW_HD so that tests/emul steps the same code on the host (tests/test_emul.py::test_chirp_z_*).
+// STATUS (round 3): built and emulation-checked after GPU access ended; NOT yet run on hardware, therefore opt-in
+// (environment MW_DIRECT_CZT=1).  The default for these grids is the MFMA GEMM form (direct_kernels.h), green on the GPU.
+#pragma once
+#include "fftmesh_kernels.h"
+
+#include <vector>
+
+namespace mw {
+
+struct CztArgs {
+    const cf* in = nullptr;   // [field][row][in_ld]: rows of N values, contiguous
+    cf* out = nullptr;        // transposed store: element (row r, column n) of field f at out[f * out_plane + n * out_ld + r]
+    const cf* w1 = nullptr;   // [N] pre-chirp
+    const cf* w2 = nullptr;   // [N] post-chirp / M
+    const cf* Hh = nullptr;   // [M] forward transform of the wrapped kernel g
+    const cf* TWf = nullptr;  // twiddle tables of the size-M forward (sign -1) and inverse (+1) transforms, TwGeom<M, P> layout
+    const cf* TWi = nullptr;
+    int N = 0, rows = 0, in_ld = 0, out_ld = 0;
+    long long in_plane = 0, out_plane = 0;
+};
+
+// transform size and points per thread for a grid of N points per axis (0: N too large for one workgroup-resident transform)
+inline int czt_size(int N) {
+    int M = 64;
+    while (M < 2 * N - 1) M *= 2;
+    return M <= 4096 ? M : 0;
+}
+constexpr int czt_points(int M) { return M >= 256 ? 16 : 8; }
+constexpr int czt_rows(int M) { return (512 / (M / czt_points(M))) < 1 ? 1 : ((512 / (M / czt_points(M))) > 8 ? 8 : (512 / (M / czt_points(M)))); }
+
+template <int M, int P>
+MW_HD void czt_load(const CztArgs& A, int f, int row, int u, bool live, cf (&x)[P]) {
+    constexpr int T = M / P;
+    const cf* __restrict__ r = A.in + (size_t)f * A.in_plane + (size_t)row * A.in_ld;
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int n = u + T * q;
+        x[q] = (live && n < A.N) ? cmul(r[n], A.w1[n]) : mk(0.f, 0.f);  // zero padding up to M
+    }
+}
+template <int M, int P>
+MW_HD void czt_mul_kernel(const CztArgs& A, int u, cf (&x)[P]) {
+    constexpr int T = M / P;
+#pragma unroll
+    for (int q = 0; q < P; q++) x[q] = cmul(x[q], A.Hh[u + T * q]);
+}
+template <int M, int P>
+MW_HD void czt_store(const CztArgs& A, int f, int row, int u, const cf (&x)[P]) {
+    constexpr int T = M / P;
+    cf* __restrict__ o = A.out + (size_t)f * A.out_plane + row;
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int n = u + T * q;
+        if (n < A.N) o[(size_t)n * A.out_ld] = cmul(x[q], A.w2[n]);
+    }
+}
+
+// ---- host-side tables (f64, once per handle) -------------------------------------------------------------------------
+// theta from the SAME float32 unit_width and length the kernels' other paths use; everything after that in double
+inline void czt_fft_f64(std::vector<double>& re, std::vector<double>& im, int sign) {  // in-place radix-2, size a power of two
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = sign * 2.0 * M_PI / (double)len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; k++) {
+                const double c = cos(ang * (double)k), s = sin(ang * (double)k);
+                const double ur = re[i + k], ui = im[i + k];
+                const double vr = re[i + k + len / 2] * c - im[i + k + len / 2] * s, vi = re[i + k + len / 2] * s + im[i + k + len / 2] * c;
+                re[i + k] = ur + vr; im[i + k] = ui + vi;
+                re[i + k + len / 2] = ur - vr; im[i + k + len / 2] = ui - vi;
+            }
+    }
+}
+inline void czt_build_tables(int N, int M, float unit_width, float length, std::vector<cf>& w1, std::vector<cf>& w2, std::vector<cf>& Hh) {
+    const double theta = 2.0 * M_PI * (double)unit_width / (double)length;
+    const double c = N / 2.0, cp = (N - 1) / 2.0, delta = cp - c;
+    auto chirp = [&](double s) {  // e^{i theta s^2 / 2}, the phase reduced in double
+        const double ph = fmod(theta * s * s / 2.0, 2.0 * M_PI);
+        return std::pair<double, double>(cos(ph), sin(ph));
+    };
+    w1.resize(N); w2.resize(N); Hh.resize(M);
+    for (int i = 0; i < N; i++) {
+        auto a = chirp((double)i - c), b = chirp((double)i - cp);
+        w1[i] = mk((float)a.first, (float)a.second);
+        w2[i] = mk((float)(b.first / M), (float)(b.second / M));
+    }
+    // conv[a] = sum_i y[i] h[a - i] with h[m] = g[-m] = e^{-i theta (-m + delta)^2 / 2}, |m| <= N - 1, wrapped modulo M
+    std::vector<double> re(M, 0.0), im(M, 0.0);
+    for (int m = -(N - 1); m <= N - 1; m++) {
+        auto g = chirp((double)(-m) + delta);
+        re[(m + M) % M] = g.first;
+        im[(m + M) % M] = -g.second;
+    }
+    czt_fft_f64(re, im, -1);
+    for (int k = 0; k < M; k++) Hh[k] = mk((float)re[k], (float)im[k]);
+}
+
+}  // namespace mw

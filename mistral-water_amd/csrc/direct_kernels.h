@@ -16,10 +16,21 @@
 // (they do not depend on t); per step: the spectrum kernel, 4 GEMM launches, one assembly kernel, the whitecap kernel.
 #pragma once
 #include "fftmesh_kernels.h"
+#include "czt_kernels.h"
 
 namespace mw {
 
+// chirp-z form (czt_kernels.h), opt-in until it has run on hardware: tables + the three complex work arrays
+struct CztState {
+    int M = 0;
+    cf *w1 = nullptr, *w2 = nullptr, *Hh = nullptr, *TWf = nullptr, *TWi = nullptr;
+    cf *F = nullptr, *TT = nullptr, *O = nullptr;  // [5][N][N] each: spectra, after the z sum (transposed), after the x sum
+    float table_length = -1.f, table_unit_width = -1.f;
+};
+
 struct DirectState {
+    CztState czt;
+    bool use_czt = false;
     int N = 0, Np = 0;
     float* A1 = nullptr;     // [5][Np][2Np]   (Fr_f | Fi_f), rebuilt every step
     float* T = nullptr;      // [5][2Np][Np]   (Tr_f ; Ti_f)
@@ -151,12 +162,174 @@ __global__ void k_direct_white(int N, const cf* hds, const float* normals, float
     else { white[4 * idx] = xx; white[4 * idx + 1] = xx; white[4 * idx + 2] = xx; white[4 * idx + 3] = xx; }
 }
 
+// ---- chirp-z launches ---------------------------------------------------------------------------------------------------
+// S/FFTMesh.cs:178-190 htilde + the five multiplier spectra of :211-215 as complex planes F[f][i][j]
+__global__ void k_czt_spec(OceanConsts C, const cf* h0, const cf* h0c, float t, cf* F) {
+    const int N = C.N;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * N) return;
+    int i = idx / N, j = idx % N;
+    float s, c;
+    mw_sincos(omega_t_f32(N, C.length, C.gravity, i, j, t), &s, &c);
+    cf a = h0[idx], b = h0c[idx];
+    cf h = mk(a.x * c - a.y * s + b.x * c + b.y * s, a.x * s + a.y * c - b.x * s + b.y * c);  // :188
+    float kx = wave_k(N, C.length, i), kz = wave_k(N, C.length, j);
+    float kl = sqrtf(kx * kx + kz * kz);
+    float ux = 0.f, uzn = 0.f;
+    if (!(kl < MW_EPS_F)) { ux = kx / kl; uzn = -kz / kl; }  // :213-215
+    const size_t NN = (size_t)N * N;
+    F[idx] = h;
+    F[NN + idx] = cscale(h, ux);
+    F[2 * NN + idx] = cscale(h, uzn);
+    F[3 * NN + idx] = cscale(h, kx);
+    F[4 * NN + idx] = cscale(h, kz);
+}
+// one axis of the sum for RW rows per workgroup: pre-chirp + zero padding, forward transform, kernel product, inverse
+// transform, post-chirp, transposed store (czt_kernels.h).  Twiddles come from global memory (L1 / L2 hits): not a throughput
+// kernel yet.  Barriers are workgroup-uniform: rows past the end compute on zeros and store nothing.
+template <int M, int P, int RW>
+__global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = M / P, BUF = FftGeom<M, P>::LBUF + 4;
+    const int tid = threadIdx.x, w = tid / T, u = tid % T, row = (int)blockIdx.x * RW + w, f = blockIdx.y;
+    const bool live = row < A.rows;
+    const Twiddles twf = TwGeom<M, P>::view(A.TWf), twi = TwGeom<M, P>::view(A.TWi);
+    cf* buf = lds + (size_t)w * BUF;
+    cf x[P];
+    czt_load<M, P>(A, f, live ? row : 0, u, live, x);
+    stage0_store<M, P, -1>(x, u, buf);
+    __syncthreads();
+#pragma unroll
+    for (int s = 1; s < FftGeom<M, P>::S; s++) {
+        load_slots<M, P>(x, u, buf, s - 1);
+        __syncthreads();
+        stage_store<M, P, -1, false>(x, u, buf, twf, s);
+        __syncthreads();
+    }
+    load_last<M, P>(x, u, buf);
+    final_stage<M, P, -1>(x, u, twf.TF);
+    czt_mul_kernel<M, P>(A, u, x);
+    __syncthreads();  // every read of the forward transform's last exchange is done
+    stage0_store<M, P, +1>(x, u, buf);
+    __syncthreads();
+#pragma unroll
+    for (int s = 1; s < FftGeom<M, P>::S; s++) {
+        load_slots<M, P>(x, u, buf, s - 1);
+        __syncthreads();
+        stage_store<M, P, +1, false>(x, u, buf, twi, s);
+        __syncthreads();
+    }
+    load_last<M, P>(x, u, buf);
+    final_stage<M, P, +1>(x, u, twi.TF);
+    if (live) czt_store<M, P>(A, f, row, u, x);
+}
+// vertices / normals / hds from the five complex output planes O[f][a][b]: H = Re, Dx Dz Sx Sz = Im (S/FFTMesh.cs:211-218)
+__global__ void k_czt_assemble(OceanConsts C, const cf* O, cf* hds, float* vertices, float* normals) {
+    const int N = C.N;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * N) return;
+    int a = idx / N, b = idx % N;
+    const size_t NN = (size_t)N * N;
+    const float h = O[idx].x, dx = O[NN + idx].y, dz = O[2 * NN + idx].y, sx = O[3 * NN + idx].y, sz = O[4 * NN + idx].y;
+    const float mag = sqrtf(sx * sx + 1.0f + sz * sz);  // up - n, S/FFTMesh.cs:218
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (mag > 1e-5f) { nx = sx / mag; ny = 1.0f / mag; nz = sz / mag; }
+    normals[3 * idx] = nx; normals[3 * idx + 1] = ny; normals[3 * idx + 2] = nz;
+    vertices[3 * idx + 0] = ssub(rest_coord(N, C.unit_width, a), smul(dx, C.choppiness));  // :245
+    vertices[3 * idx + 1] = h;                                                             // :243
+    vertices[3 * idx + 2] = ssub(rest_coord(N, C.unit_width, b), smul(dz, C.choppiness));  // :244
+    hds[idx] = mk(dx, dz);                                                                 // :247
+}
+
+std::vector<cf> build_twiddle_table(int N, int P, int sgn);  // mistral_water.hip
+
+static inline void czt_free(CztState& z) {
+    hipFree(z.w1); hipFree(z.w2); hipFree(z.Hh); hipFree(z.TWf); hipFree(z.TWi); hipFree(z.F); hipFree(z.TT); hipFree(z.O);
+    z = CztState();
+}
+static inline int czt_alloc(CztState& z, int N) {
+    z.M = czt_size(N);
+    if (!z.M) return 1;
+    const int P = czt_points(z.M);
+    const std::vector<cf> tf = build_twiddle_table(z.M, P, -1), ti = build_twiddle_table(z.M, P, +1);
+    const size_t NN = (size_t)N * N;
+    if (hipMalloc((void**)&z.w1, sizeof(cf) * N) != hipSuccess || hipMalloc((void**)&z.w2, sizeof(cf) * N) != hipSuccess ||
+        hipMalloc((void**)&z.Hh, sizeof(cf) * z.M) != hipSuccess || hipMalloc((void**)&z.TWf, sizeof(cf) * tf.size()) != hipSuccess ||
+        hipMalloc((void**)&z.TWi, sizeof(cf) * ti.size()) != hipSuccess || hipMalloc((void**)&z.F, sizeof(cf) * 5 * NN) != hipSuccess ||
+        hipMalloc((void**)&z.TT, sizeof(cf) * 5 * NN) != hipSuccess || hipMalloc((void**)&z.O, sizeof(cf) * 5 * NN) != hipSuccess ||
+        hipMemcpy(z.TWf, tf.data(), sizeof(cf) * tf.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(z.TWi, ti.data(), sizeof(cf) * ti.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        czt_free(z);
+        return 4;
+    }
+    return 0;
+}
+template <int M>
+static hipError_t czt_launch(const CztArgs& A, hipStream_t st) {
+    constexpr int P = czt_points(M), RW = czt_rows(M), LB = RW * (FftGeom<M, P>::LBUF + 4) * (int)sizeof(cf);
+    static AttrOnce attr;
+    hipError_t e = attr.set(reinterpret_cast<const void*>(&k_czt<M, P, RW>), LB);
+    if (e != hipSuccess) return e;
+    k_czt<M, P, RW><<<dim3((A.rows + RW - 1) / RW, 5), dim3(RW * M / P), LB, st>>>(A);
+    return hipGetLastError();
+}
+static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h0, const cf* h0c, float t, float* dv, float* dn, float* dw,
+                                      int white_stride, hipStream_t st) {
+    CztState& z = d.czt;
+    const int N = C.N;
+    const unsigned nb = (unsigned)(((size_t)N * N + 127) / 128);
+    if (z.table_length != C.length || z.table_unit_width != C.unit_width) {  // chirps and the kernel's transform: once per handle / length
+        std::vector<cf> w1, w2, Hh;
+        czt_build_tables(N, z.M, C.unit_width, C.length, w1, w2, Hh);
+        hipError_t e = hipStreamSynchronize(st);  // a step still in flight may be reading the old tables
+        if (e == hipSuccess) e = hipMemcpy(z.w1, w1.data(), sizeof(cf) * N, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(z.w2, w2.data(), sizeof(cf) * N, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(z.Hh, Hh.data(), sizeof(cf) * z.M, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+        z.table_length = C.length;
+        z.table_unit_width = C.unit_width;
+    }
+    hipLaunchKernelGGL(k_czt_spec, dim3(nb), dim3(128), 0, st, C, h0, h0c, t, z.F);
+    CztArgs A;
+    A.w1 = z.w1; A.w2 = z.w2; A.Hh = z.Hh; A.TWf = z.TWf; A.TWi = z.TWi;
+    A.N = N; A.rows = N; A.in_ld = N; A.out_ld = N; A.in_plane = (long long)N * N; A.out_plane = (long long)N * N;
+    hipError_t e = hipSuccess;
+    for (int pass = 0; pass < 2 && e == hipSuccess; pass++) {
+        A.in = pass == 0 ? z.F : z.TT;   // along j (rows i) -> TT[f][b][i]; along i (rows b) -> O[f][a][b]
+        A.out = pass == 0 ? z.TT : z.O;
+        switch (z.M) {
+            case 64: e = czt_launch<64>(A, st); break;
+            case 128: e = czt_launch<128>(A, st); break;
+            case 256: e = czt_launch<256>(A, st); break;
+            case 512: e = czt_launch<512>(A, st); break;
+            case 1024: e = czt_launch<1024>(A, st); break;
+            case 2048: e = czt_launch<2048>(A, st); break;
+            case 4096: e = czt_launch<4096>(A, st); break;
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_czt_assemble, dim3(nb), dim3(128), 0, st, C, z.O, d.hds, dv, dn);
+    hipLaunchKernelGGL(k_direct_white, dim3(nb), dim3(128), 0, st, N, d.hds, dn, dw, white_stride);
+    return hipGetLastError();
+}
+
 static inline void direct_free(DirectState& d) {
     hipFree(d.A1); hipFree(d.T); hipFree(d.B1re); hipFree(d.B1im); hipFree(d.A2re); hipFree(d.A2im); hipFree(d.out); hipFree(d.hds);
+    czt_free(d.czt);
     d = DirectState();
 }
 static inline int direct_alloc(DirectState& d, int N, hipStream_t st) {
     d.N = N;
+    // MW_DIRECT_CZT=1: the chirp-z form (opt-in until it has run on hardware; needs 2N - 1 <= 4096)
+    const char* env = std::getenv("MW_DIRECT_CZT");
+    if (env && std::atoi(env) == 1 && czt_size(N) != 0) {
+        if (czt_alloc(d.czt, N) != 0 || hipMalloc((void**)&d.hds, sizeof(cf) * (size_t)N * N) != hipSuccess) { direct_free(d); return 4; }
+        d.N = N;
+        d.use_czt = true;
+        return 0;
+    }
     d.Np = (N + 63) / 64 * 64;
     const size_t P2 = (size_t)d.Np * d.Np;
     struct { float** p; size_t n; } bufs[] = {{&d.A1, 10 * P2}, {&d.T, 10 * P2}, {&d.B1re, 2 * P2}, {&d.B1im, 2 * P2},
@@ -183,6 +356,12 @@ static inline hipError_t direct_gemm(const float* A, const float* B, float* C, i
 // ev (measurement hook, mw_ocean_profile_kernels): three events recorded before the spectrum kernel, before and after the GEMMs
 static inline hipError_t direct_evaluate(DirectState& d, OceanConsts C, const cf* h0, const cf* h0c, float t, float* dv,
                                          float* dn, float* dw, int white_stride, hipStream_t st, hipEvent_t* ev = nullptr) {
+    if (d.use_czt) {
+        if (ev) { hipEventRecord(ev[0], st); hipEventRecord(ev[1], st); }
+        const hipError_t e = czt_evaluate(d, C, h0, h0c, t, dv, dn, dw, white_stride, st);
+        if (ev) hipEventRecord(ev[2], st);
+        return e;
+    }
     const int N = C.N, Np = d.Np;
     const unsigned nb = (unsigned)(((size_t)N * N + 127) / 128);
     const long long P2 = (long long)Np * Np;

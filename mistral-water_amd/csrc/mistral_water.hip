@@ -20,8 +20,8 @@
 #include "../../include/mistral_water.h"
 #include "../../include/mistral_water_hooks.h"
 #include "fftmesh_kernels.h"
-#include "direct_kernels.h"
 #include "ocean_renderer_device.h"
+#include "direct_kernels.h"
 #include "gerstner_kernels.h"
 #include "pond_kernels.h"
 

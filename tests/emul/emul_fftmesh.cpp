@@ -17,6 +17,7 @@
 #include "../../mistral-water_amd/csrc/gerstner_kernels.h"
 #include "../../mistral-water_amd/csrc/pond_kernels.h"
 #include "../../mistral-water_amd/csrc/ocean_renderer_kernels.h"
+#include "../../mistral-water_amd/csrc/czt_kernels.h"
 
 using namespace mw;
 
@@ -291,6 +292,58 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
     return 0;
 }
 
+// ---- chirp-z form of the separable sum (czt_kernels.h): one launch of k_czt stepped phase by phase -------------------------
+// workgroup = RW rows x T threads; phases separated by the kernel's barriers; per-thread registers persist across phases
+template <int M, int P>
+int czt_pass_np(CztArgs A, int nfields) {
+    constexpr int T = M / P, RW = czt_rows(M), BUF = FftGeom<M, P>::LBUF + 4, NT = RW * T;
+    Tables tf(M, P, -1), ti(M, P, +1);
+    A.TWf = tf.TW.data();
+    A.TWi = ti.TW.data();
+    const Twiddles twf = TwGeom<M, P>::view(A.TWf), twi = TwGeom<M, P>::view(A.TWi);
+    struct S { cf x[P]; };
+    std::vector<S> st(NT);
+    std::vector<cf> lds((size_t)RW * BUF);
+    for (int f = 0; f < nfields; f++)
+        for (int rb = 0; rb * RW < A.rows; rb++) {
+            auto all = [&](auto&& body) {
+                for (int tid = 0; tid < NT; tid++) {
+                    const int w = tid / T, u = tid % T, row = rb * RW + w;
+                    body(st[tid].x, u, row, row < A.rows, lds.data() + (size_t)w * BUF);
+                }
+            };
+            all([&](cf (&x)[P], int u, int row, bool live, cf* buf) { czt_load<M, P>(A, f, row, u, live, x); stage0_store<M, P, -1>(x, u, buf); });
+            for (int s = 1; s < FftGeom<M, P>::S; s++) {
+                all([&](cf (&x)[P], int u, int, bool, cf* buf) { load_slots<M, P>(x, u, buf, s - 1); });
+                all([&](cf (&x)[P], int u, int, bool, cf* buf) { stage_store<M, P, -1, false>(x, u, buf, twf, s); });
+            }
+            all([&](cf (&x)[P], int u, int, bool, cf* buf) { load_last<M, P>(x, u, buf); final_stage<M, P, -1>(x, u, twf.TF); czt_mul_kernel<M, P>(A, u, x); });
+            all([&](cf (&x)[P], int u, int, bool, cf* buf) { stage0_store<M, P, +1>(x, u, buf); });
+            for (int s = 1; s < FftGeom<M, P>::S; s++) {
+                all([&](cf (&x)[P], int u, int, bool, cf* buf) { load_slots<M, P>(x, u, buf, s - 1); });
+                all([&](cf (&x)[P], int u, int, bool, cf* buf) { stage_store<M, P, +1, false>(x, u, buf, twi, s); });
+            }
+            all([&](cf (&x)[P], int u, int row, bool live, cf* buf) {
+                load_last<M, P>(x, u, buf);
+                final_stage<M, P, +1>(x, u, twi.TF);
+                if (live) czt_store<M, P>(A, f, row, u, x);
+            });
+        }
+    return 0;
+}
+int czt_pass(int M, const CztArgs& A, int nfields) {
+    switch (M) {
+        case 64: return czt_pass_np<64, czt_points(64)>(A, nfields);
+        case 128: return czt_pass_np<128, czt_points(128)>(A, nfields);
+        case 256: return czt_pass_np<256, czt_points(256)>(A, nfields);
+        case 512: return czt_pass_np<512, czt_points(512)>(A, nfields);
+        case 1024: return czt_pass_np<1024, czt_points(1024)>(A, nfields);
+        case 2048: return czt_pass_np<2048, czt_points(2048)>(A, nfields);
+        case 4096: return czt_pass_np<4096, czt_points(4096)>(A, nfields);
+        default: return 1;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -446,5 +499,22 @@ int emul_p1_block_map(int bid, int gx, int nsteps, int tgroup, int* jb, int* ste
     return p1_block_map(bid, gx, nsteps, tgroup, jb, step) ? 1 : 0;
 }
 int emul_p1_grid_blocks(int gx, int nsteps, int tgroup) { return p1_grid_blocks(gx, nsteps, tgroup); }
+
+// sum_ij F_f(i,j) e^{i(k_i x_a + k_j z_b)} for nfields complex N x N fields through the two chirp-z launches (along j, then
+// along i; each stores transposed), tables from czt_build_tables: in [f][i][j], out [f][a][b], interleaved (re, im) float32
+int emul_czt2d(int N, float unit_width, float length, int nfields, const float* in_xy, float* out_xy) {
+    const int M = czt_size(N);
+    if (!M) return 2;
+    std::vector<cf> w1, w2, Hh, tmp((size_t)nfields * N * N);
+    czt_build_tables(N, M, unit_width, length, w1, w2, Hh);
+    CztArgs A;
+    A.w1 = w1.data(); A.w2 = w2.data(); A.Hh = Hh.data();
+    A.N = N; A.rows = N; A.in_ld = N; A.out_ld = N; A.in_plane = (long long)N * N; A.out_plane = (long long)N * N;
+    A.in = reinterpret_cast<const cf*>(in_xy); A.out = tmp.data();          // along j: tmp[f][b][i]
+    int r = czt_pass(M, A, nfields);
+    if (r) return r;
+    A.in = tmp.data(); A.out = reinterpret_cast<cf*>(out_xy);               // along i: out[f][a][b]
+    return czt_pass(M, A, nfields);
+}
 
 }  // extern "C"

@@ -122,6 +122,15 @@ class Emul:
         self.L.emul_or_displace_mesh(M, res, C.c_float(unit_width), _p(h), _p(d), _p(n), _p(w), _p(v), _p(nr), _p(c))
         return v, nr, c
 
+    def czt2d(self, N, unit_width, length, fields):
+        """fields: complex [nf, N, N] -> the separable sum of every field through the two chirp-z launches (czt_kernels.h)."""
+        fields = np.asarray(fields)
+        fin = np.ascontiguousarray(np.stack([fields.real, fields.imag], -1), np.float32)
+        out = np.empty_like(fin)
+        r = self.L.emul_czt2d(int(N), C.c_float(unit_width), C.c_float(length), fin.shape[0], _p(fin), _p(out))
+        assert r == 0, f"emul_czt2d -> {r}"
+        return out[..., 0] + 1j * out[..., 1], fin[..., 0].astype(np.float64) + 1j * fin[..., 1]
+
     def gerstner_steps(self, pos, waves, amplitude, frequency, steepness, times):
         pos = np.ascontiguousarray(pos, np.float32)
         wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)

@@ -269,3 +269,20 @@ def test_pipeline_random_inspector_settings(emul, oracle):
         v, n, w = emul.evaluate(p, h0, h0c, [t])
         vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, t, return_hds=True)
         workloads.assert_parity(v[0], n[0], w[0], vf, nf, cf, oracle.rest_mesh(p)[0], np.abs(hds).max(), tag=f"{p} t={t}")
+
+
+@pytest.mark.parametrize("N,u,L", [(12, 1.0, 12.39), (33, 0.9, 33.0), (50, 1.0, 1.0), (64, 1.0, 64.0), (65, 0.5, 40.0), (100, 0.9, 100.0),
+                                   (200, 1.0, 212.5), (600, 1.0, 600.0)])
+def test_chirp_z_form_equals_the_separable_sum(emul, oracle, N, u, L):
+    """czt_kernels.h: the reference's basis is bilinear in the two indices on ANY grid, k_i x_a = theta (i - N/2)(a - (N-1)/2), so one
+    axis of S/FFTMesh.cs:199-217 is a chirp-modulated convolution: two Stockham transforms of size M >= 2N - 1 (the FFT path's own
+    passes) instead of an O(N^2) sum.  The kernel's phase functions stepped on the host, both launches with their transposed
+    stores, against the f64 matrix-product form of the oracle: the shipped scene, an odd grid, the Inspector defaults (phases up
+    to 3900 rad -- the chirps are reduced in f64), a commensurate grid, one past a power of two, M = 64 ... 2048."""
+    p = oracle.Params(N=N, unit_width=u, length=L, wind_x=5.0, wind_y=3.0, amplitude=1.0 if L == 1.0 else 1e-3, choppiness=0.8)
+    h0, h0c = oracle.generate_spectrum(p, 2)
+    F = oracle.htilde_fields_f64(p, h0, h0c, 1.25)
+    got, fin = emul.czt2d(N, u, L, F)
+    want = oracle.transform_matmul_f64(p, fin)            # of the float32-rounded spectra the kernels see
+    for f in range(5):
+        assert np.abs(got[f] - want[f]).max() <= 2e-6 * np.abs(want[f]).max(), (f, np.abs(got[f] - want[f]).max() / np.abs(want[f]).max())
