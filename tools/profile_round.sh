@@ -1,0 +1,25 @@
+#!/bin/bash
+# rocprofv3 evidence of the CURRENT build, every workload at the batch sizes bench.py reports (run through gpurun; ~6 min):
+#   tools/profile_round.sh r04     (then set PROFILE_ROUND = "r04" in bench.py)  ->  gpurun_out/prof_<tag>_<workload>/ and the condensed profiles/<tag>_<workload>_b<B>_{kernel_stats.csv,pmc.json}
+# Each summary stores the bench line of the traced run (with mw_build_id()): bench.py quotes roofline.traffic from it only while
+# the library is that build.  Memory guard: a host-side bug once took the GPU boxes down -- every python
+# process below runs under `timeout`, and nothing here allocates more than a few GB.
+tag=${1:-r04}
+run() {  # run TAG WORKLOAD BATCH STEPS [extra bench args]: trace + PMC passes, then the summary under profiles/
+  local name=$1 b=$3
+  timeout 900 bash tools/prof_workload.sh "${tag}_${name}_b${b}" "$2" "$3" "$4" "${@:5}" > gpurun_out/prof_${tag}_${name}_b${b}.log 2>&1
+  python tools/summarize_profiles.py gpurun_out/prof_${tag}_${name}_b${b} profiles/${tag}_${name}_b${b} > /dev/null 2>&1 || echo "summary failed: ${name} b${b}"
+}
+run ocean1024 ocean1024 32 1600
+run ocean1024 ocean1024 20 1000          # the driver's --steps 20: one 20-step enqueue per launch
+run ocean2048 ocean2048 32 320
+run ocean4096 ocean4096 32 128
+run pond pond 32 3200
+run renderer1024 renderer1024 1 2000
+run renderer1024 renderer1024 4 500 --tiles 4
+for n in 50 100 1000; do
+  timeout 300 python bench.py --workload direct --direct-n $n --steps 200 --warmup 20 2> gpurun_out/${tag}_direct_$n.err | tail -1 > profiles/${tag}_bench_direct_$n.json
+done
+timeout 300 python bench.py --steps 20 --warmup 5 2> gpurun_out/${tag}_bench_driver.err | tail -1 > profiles/${tag}_bench_ocean1024_driver_k20.json
+python tools/bench_summary.py profiles/${tag}_bench_direct_50.json profiles/${tag}_bench_direct_100.json profiles/${tag}_bench_direct_1000.json profiles/${tag}_bench_ocean1024_driver_k20.json
+ls profiles | grep "^${tag}_"
