@@ -139,17 +139,20 @@ public class OceanRenderer : MonoBehaviour
         t.Apply(false, false);
     }
 
-    /// Checkpoint of the animation: initialTexture and the phase texture are the whole state.
-    public void SaveState(Vector2[] h0, Vector2[] h0conj, float[] phase)
+    /// Checkpoint of the animation: initialTexture, the phase texture and the length the normal pass uses.  The last one differs
+    /// from `length` after a length change: the reference sets normalMat._Length once in SetParams (S/OceanRenderer.cs:163).
+    public void SaveState(Vector2[] h0, Vector2[] h0conj, float[] phase, out float normalLength)
     {
         Native.Check(Native.mw_ocean_get_spectrum(ocean, h0, h0conj));
         Native.Check(Native.mw_ocean_get_phase(ocean, phase));
+        normalLength = Native.mw_ocean_normal_length(ocean);
     }
 
-    public void RestoreState(Vector2[] h0, Vector2[] h0conj, float[] phase)
+    public void RestoreState(Vector2[] h0, Vector2[] h0conj, float[] phase, float normalLength)
     {
         Native.Check(Native.mw_ocean_set_spectrum(ocean, h0, h0conj));
         Native.Check(Native.mw_ocean_set_phase(ocean, phase));
+        Native.Check(Native.mw_ocean_set_normal_length(ocean, normalLength));
     }
 
     void OnDestroy()
