@@ -57,9 +57,28 @@ def dump_renderer(name):
                         mesh_vertices=v, mesh_normals=n, mesh_colors=c)
 
 
+def dump_config1_sample(name):
+    """BASELINE configs[0] / SURVEY 8d config 1 (the reference's own CPU-runnable case): 256 x 256 grid, unit_width 1, length 256,
+    wind (5, 3), amplitude 0.01, choppiness 1, t = 1.0, seed 1 -- the literal float32 O(N^4) FFTMesh.Displacement loop
+    (S/FFTMesh.cs:192-220) on 192 seeded vertices (the full grid is ~4 minutes on one core), and the f64 values beside it.  The
+    spectrum is NOT stored (1 MB): it is regenerated from the seed by the documented counter RNG."""
+    p = O.Params(N=256, unit_width=1.0, length=256.0, wind_x=5.0, wind_y=3.0, amplitude=0.01, choppiness=1.0, gravity=9.81)
+    h0, h0c = O.generate_spectrum(p, 1)
+    idx = np.sort(np.random.default_rng(256).choice(256 * 256, 192, replace=False)).astype(np.int32)
+    hd, nor = O.displacement_subset_f32(p, h0, h0c, 1.0, idx)       # (d.x, h, d.z) and the unit normal per sampled vertex
+    vf, nf, cf, hds = O.eval_fft_f64(p, h0, h0c, 1.0, return_hds=True)
+    rest = O.rest_mesh(p)[0]
+    params = np.array([p.N, p.unit_width, p.length, p.wind_x, p.wind_y, p.amplitude, p.choppiness, p.gravity], np.float64)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), params=params, seed=1, t=np.float32(1.0), vertex_idx=idx,
+                        literal_hd=hd, literal_normals=nor, f64_height=vf[idx, 1], f64_disp_x=hds[idx, 0], f64_disp_z=hds[idx, 1],
+                        f64_normals=nf[idx], f64_white=cf[idx, 0], rest=rest[idx].astype(np.float32),
+                        h0_checksum=np.array([np.float64(h0.astype(np.float64).sum()), np.float64(np.abs(h0).astype(np.float64).sum())]))
+
+
 if __name__ == "__main__":
     dump_pond("pond_modes_t3p25")
     dump_renderer("renderer_res8_frame2")
+    dump_config1_sample("fftmesh_config1_256_literal_sample")
     dump("fftmesh_n16_t1p5", workloads.fftmesh_params(16, choppiness=1.0), 42, 1.5)
     dump("fftmesh_shipped_n12_t2", workloads.shipped_fftmesh_scene(), 7, 2.0)
     print("ok")

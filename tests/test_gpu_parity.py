@@ -417,6 +417,26 @@ def test_direct_path_large_and_odd_grids(mw, oracle, N, u, L):
         assert (v1 == v2).all() and (c1 == c2).all()
 
 
+def test_config1_256_literal_sample_fixture(mw, oracle):
+    """BASELINE configs[0] on the GPU: the 256 x 256 configuration of the reference's CPU path against the
+    committed sample of the literal float32 O(N^4) loop and its f64 values (tests/golden/fftmesh_config1_256_literal_sample.npz)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fftmesh_config1_256_literal_sample.npz"))
+    pr = z["params"]
+    p = oracle.Params(N=int(pr[0]), unit_width=pr[1], length=pr[2], wind_x=pr[3], wind_y=pr[4], amplitude=pr[5], choppiness=pr[6], gravity=pr[7])
+    h0, h0c = oracle.generate_spectrum(p, int(z["seed"]))
+    idx, rest = z["vertex_idx"], z["rest"]
+    with make(mw, p) as o:
+        o.set_spectrum(h0, h0c)
+        v, n, c = o.evaluate(float(z["t"]))
+    sc = float(np.abs(z["literal_hd"]).max())
+    dx, h, dz = (rest[:, 0] - v[idx, 0]) / p.choppiness, v[idx, 1], (rest[:, 2] - v[idx, 2]) / p.choppiness   # S/FFTMesh.cs:243-247
+    for got, lit, f64 in ((dx, z["literal_hd"][:, 0], z["f64_disp_x"]), (h, z["literal_hd"][:, 1], z["f64_height"]), (dz, z["literal_hd"][:, 2], z["f64_disp_z"])):
+        assert np.abs(got - f64).max() <= 4e-6 * sc + 2.0 ** -22 * np.abs(rest).max()      # the stated float32 tolerance (+ the stored coordinate's ulp)
+        assert np.abs(got - lit).max() <= 3e-4 * sc                                        # the literal float32 sum is itself ~1e-5 off here
+    assert np.abs(n[idx] - z["f64_normals"]).max() < 4e-6 * max(1.0, float(np.abs(z["f64_normals"][:, [0, 2]] / z["f64_normals"][:, [1]]).max()))
+
+
 def test_golden_fixture_n16(mw):
     import os
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fftmesh_n16_t1p5.npz"))

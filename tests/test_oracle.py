@@ -236,3 +236,21 @@ def test_matmul_form_equals_the_direct_f64_sum(oracle, N, u, L):
     b = oracle.eval_matmul_f64(p, h0, h0c, 1.25)
     for x, y in zip(a, b):
         assert np.abs(x - y).max() <= 1e-11 * max(1.0, float(np.abs(x).max()))
+
+
+def test_config1_literal_sample_fixture(oracle):
+    """tests/golden/fftmesh_config1_256_literal_sample.npz -- BASELINE configs[0] (256 x 256, the reference's CPU-runnable case):
+    the spectrum regenerates from the seed, the literal float32 loop reproduces the committed sample bit for bit, and the f64
+    FFT-form evaluator stands where the fixture says (1e-5 of the field: the literal sum of 65536 float32 terms)."""
+    z = np.load(os.path.join(GOLDEN, "fftmesh_config1_256_literal_sample.npz"))
+    pr = z["params"]
+    p = oracle.Params(N=int(pr[0]), unit_width=pr[1], length=pr[2], wind_x=pr[3], wind_y=pr[4], amplitude=pr[5], choppiness=pr[6], gravity=pr[7])
+    h0, h0c = oracle.generate_spectrum(p, int(z["seed"]))
+    assert np.allclose([h0.astype(np.float64).sum(), np.abs(h0).astype(np.float64).sum()], z["h0_checksum"], rtol=1e-12, atol=0)
+    idx = z["vertex_idx"]
+    hd, nor = oracle.displacement_subset_f32(p, h0, h0c, float(z["t"]), idx[:24])          # a slice: 24 x 65536 terms
+    assert (hd == z["literal_hd"][:24]).all() and (nor == z["literal_normals"][:24]).all()
+    vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, float(z["t"]), return_hds=True)
+    assert np.allclose(vf[idx, 1], z["f64_height"], rtol=0, atol=1e-9) and np.allclose(hds[idx, 0], z["f64_disp_x"], rtol=0, atol=1e-9)
+    sc = np.abs(z["literal_hd"]).max()
+    assert np.abs(z["literal_hd"][:, 1] - z["f64_height"]).max() < 3e-5 * sc
