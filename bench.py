@@ -424,9 +424,21 @@ def main():
     roof_ach = BYTES_PASS2 * NN * B / (k2_ms * 1e-3)
     traffic, traffic_note = pmc_traffic(a.workload, B, "k_pass2", build_id)
     traffic1, _ = pmc_traffic(a.workload, B, "k_pass1", build_id)
+    stale = None
+    if traffic is None:      # context only, never `traffic`: the last committed counter pass of this kernel, whatever build it was
+        for rnd in ("r02",):
+            try:
+                j = json.load(open(os.path.join(REPO, "profiles", f"{rnd}_{a.workload}_b32_pmc.json")))["pmc_mean_per_launch"]
+                k = [v for name, v in j.items() if "k_pass2" in name][0]
+                stale = {"bytes_per_point": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / (NN * 32),
+                         "source": f"profiles/{rnd}_{a.workload}_b32_pmc.json",
+                         "note": "counters of an EARLIER build of the same kernel (32-step launches): not this build's traffic"}
+            except Exception:
+                pass
     roofline = {"bound": "hbm", "kernel": "k_pass2", "achieved": roof_ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": roof_ach / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
                 "real_frac": (traffic / (k2_ms * 1e-3) / HBM_PEAK) if traffic else None,
+                "traffic_previous_build": stale,
                 "physical_bytes_per_point": (traffic / (NN * B)) if traffic else None,
                 "bytes_per_launch": BYTES_PASS2 * NN * B, "algorithmic_bytes_per_point": BYTES_PASS2, "launch_us": k2_ms * 1e3,
                 "steps_per_launch": B,
