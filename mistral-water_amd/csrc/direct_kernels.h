@@ -321,7 +321,6 @@ static inline void direct_free(DirectState& d) {
     d = DirectState();
 }
 static inline int direct_alloc(DirectState& d, int N, hipStream_t st) {
-    d.N = N;
     // MW_DIRECT_CZT=1: the chirp-z form (opt-in until it has run on hardware; needs 2N - 1 <= 4096)
     const char* env = std::getenv("MW_DIRECT_CZT");
     if (env && std::atoi(env) == 1 && czt_size(N) != 0) {
@@ -349,6 +348,8 @@ static inline double direct_flops_padded(const DirectState& d) { return 60.0 * (
 
 static inline hipError_t direct_gemm(const float* A, const float* B, float* C, int M, int Nc, int K, int lda, int ldb, int ldc,
                                      long long sA, long long sB, long long sC, int batch, hipStream_t st) {
+    // the kernel has no bounds checks: every operand must be padded to whole tiles and 16-byte aligned rows
+    if (M % MW_GEMM_BM || Nc % MW_GEMM_BN || K % MW_GEMM_BK || lda % 4 || ldb % 4 || batch < 1) return hipErrorInvalidValue;
     k_gemm_f32_mfma<<<dim3(Nc / MW_GEMM_BN, M / MW_GEMM_BM, batch), dim3(256), 0, st>>>(A, B, C, K, lda, ldb, ldc, sA, sB, sC);
     return hipGetLastError();
 }
