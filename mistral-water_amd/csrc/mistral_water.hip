@@ -637,6 +637,13 @@ static OceanConsts consts_of(const mw_ocean* o) {
     return c;
 }
 
+// the frame-at-a-time plan (single-step enqueues at 1024^2): compiled in by MW_LATENCY_PLAN, switched at run time by the
+// environment variable of the same name (0 = the batched plan for every enqueue; A/B without a rebuild)
+static bool latency_plan_on() {
+    static const bool on = [] { const char* e = std::getenv("MW_LATENCY_PLAN"); return MW_LATENCY_PLAN && (!e || std::atoi(e) != 0); }();
+    return on;
+}
+
 // ---- kernel dispatch over N ----------------------------------------------------------------------
 template <int N>
 static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nsteps, hipStream_t st) {
@@ -674,7 +681,7 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     // four waves per workgroup) puts a wave on every SIMD; the arithmetic of a row does not depend on the lane mapping, so the
     // results are the bit patterns of the batched plan.
     if constexpr (HS && N == 1024 && VT == 2 && !DUMP && MW_LATENCY_PLAN) {
-        if (nsteps == 1) {
+        if (nsteps == 1 && latency_plan_on()) {
             static AttrOnce attr1;
             hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, 1, false, 0>), LB);
             if (e != hipSuccess) return e;
@@ -715,7 +722,7 @@ static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipS
     A.c = consts_of(o);
     A.nsteps = nsteps;
     A.tgroup = p1_time_group(o, nsteps);
-    A.field_split = (MW_LATENCY_PLAN && nsteps == 1 && o->N == 1024) ? 1 : 0;  // the frame-at-a-time plan (k_pass1)
+    A.field_split = (latency_plan_on() && nsteps == 1 && o->N == 1024) ? 1 : 0;  // the frame-at-a-time plan (k_pass1)
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass1_n<NN>(A, tm, nsteps, st));
     if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pass1 launch: ") + hipGetErrorString(e));
