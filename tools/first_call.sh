@@ -28,3 +28,7 @@ for wl in ocean2048 ocean4096; do
   timeout 400 python bench.py --workload $wl --steps 128 --warmup 32 --no-cpu-baseline --no-latency 2> $out/$wl.err | tail -1 > $out/$wl.json
 done
 python tools/bench_summary.py $out/ocean2048.json $out/ocean4096.json
+# 4096^2 pass 2 with TWO rows per workgroup (4 waves, 76 KiB: two workgroups per CU like the 2048^2 plan; half-line reads and a halo row
+# per two rows against it) -- A/B against the 4-row plan, parity gate on (compiled 0 spills: 207 / 185 / 217 VGPRs)
+(bash tools/build_variant.sh r2x2_pf1 -DMW_R2_4096=2 > /dev/null 2>&1 & bash tools/build_variant.sh r2x2_pf0 -DMW_R2_4096=2 -DMW_PF_4096=0 > /dev/null 2>&1 & bash tools/build_variant.sh r2x2_pf0_he -DMW_R2_4096=2 -DMW_PF_4096=0 -DMW_HS_HALO_EARLY_4096=1 > /dev/null 2>&1 & wait)
+ABV_EXTRA="--no-latency" bash tools/abv.sh "ocean4096 32 256" base r2x2_pf1 r2x2_pf0 r2x2_pf0_he 2>&1 | tee $out/ab_r2x2_4096.txt
