@@ -30,6 +30,9 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "mistral-water_amd"))
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
+import memguard  # noqa: E402  host-memory cap (tests/memguard.py): a harness bug must end this process, not the GPU box
+memguard.install()
+
 import numpy as np  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)

@@ -16,6 +16,9 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "mistral-water_amd"))
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
+import memguard  # noqa: E402  host-memory cap for the whole test process (DESIGN.md "Incident")
+memguard.install()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
