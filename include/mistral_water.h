@@ -94,7 +94,11 @@ int32_t mw_ocean_batch_size(const mw_ocean* o);
 /* Run all subsequent work of this handle on an existing hipStream_t (e.g. torch's current stream).  The argument means
  * what it says: NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is by default), as in
  * the pond entry points.  A fresh handle runs on its own private non-blocking stream; mw_ocean_use_own_stream returns to
- * it.  Work already enqueued on the previous stream is waited for before the switch.                                */
+ * it.  Work already enqueued on the previous stream is waited for before the switch.
+ * LIFETIME CONTRACT: the stream belongs to the caller and must outlive its use by the handle -- call
+ * mw_ocean_use_own_stream (or mw_ocean_set_stream with another stream, or mw_ocean_destroy) BEFORE destroying it.  A
+ * destroyed hipStream_t is a dangling pointer to HIP; the library tolerates the error codes the runtime returns for one
+ * ("nothing pending") as a courtesy, but cannot make the use of a freed handle defined.                              */
 mw_status mw_ocean_set_stream(mw_ocean* o, void* hip_stream);
 mw_status mw_ocean_use_own_stream(mw_ocean* o);
 void* mw_ocean_get_stream(mw_ocean* o);

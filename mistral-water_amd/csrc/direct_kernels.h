@@ -274,8 +274,9 @@ static hipError_t czt_launch(const CztArgs& A, hipStream_t st) {
     k_czt<M, P, RW><<<dim3((A.rows + RW - 1) / RW, 5), dim3(RW * M / P), LB, st>>>(A);
     return hipGetLastError();
 }
+// ev (measurement hook): three events recorded before the spectrum kernel, before and after the two k_czt launches
 static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h0, const cf* h0c, float t, float* dv, float* dn, float* dw,
-                                      int white_stride, hipStream_t st) {
+                                      int white_stride, hipStream_t st, hipEvent_t* ev = nullptr) {
     CztState& z = d.czt;
     const int N = C.N;
     const unsigned nb = (unsigned)(((size_t)N * N + 127) / 128);
@@ -290,7 +291,9 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
         z.table_length = C.length;
         z.table_unit_width = C.unit_width;
     }
+    if (ev) hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(k_czt_spec, dim3(nb), dim3(128), 0, st, C, h0, h0c, t, z.F);
+    if (ev) hipEventRecord(ev[1], st);
     CztArgs A;
     A.w1 = z.w1; A.w2 = z.w2; A.Hh = z.Hh; A.TWf = z.TWf; A.TWi = z.TWi;
     A.N = N; A.rows = N; A.in_ld = N; A.out_ld = N; A.in_plane = (long long)N * N; A.out_plane = (long long)N * N;
@@ -310,6 +313,7 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
         }
     }
     if (e != hipSuccess) return e;
+    if (ev) hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_czt_assemble, dim3(nb), dim3(128), 0, st, C, z.O, d.hds, dv, dn);
     hipLaunchKernelGGL(k_direct_white, dim3(nb), dim3(128), 0, st, N, d.hds, dn, dw, white_stride);
     return hipGetLastError();
@@ -357,12 +361,7 @@ static inline hipError_t direct_gemm(const float* A, const float* B, float* C, i
 // ev (measurement hook, mw_ocean_profile_kernels): three events recorded before the spectrum kernel, before and after the GEMMs
 static inline hipError_t direct_evaluate(DirectState& d, OceanConsts C, const cf* h0, const cf* h0c, float t, float* dv,
                                          float* dn, float* dw, int white_stride, hipStream_t st, hipEvent_t* ev = nullptr) {
-    if (d.use_czt) {
-        if (ev) { hipEventRecord(ev[0], st); hipEventRecord(ev[1], st); }
-        const hipError_t e = czt_evaluate(d, C, h0, h0c, t, dv, dn, dw, white_stride, st);
-        if (ev) hipEventRecord(ev[2], st);
-        return e;
-    }
+    if (d.use_czt) return czt_evaluate(d, C, h0, h0c, t, dv, dn, dw, white_stride, st, ev);
     const int N = C.N, Np = d.Np;
     const unsigned nb = (unsigned)(((size_t)N * N + 127) / 128);
     const long long P2 = (long long)Np * Np;

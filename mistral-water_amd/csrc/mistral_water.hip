@@ -785,34 +785,17 @@ extern "C" {
 
 int32_t mw_abi_version(void) { return MW_ABI_VERSION; }
 
-// Identity of this build: FNV-1a 64 of the shared object's own bytes (hipcc is deterministic: same sources and flags ->
-// same file; a comment-only edit keeps the id) + the tag the build gave it (-DMW_BUILD_TAG, "default" for the in-tree .so).
+// Identity of this build, fixed AT BUILD TIME: -DMW_BUILD_HASH = SHA-256 (first 16 hex digits) over the kernel sources, the two
+// headers of the boundary and the compile flags, computed by the build recipe (mistral_water/_native.py::source_hash, the one
+// place that knows them; tools/build_variant.sh calls the same function) + the tag the build gave it (-DMW_BUILD_TAG, "default"
+// for the in-tree .so).  It names the code that is loaded, whatever happens to the file on disk afterwards.
 #ifndef MW_BUILD_TAG
 #define MW_BUILD_TAG "default"
 #endif
-const char* mw_build_id(void) {
-    static std::string id;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        Dl_info info;
-        unsigned long long h = 1469598103934665603ull;
-        bool ok = false;
-        if (dladdr(reinterpret_cast<const void*>(&mw_abi_version), &info) && info.dli_fname) {
-            if (FILE* f = std::fopen(info.dli_fname, "rb")) {
-                std::vector<unsigned char> buf(1 << 20);
-                size_t n;
-                while ((n = std::fread(buf.data(), 1, buf.size(), f)) > 0)
-                    for (size_t i = 0; i < n; i++) { h ^= buf[i]; h *= 1099511628211ull; }
-                std::fclose(f);
-                ok = true;
-            }
-        }
-        char hex[32];
-        std::snprintf(hex, sizeof hex, "%016llx", ok ? h : 0ull);
-        id = std::string(hex) + " " + MW_BUILD_TAG;
-    });
-    return id.c_str();
-}
+#ifndef MW_BUILD_HASH
+#define MW_BUILD_HASH "unhashed-build"
+#endif
+const char* mw_build_id(void) { return MW_BUILD_HASH " " MW_BUILD_TAG; }
 const char* mw_last_error(void) { return g_err.c_str(); }
 
 int32_t mw_device_count(void) {
@@ -1046,32 +1029,32 @@ mw_status mw_ocean_reinit_spectrum(mw_ocean* o, float length, float wind_x, floa
             return fail(MW_ESTATE, "mw_ocean_reinit_spectrum: the new length moves the grid between the FFT and the direct-sum path; "
                                    "create a new handle");
         const size_t NN = (size_t)N * N;
-        // Transactional: the new spectrum is generated into staging memory and the derived tables (PQt, omega) are built from
-        // there; h0 / h0conj are replaced only once that has succeeded.  On failure the tables are rebuilt from the untouched
-        // old spectrum with the old length, so the handle stays consistent either way.
-        void* buf = nullptr;
-        mw_status s = scratch_reserve(o, 2 * align256(NN * sizeof(cf)), &buf);
-        if (s != MW_OK) return s;
-        cf *n0 = static_cast<cf*>(buf), *n0c = reinterpret_cast<cf*>(static_cast<char*>(buf) + align256(NN * sizeof(cf)));
+        // Transactional: the new spectrum is generated into buffers of its own and the derived tables (PQt, omega) are rebuilt
+        // from there; the handle adopts the new buffers only once every step has succeeded (and frees the old ones), otherwise
+        // it keeps the old spectrum and rebuilds the tables from it with the old length.  No staging in `scratch`: another host
+        // entry point cannot clobber the new spectrum half-way.
+        cf *n0 = nullptr, *n0c = nullptr;
+        mw_status s = dmalloc(&n0, NN);
+        if (s == MW_OK) s = dmalloc(&n0c, NN);
+        if (s != MW_OK) { hipFree(n0); hipFree(n0c); return s; }
         hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, o->stream, N, length, wind_x, wind_y,
                            amplitude, o->p.gravity, seed, n0, n0c);
-        HIP_TRY(hipGetLastError());
+        hipError_t e = hipGetLastError();
         const float old_length = o->p.length;
         cf *old0 = o->h0, *old0c = o->h0c;
         o->p.length = length;  // run_prep reads it (omega table, S/FFTMesh.cs:141-147)
         o->h0 = n0; o->h0c = n0c;
-        s = run_prep(o);
-        o->h0 = old0; o->h0c = old0c;
-        hipError_t e = hipSuccess;
-        if (s == MW_OK) e = hipMemcpyAsync(o->h0, n0, NN * sizeof(cf), hipMemcpyDeviceToDevice, o->stream);
-        if (s == MW_OK && e == hipSuccess) e = hipMemcpyAsync(o->h0c, n0c, NN * sizeof(cf), hipMemcpyDeviceToDevice, o->stream);
+        if (e == hipSuccess) s = run_prep(o);
         if (s == MW_OK && e == hipSuccess) e = hipStreamSynchronize(o->stream);
         if (s != MW_OK || e != hipSuccess) {
+            o->h0 = old0; o->h0c = old0c;
             o->p.length = old_length;
-            (void)run_prep(o);  // best effort: tables back to (old spectrum, old length)
+            (void)run_prep(o);  // tables back to (old spectrum, old length); if the device is gone, the handle is too (MW_EDEVICE)
             (void)hipStreamSynchronize(o->stream);
+            hipFree(n0); hipFree(n0c);
             return s != MW_OK ? s : fail(MW_EDEVICE, std::string("mw_ocean_reinit_spectrum: ") + hipGetErrorString(e));
         }
+        hipFree(old0); hipFree(old0c);
     }
     o->p.length = length; o->p.wind_x = wind_x; o->p.wind_y = wind_y; o->p.amplitude = amplitude; o->p.seed = seed;
     HIP_TRY(hipStreamSynchronize(o->stream));
@@ -1297,7 +1280,9 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
     HIP_TRY(hipStreamSynchronize(o->stream));
     if (!o->use_fft) {  // direct-sum path: kernel 0 = the four GEMM launches of one step, kernel 1 = spectrum + assembly + whitecap
         if (nsteps != 1) return fail(MW_EINVAL, "mw_ocean_profile_kernels: the direct-sum path evaluates one step per enqueue");
-        static const char* dnames[2] = {"k_gemm_f32_mfma (4 launches: z sum, x sum)", "k_direct_spec + k_direct_assemble + k_direct_white"};
+        static const char* gnames[2] = {"k_gemm_f32_mfma (4 launches: z sum, x sum)", "k_direct_spec + k_direct_assemble + k_direct_white"};
+        static const char* znames[2] = {"k_czt (2 launches: chirp-z along j, along i)", "k_czt_spec + k_czt_assemble + k_direct_white"};
+        const char* const* dnames = o->direct.use_czt ? znames : gnames;
         hipEvent_t ev[4];
         for (auto& e : ev) hipEventCreate(&e);
         hipError_t he = hipSuccess;

@@ -59,6 +59,18 @@ BUILD_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 
 
+def source_hash(extra=()) -> str:
+    """What mw_build_id() reports (-DMW_BUILD_HASH): SHA-256 over the kernel sources, the boundary headers and the compile flags."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)) + [HEADER_PATH, HOOKS_HEADER_PATH]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update("\0".join(BUILD_FLAGS + list(extra)).encode())
+    return h.hexdigest()[:16]
+
+
 def build_native(force: bool = False, verbose: bool = False, out: str | None = None, extra=(), tag: str | None = None,
                  resource_report: str | None = None) -> str:
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU).
@@ -68,7 +80,7 @@ def build_native(force: bool = False, verbose: bool = False, out: str | None = N
     if (not force and not extra and os.path.exists(target)
             and all(os.path.getmtime(s) <= os.path.getmtime(target) for s in srcs)):
         return target
-    cmd = ["hipcc"] + BUILD_FLAGS + list(extra)
+    cmd = ["hipcc"] + BUILD_FLAGS + list(extra) + ['-DMW_BUILD_HASH="%s"' % source_hash(extra)]
     if tag:
         cmd.append('-DMW_BUILD_TAG="%s"' % tag)
     if resource_report:

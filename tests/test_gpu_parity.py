@@ -95,9 +95,10 @@ def test_fftmesh_survey_config2_literal_parameters(mw, oracle, N):
             workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"config literal {N}^2, t={t}", hds=hds)
 
 
-@pytest.mark.parametrize("N,u,L", [(64, 1.0, 64.0), (256, 0.5, 128.0), (512, 1.0, 512.0), (1024, 1.0, 1024.0), (2048, 1.0, 2048.0),
-                                   (4096, 1.0, 4096.0), (12, 1.0, 12.39), (33, 0.9, 33.0)])
-def test_whitecap_stage_bit_exact_on_device(mw, oracle, N, u, L):
+@pytest.mark.parametrize("N,u,L,literal", [(64, 1.0, 64.0, False), (256, 0.5, 128.0, False), (512, 1.0, 512.0, False), (1024, 1.0, 1024.0, False),
+                                           (2048, 1.0, 2048.0, False), (4096, 1.0, 4096.0, False), (12, 1.0, 12.39, False), (33, 0.9, 33.0, False),
+                                           (1024, 1.0, 1024.0, True), (4096, 1.0, 4096.0, True)])
+def test_whitecap_stage_bit_exact_on_device(mw, oracle, N, u, L, literal):
     """The Jacobian / whitecap stage (S/FFTMesh.cs:251-276) is index and sign work once hds and the normals exist: forward
     differences, the i = N-1 and j = N-1 edge rules, strict-float32 J, noise, SmoothStep.  With hds taken from the device
     (mw_debug_evaluate_hds) the device's colours must equal the oracle's float32 whitecap of the SAME hds and normals bit
@@ -105,6 +106,8 @@ def test_whitecap_stage_bit_exact_on_device(mw, oracle, N, u, L):
     also proves that a halo row handed to the previous workgroup is the very row its owner computed."""
     amp = 1.5e-8 * (1024.0 / N) ** 2 * u * u * 400.0          # steep enough that the mesh folds here and there
     p = oracle.Params(N=N, unit_width=u, length=L, wind_x=14.45, wind_y=12.0, amplitude=amp if N >= 64 else 0.01, choppiness=1.3)
+    if literal:      # SURVEY 8d configs 2 / 4 literally (amplitude 0.41: what bench.py times) -- a saturated whitecap, so the
+        p = workloads.fftmesh_config2(N)      # "stage is exercised" assertion below does not apply; bit equality does
     h0, h0c = oracle.generate_spectrum(p, 21)
     with make(mw, p) as o:
         o.set_spectrum(h0, h0c)
@@ -114,8 +117,10 @@ def test_whitecap_stage_bit_exact_on_device(mw, oracle, N, u, L):
             assert (c == want).all(), f"N={N} t={t}: {(c != want).sum()} colours differ"
             cc = c[:, 0].reshape(N, N)
             assert cc.min() >= 0 and cc.max() <= 1 + 2.0 ** -22    # -2t^3 + 3t^2 left to right in float32 can pass 1 by an ulp (:273)
-            if N >= 64:
+            if N >= 64 and not literal:
                 assert cc.max() > 0.1 and cc.min() < 0.05       # not a saturated or empty field: the stage is exercised
+            if literal:
+                assert 0.2 < cc.mean() < 0.8 and ((cc == 0) | (cc == 1)).mean() > 0.99      # both saturated values occur, in bulk
             # the hook runs a second instantiation of the same kernel templates (with the hds store compiled in): the same
             # values up to the compiler's choice of fused multiply-adds in the butterflies
             v2, n2, c2 = o.evaluate(t)

@@ -8,10 +8,11 @@ sys.path.insert(0, "tests"); sys.path.insert(0, "mistral-water_amd")
 import memguard
 print("mode", memguard.install(64))
 import numpy as np
+import torch; torch.cuda.init()      # PyTorch's bundled HIP runtime initialises first (INTEGRATION.md)
 import mistral_water as mw
 from mistral_water import FFTMesh
 m = FFTMesh(); m.resolution = 256; m.length = 256.0; m.unitWidth = 1.0; m.Awake(); m.Update(1.0 / 60)
-import torch; torch.zeros(8, device="cuda").sum().item()
+torch.zeros(8, device="cuda").sum().item()
 print("hip ok")
 try:
     a = np.ones(200 * 2**30 // 8); print("200 GB allocated and touched?!", a[-1])
