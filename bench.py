@@ -649,6 +649,30 @@ def direct(a, mw, torch, dev, stream, barrier, dist, rank, world):
                                       "what": "the same step as two complex128 matrix products through numpy/BLAS (oracle.eval_matmul_f64), all host cores"}}
     if rank == 0:
         v = world * a.steps * NN / el
+        czt = "k_czt" in kern[0][0]
+        step_ms = kern[0][1] + kern[1][1]
+        if czt:
+            # chirp-z form (csrc/czt_kernels.h; the default for N <= 2048): O(N^2 log N), memory-bound.  Algorithmic bytes per grid point by
+            # SURVEY 8d's general formula 16 + 16 F + out with F = 5 unpacked complex fields crossing between the two axis passes:
+            # 16 (h0, h0conj) + 80 (5 fields written + read once) + 28 (vertex, normal, whitecap) = 124 B.
+            bpp = 16 + 16 * 5 + 28
+            roof = {"bound": "hbm", "kernel": "k_czt (2 launches) + spectrum / assembly kernels = one step", "achieved": bpp * NN / (step_ms * 1e-3) / 1e9,
+                    "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bpp * NN / (step_ms * 1e-3) / HBM_PEAK, "traffic": None,
+                    "algorithmic_bytes_per_point": bpp, "bytes_per_launch_group": bpp * NN, "launch_group_us": step_ms * 1e3,
+                    "kernels": [{"name": nm, "us_per_step": ms * 1e3} for nm, ms in kern],
+                    "note": "achieved = 124 B x N^2 / the mean duration of one step's five launches (HIP events on the launch stream).  Small "
+                            "grids are launch-latency-bound (N = 50: five launches of a few workgroups), and up to N ~ 1500 the whole working "
+                            "set sits in the 256-MiB Infinity Cache: the fraction says how far one step is from streaming at HBM rate"}
+            path = f"chirp-z: two Stockham transforms of size {1 << max(6, (2 * N - 2).bit_length())} per line and axis (k_czt x 2)"
+        else:
+            roof = {"bound": "mfma", "kernel": "k_gemm_f32_mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
+                    "unit": "TFLOP/s", "frac": flops / (gemm_ms * 1e-3) / MFMA_F32_PEAK, "traffic": None,
+                    "flop_per_launch_group": flops, "algorithmic_flop_per_point": 60.0 * N, "launch_group_us": gemm_ms * 1e3,
+                    "executed_flop_padded": 60.0 * ((N + 63) // 64 * 64) ** 3,
+                    "kernels": [{"name": nm, "us_per_step": ms * 1e3} for nm, ms in kern],
+                    "note": "achieved = 60 N^3 algorithmic flop of one step / the mean duration of that step's four GEMM launches "
+                            "(HIP events on the launch stream); the GEMMs execute the zero-padded size"}
+            path = f"direct sum as 4 MFMA GEMM launches (MW_DIRECT_CZT=0 or N > 2048), operands padded to {(N + 63) // 64 * 64}"
         emit({
             "metric": f"FFTMesh direct-sum grid-points/sec (non-FFT grid, spectrum -> separable sum -> disp -> Jacobian), {N}^2 grid",
             "value": v, "unit": "grid-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
@@ -656,15 +680,8 @@ def direct(a, mw, torch, dev, stream, barrier, dist, rank, world):
             "config": {"workload": f"FFTMesh-semantics grid {N}x{N}, unit_width {p.unit_width:g}, length {p.length:g}, wind ({p.wind_x:g}, {p.wind_y:g}), "
                                    f"amplitude {p.amplitude:.3g}, choppiness {p.choppiness:g}: not FFT-expressible, one step per call "
                                    f"(SURVEY 8f rank 2; N = 50 is the reference's Inspector default, S/FFTMesh.cs:13-19)",
-                       "grid": N, "padded_grid": (N + 63) // 64 * 64, "semantics": "MW_SEM_FFTMESH", "path": "direct sum as 4 MFMA GEMM launches"},
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_f32_mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": flops / (gemm_ms * 1e-3) / MFMA_F32_PEAK, "traffic": None,
-                         "flop_per_launch_group": flops, "algorithmic_flop_per_point": 60.0 * N, "launch_group_us": gemm_ms * 1e3,
-                         "executed_flop_padded": 60.0 * ((N + 63) // 64 * 64) ** 3,
-                         "kernels": [{"name": nm, "us_per_step": ms * 1e3} for nm, ms in kern],
-                         "note": "achieved = 60 N^3 algorithmic flop of one step / the mean duration of that step's four GEMM launches "
-                                 "(HIP events on the launch stream); the GEMMs execute the zero-padded size"},
-            "parity": parity, "cpu_baseline": cpu})
+                       "grid": N, "semantics": "MW_SEM_FFTMESH", "path": path},
+            "roofline": roof, "parity": parity, "cpu_baseline": cpu})
     o.close()
 
 

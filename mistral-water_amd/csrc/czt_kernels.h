@@ -14,8 +14,8 @@
 // All chirps and the kernel's transform are formed in f64 on the host once per handle (they do not depend on t).
 //
 // Phase functions are MW_HD so that tests/emul steps the same code on the host (tests/test_emul.py::test_chirp_z_*).
-// STATUS (round 3): built and emulation-checked after GPU access ended; NOT yet run on hardware, therefore opt-in
-// (environment MW_DIRECT_CZT=1).  The default for these grids is the MFMA GEMM form (direct_kernels.h), green on the GPU.
+// STATUS (round 4): green on hardware at N = 12 ... 1000 and the default for every non-FFT grid with 2N - 1 <= 4096
+// (direct_alloc); the MFMA GEMM form (direct_kernels.h) serves larger grids and MW_DIRECT_CZT=0.
 #pragma once
 #include "fftmesh_kernels.h"
 

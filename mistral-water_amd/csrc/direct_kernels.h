@@ -20,7 +20,7 @@
 
 namespace mw {
 
-// chirp-z form (czt_kernels.h), opt-in until it has run on hardware: tables + the three complex work arrays
+// chirp-z form (czt_kernels.h; the default for N <= 2048): tables + the three complex work arrays
 struct CztState {
     int M = 0;
     cf *w1 = nullptr, *w2 = nullptr, *Hh = nullptr, *TWf = nullptr, *TWi = nullptr;
@@ -325,9 +325,11 @@ static inline void direct_free(DirectState& d) {
     d = DirectState();
 }
 static inline int direct_alloc(DirectState& d, int N, hipStream_t st) {
-    // MW_DIRECT_CZT=1: the chirp-z form (opt-in until it has run on hardware; needs 2N - 1 <= 4096)
+    // The chirp-z form is the default wherever one workgroup holds the transform (2N - 1 <= 4096, i.e. N <= 2048): first hardware
+    // run in round 4 -- 2.4x (N = 100) to 5.8x (N = 1000) faster than the GEMM form and an order of magnitude more accurate on
+    // grids with large phases (profiles/r04a_bench_direct_*).  MW_DIRECT_CZT=0 selects the GEMM form (A/B, and the path of larger N).
     const char* env = std::getenv("MW_DIRECT_CZT");
-    if (env && std::atoi(env) == 1 && czt_size(N) != 0) {
+    if (!(env && std::atoi(env) == 0) && czt_size(N) != 0) {
         if (czt_alloc(d.czt, N) != 0 || hipMalloc((void**)&d.hds, sizeof(cf) * (size_t)N * N) != hipSuccess) { direct_free(d); return 4; }
         d.N = N;
         d.use_czt = true;

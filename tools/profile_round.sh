@@ -5,10 +5,11 @@
 # the library is that build.  Memory guard: a host-side bug once took the GPU boxes down -- every python
 # process below runs under `timeout`, and nothing here allocates more than a few GB.
 tag=${1:-r04}
+mkdir -p gpurun_out/profiles_${tag}
 run() {  # run TAG WORKLOAD BATCH STEPS [extra bench args]: trace + PMC passes, then the summary under profiles/
   local name=$1 b=$3
   timeout 900 bash tools/prof_workload.sh "${tag}_${name}_b${b}" "$2" "$3" "$4" "${@:5}" > gpurun_out/prof_${tag}_${name}_b${b}.log 2>&1
-  python tools/summarize_profiles.py gpurun_out/prof_${tag}_${name}_b${b} profiles/${tag}_${name}_b${b} > /dev/null 2>&1 || echo "summary failed: ${name} b${b}"
+  python tools/summarize_profiles.py gpurun_out/prof_${tag}_${name}_b${b} gpurun_out/profiles_${tag}/${tag}_${name}_b${b} > /dev/null 2>&1 || echo "summary failed: ${name} b${b}"
 }
 run ocean1024 ocean1024 32 1600
 run ocean1024 ocean1024 20 1000          # the driver's --steps 20: one 20-step enqueue per launch
@@ -18,8 +19,9 @@ run pond pond 32 3200
 run renderer1024 renderer1024 1 2000
 run renderer1024 renderer1024 4 500 --tiles 4
 for n in 50 100 1000; do
-  timeout 300 python bench.py --workload direct --direct-n $n --steps 200 --warmup 20 2> gpurun_out/${tag}_direct_$n.err | tail -1 > profiles/${tag}_bench_direct_$n.json
+  timeout 300 python bench.py --workload direct --direct-n $n --steps 200 --warmup 20 2> gpurun_out/${tag}_direct_$n.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_direct_$n.json
 done
-timeout 300 python bench.py --steps 20 --warmup 5 2> gpurun_out/${tag}_bench_driver.err | tail -1 > profiles/${tag}_bench_ocean1024_driver_k20.json
-python tools/bench_summary.py profiles/${tag}_bench_direct_50.json profiles/${tag}_bench_direct_100.json profiles/${tag}_bench_direct_1000.json profiles/${tag}_bench_ocean1024_driver_k20.json
-ls profiles | grep "^${tag}_"
+timeout 300 python bench.py --steps 20 --warmup 5 2> gpurun_out/${tag}_bench_driver.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_ocean1024_driver_k20.json
+P=gpurun_out/profiles_${tag}; python tools/bench_summary.py $P/${tag}_bench_direct_50.json $P/${tag}_bench_direct_100.json $P/${tag}_bench_direct_1000.json $P/${tag}_bench_ocean1024_driver_k20.json
+ls gpurun_out/profiles_${tag}
+# back in the container: cp gpurun_out/profiles_${tag}/* profiles/   (only gpurun_out/ travels back from the GPU box)
