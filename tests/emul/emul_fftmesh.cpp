@@ -27,27 +27,7 @@ namespace {
 struct Tables {
     std::vector<cf> TW, Wpre;
     Tables(int N, int P, int sgn = +1) : Wpre(2 * N) {
-        const int T = N / P;
-        int S = 0;
-        long long PS = 1;
-        while (PS * P <= N) { PS *= P; S++; }
-        const int RL = (int)(N / PS);
-        for (int s = 1; s < S; s++) {
-            long long p = 1;
-            for (int i = 0; i < s; i++) p *= P;
-            for (long long k = 0; k < p; k++)
-                for (int r = 0; r < P + 1; r++) {
-                    double a = sgn * 2.0 * M_PI * (double)((r % P) * k) / (double)(p * P);
-                    TW.push_back(mk((float)cos(a), (float)sin(a)));
-                }
-        }
-        if (RL > 1)
-            for (int r = 0; r < RL; r++)
-                for (int u = 0; u < T; u++) {
-                    double a = sgn * 2.0 * M_PI * (double)(r * u) / (double)N;
-                    TW.push_back(mk((float)cos(a), (float)sin(a)));
-                }
-        if (TW.empty()) TW.push_back(mk(1.f, 0.f));
+        TW = build_twiddle_table_host(N, P, sgn);
         for (int m = 0; m < 2 * N; m++) {
             double a = M_PI * (double)m / (double)N;
             double sg = (m & 1) ? -1.0 : 1.0;
@@ -79,6 +59,42 @@ void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
                         stage_store<N, P, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, tw, s);
                 }
                 for (int tid = 0; tid < NT; tid++) p1_finish<N, P>(A, tw, jb, step, tid, f, st[tid].x, lds.data());
+            }
+        }
+}
+
+// k_pass1_wave (one wave per column), phase by phase
+template <int N>
+void run_pass1_wave(const P1Args& A, const StepTimes& tm, int nsteps) {
+    using G = P1WGeom<N>;
+    constexpr int NT = G::NTHREADS, T = G::T;
+    std::vector<cf> xch(G::CW * G::HBUF);
+    const Twiddles tw = TwGeom<N, 64>::view(A.TW);
+    struct St { cf x[64]; P1WRing ring; };
+    std::vector<St> st(NT);
+    auto fb = [&](int tid) { return reinterpret_cast<float*>(xch.data() + (tid / T) * G::HBUF); };
+    for (int step = 0; step < nsteps; step++)
+        for (int jb = 0; jb < G::GRID_X; jb++) {
+            const float t = tm.t[step];
+            for (int f = 0; f < 3; f++) {
+                if (!p1_field_active(N, jb, f, G::CW)) continue;
+                for (int tid = 0; tid < NT; tid++) {
+                    for (int c = 0; c < 64 / MW_P1W_CHUNK; c++) {  // the ring of landing registers: issue, consume, reuse the slot
+                        p1w_issue<N>(A, jb, tid, c, st[tid].ring);
+                        p1w_consume<N>(A, jb, tid, t, f, c, st[tid].ring, st[tid].x);
+                    }
+                    p1w_row0<N>(A, jb, tid, t, f, st[tid].x);
+                    dft64<+1>(st[tid].x);
+                }
+                for (int tid = 0; tid < NT; tid++) p1w_re_out(st[tid].x, tid % T, fb(tid));
+                for (int tid = 0; tid < NT; tid++) p1w_re_in(st[tid].x, tid % T, fb(tid));
+                for (int tid = 0; tid < NT; tid++) p1w_im_out(st[tid].x, tid % T, fb(tid));
+                for (int tid = 0; tid < NT; tid++) p1w_im_in(st[tid].x, tid % T, fb(tid));
+                for (int tid = 0; tid < NT; tid++) { twiddle_two_level(st[tid].x, tw.TS[1], tid % T, 64); dft64<+1>(st[tid].x); }
+                for (int h = 0; h < 2; h++) {
+                    for (int tid = 0; tid < NT; tid++) p1w_half_out<N>(st[tid].x, tid % T, h, xch.data() + (tid / T) * G::HBUF);
+                    for (int tid = 0; tid < NT; tid++) p1w_half_store<N>(A, jb, step, tid, f, h, xch.data());
+                }
             }
         }
 }
@@ -180,7 +196,8 @@ int evaluate_np(const OceanConsts& C, const cf* h0, const cf* h0c, const float* 
     A1.Cj0 = Cj0.data(); A1.E = E.data(); A1.c = C;
     StepTimes tm;
     for (int k = 0; k < nsteps; k++) tm.t[k] = times[k];
-    run_pass1<N, PA>(A1, tm, nsteps);
+    if constexpr (N == 4096 && PA == 64 && MW_P1_WAVE_4096) run_pass1_wave<N>(A1, tm, nsteps);
+    else run_pass1<N, PA>(A1, tm, nsteps);
     P2Args A2;
     A2.E = E.data(); A2.Cj0 = Cj0.data(); A2.TW = tb2.TW.data(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
     A2.white_stride = white_stride; A2.c = C;
@@ -200,6 +217,9 @@ int evaluate_n(int pts, const OceanConsts& C, const cf* h0, const cf* h0c, const
                float* normals, float* white, int white_stride) {
     if (pts == 0) return evaluate_np<N, Plan<N>::P1, Plan<N>::P2>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
     if (pts == 16) return evaluate_np<N, 16, 16>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
+    if constexpr (N == 4096) {  // one wave per column in pass 1 (64 points per lane), the 16-point pass 2
+        if (pts == 64) return evaluate_np<N, 64, 16>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
+    }
     if constexpr (N <= 1024) {
         if (pts == 8) return evaluate_np<N, 8, 8>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
     }
@@ -374,6 +394,7 @@ int emul_fft1d(int N, int pts, const float* in_xy, float* out_xy) {
 #define RUN(NN)                                              \
     case NN:                                                 \
         if (pts == 8) return fft1d_np<NN, 8>(in_xy, out_xy); \
+        if constexpr (NN == 4096) { if (pts == 64) return fft1d_np<NN, 64>(in_xy, out_xy); } \
         return fft1d_np<NN, 16>(in_xy, out_xy);
     switch (N) {
         RUN(64) RUN(128) RUN(256) RUN(512) RUN(1024) RUN(2048) RUN(4096)
