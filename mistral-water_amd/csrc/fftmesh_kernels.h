@@ -289,8 +289,7 @@ struct P1Geom {
     static constexpr int T = FftGeom<N, P>::T;
     static constexpr int CW = Exch<N>::CW;  // spectrum columns per workgroup
     static constexpr int NTHREADS = CW * T;
-    // P = 64 (one wave per column): the final read interleaves the 4 buffers in consecutive lanes, 8 consecutive n each: stride 8 mod 32
-    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + ((XLay<N, P>::EXACT || P == 64) ? XLay<N, P>::PAD_RD4 : MW_BUF_PAD);
+    static constexpr int BUFSTRIDE = FftGeom<N, P>::LBUF + (XLay<N, P>::EXACT ? XLay<N, P>::PAD_RD4 : MW_BUF_PAD);
     static constexpr int TW_LDS = (TwGeom<N, P>::LDS_ALL + 1) & ~1;  // cf units, 16-B aligned
     static constexpr int SETSTRIDE = CW * BUFSTRIDE;
     // 2: ping-pong exchange buffers, one barrier per exchange (when both sets fit a 100 KiB budget)
@@ -431,152 +430,6 @@ MW_HD void p1_finish(const P1Args& A, const Twiddles& tw, int jb, int step, int 
     const unsigned voff = (unsigned)(u2 * CW + w2);
 #pragma unroll
     for (int q = 0; q < P; q++) mw_store_stream<mw_nt_exchange(N)>(&(Ef + (size_t)T * q * CW)[voff], x[q]);
-}
-
-// ---- pass 1, ONE WAVE PER COLUMN (N = 4096, 64 points per lane; round 4) -----------------------------------------------------
-// A 4096-point column is two in-register 64-point transforms around ONE exchange, and a wave that owns the whole column can make
-// that exchange by itself: no workgroup barrier, the four waves of a workgroup (4 columns = whole 128-B lines of the exchange
-// buffer) drift apart, and two workgroups share a CU.  What makes two fit (a lone wave on a SIMD issues a VALU instruction only
-// every ~6 cycles, two waves every ~3: tools/valu_probe.hip, profiles/r04_valu_probe.txt):
-//   * the wave-local exchange goes through LDS as REAL parts, then IMAGINARY parts: 4160 floats (16.6 KiB) per wave instead of
-//     33 KiB; DS operations of one wave execute in order, so the imaginary parts can overwrite the real ones without a barrier;
-//   * the transposing exchange in front of the stores (the one exchange that crosses waves: 4 columns -> whole lines) runs in two
-//     halves of the column, a < N/2 then a >= N/2, each 2080 complex values per column -- the same 66.5 KiB;
-//   * the animated spectrum is re-formed per field (its rows come from L2) instead of living in 128 registers across the fields:
-//     the kernel fits 256 registers (arch + acc), two waves per SIMD.
-#ifndef MW_P1W_CHUNK
-#define MW_P1W_CHUNK 8  // points per load chunk of k_pass1_wave
-#endif
-#ifndef MW_P1W_DEPTH
-#define MW_P1W_DEPTH 4  // chunks in flight (5 landing registers per point: 160 at 4 x 8)
-#endif
-template <int N>
-struct P1WGeom {
-    static constexpr int P = 64, T = N / P, CW = Exch<N>::CW, NTHREADS = CW * T;
-    static constexpr int LBUF = N + N / P;                       // padded index n + n / 64: floats (wave-local) or cf of HALF a column
-    static constexpr int HBUF = LBUF / 2 + 8;                    // cf per column half in the transposing exchange (2088 = 8 mod 32: the
-                                                                 // column-interleaved read is conflict-free); wave w's float buffer of the
-                                                                 // local exchange (LBUF floats) is the SAME region as column w's half buffer
-    static constexpr int TW_LDS = (TwGeom<N, P>::LDS_ALL + 1) & ~1;  // cf units
-    static constexpr int LDS_BYTES = (TW_LDS + CW * HBUF) * 8;
-    static_assert(2 * HBUF >= LBUF, "the float buffer of the wave-local exchange must fit the column's half buffer");
-    static constexpr int GRID_X = N / CW + 1;
-    static_assert(T == 64, "one wave per column");
-};
-// The column's spectrum rows arrive in chunks of CH points through a DEPTH-deep ring of landing registers (5 per point): chunk
-// c + DEPTH is requested when chunk c has been animated, and the first DEPTH chunks of the NEXT field (the same rows: only the
-// multiplier differs) are requested before the current field's last stores, so that they do not queue behind them (vmcnt is in
-// order) -- the requests that a lone chunk-by-chunk loop left exposed 8 times per field (cycle stamps, profiles/r04_p1wave_notes.md).
-struct P1WRing {
-    f4 pq[MW_P1W_DEPTH][MW_P1W_CHUNK];
-    float om[MW_P1W_DEPTH][MW_P1W_CHUNK];
-};
-template <int N>
-MW_HD void p1w_issue(const P1Args& A, int jb, int tid, int c, P1WRing& R) {  // c compile-time after unrolling
-    constexpr int T = N / 64, CW = Exch<N>::CW, CH = MW_P1W_CHUNK;
-    const int w = wave_uniform<true>(tid / T), u = tid % T;
-    const bool fix = (jb == N / CW);
-    const int j = fix ? 0 : CW * jb + w;
-    const f4* __restrict__ pqrow = fix ? A.dPQ_j0 : A.PQt + (size_t)j * N;
-    const float* __restrict__ omrow = A.Om + (size_t)j * N;
-#pragma unroll
-    for (int i = 0; i < CH; i++) {
-        R.pq[c % MW_P1W_DEPTH][i] = (pqrow + T * (CH * c + i))[(unsigned)u];
-        R.om[c % MW_P1W_DEPTH][i] = (omrow + T * (CH * c + i))[(unsigned)u];
-    }
-}
-// animated spectrum times the field's multiplier for the CH points of chunk c (p1_animate + p1_build of the 16-point plan)
-template <int N>
-MW_HD void p1w_consume(const P1Args& A, int jb, int tid, float t, int f, int c, const P1WRing& R, cf (&x)[64]) {
-    constexpr int T = N / 64, CW = Exch<N>::CW, CH = MW_P1W_CHUNK;
-    const int w = wave_uniform<true>(tid / T), u = tid % T;
-    const bool fix = (jb == N / CW);
-    const int j = fix ? 0 : CW * jb + w;
-    const bool live = !fix || w == 0;
-    const float kscale = 2.0f * MW_PI_F / A.c.length;
-    const float kz = wave_k_fast(N, kscale, j);
-    const float fx = fix ? 0.f : 1.f;  // the Nyquist-column job keeps only the cz part
-#pragma unroll
-    for (int i = 0; i < CH; i++) {
-        const int q = CH * c + i;
-        const f4 pq = R.pq[c % MW_P1W_DEPTH][i];
-        float s, cs;
-        mw_sincos(smul(R.om[c % MW_P1W_DEPTH][i], t), &s, &cs);  // omega*t: one f32 multiply, S/FFTMesh.cs:183
-        cf h = animate(pq.x, pq.y, pq.z, pq.w, cs, s);
-        h = live ? h : mk(0.f, 0.f);
-        cf cx, cz;
-        field_coeffs(f == 0 ? 2 : f, wave_k_fast(N, kscale, u + T * q), kz, &cx, &cz);
-        cf m = (mw_split_slopes(N) == 1 && f == 2) ? (fix ? cz : cx) : (cscale(cx, fx) + cz);  // regular column of the slope field: G only
-        x[q] = (f == 0) ? h : cmul(m, h);
-    }
-}
-// element i = 0 of the column: the row-Nyquist correction (P1State::dl0 of the 16-point plan), lane 0 only
-template <int N>
-MW_HD void p1w_row0(const P1Args& A, int jb, int tid, float t, int f, cf (&x)[64]) {
-    constexpr int T = N / 64, CW = Exch<N>::CW;
-    const int w = tid / T, u = tid % T;
-    const bool fix = (jb == N / CW);
-    if (f == 0 || u != 0 || fix) return;
-    const int j = CW * jb + w;
-    const float kscale = 2.0f * MW_PI_F / A.c.length;
-    const f4 d = A.dPQ_i0[j];
-    float s, c;
-    mw_sincos(smul(A.Om[(size_t)j * N], t), &s, &c);
-    cf cx, cz;
-    field_coeffs(f, wave_k_fast(N, kscale, 0), wave_k_fast(N, kscale, j), &cx, &cz);
-    x[0] = x[0] + cmul(cx, animate(d.x, d.y, d.z, d.w, c, s));
-}
-// wave-local exchange, one component at a time: real parts out (slot r of lane u = element 64 u + r -> padded index 65 u + r: lane
-// stride 65 floats, conflict-free), real parts back in the transposed order (lane u, slot q = element u + 64 q -> 65 q + u), then the
-// same for the imaginary parts through the same floats.  Between the steps the CALLER orders the wave's own LDS accesses
-// (mw_wave_sync: DS operations of one wave execute in order; the fence only keeps the compiler from reordering them).
-MW_HD void p1w_re_out(const cf (&x)[64], int u, float* buf) {
-#pragma unroll
-    for (int r = 0; r < 64; r++) buf[65 * u + r] = x[r].x;
-}
-MW_HD void p1w_re_in(cf (&x)[64], int u, const float* buf) {
-#pragma unroll
-    for (int q = 0; q < 64; q++) x[q].x = buf[65 * q + u];
-}
-MW_HD void p1w_im_out(const cf (&x)[64], int u, float* buf) {
-#pragma unroll
-    for (int r = 0; r < 64; r++) buf[65 * u + r] = x[r].y;
-}
-MW_HD void p1w_im_in(cf (&x)[64], int u, const float* buf) {
-#pragma unroll
-    for (int q = 0; q < 64; q++) x[q].y = buf[65 * q + u];
-}
-MW_HD void mw_wave_sync() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#endif
-}
-// transposing exchange, half h of the column (elements a = u + 64 r, r in [32 h, 32 h + 32)): natural order into this column's
-// half buffer ...
-template <int N>
-MW_HD void p1w_half_out(const cf (&x)[64], int u, int h, cf* hbuf) {
-#pragma unroll
-    for (int r = 0; r < 32; r++) hbuf[65 * r + u] = x[32 * h + r];  // local element u + 64 r -> padded index (u + 64 r) + r
-}
-// ... and back in the column-interleaved mapping (lane: column w2 = tid % 4, rows u2 = tid / 4 + 64 q), then whole lines to E / Cj0
-template <int N>
-MW_HD void p1w_half_store(const P1Args& A, int jb, int step, int tid, int f, int h, const cf* lds_h) {
-    constexpr int CW = Exch<N>::CW, T = 64;
-    const int w2 = tid % CW, u2 = tid / CW;
-    const cf* __restrict__ b = lds_h + w2 * P1WGeom<N>::HBUF + u2;
-    if (jb == N / CW) {
-        if (w2 == 0) {
-            cf* C = A.Cj0 + ((size_t)step * 3 + f) * N + (size_t)h * (N / 2);
-#pragma unroll
-            for (int q = 0; q < 32; q++) C[u2 + T * q] = b[65 * q];
-        }
-        return;
-    }
-    cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)jb * N * CW + (size_t)h * (N / 2) * CW;  // block-uniform
-    const unsigned voff = (unsigned)(u2 * CW + w2);
-#pragma unroll
-    for (int q = 0; q < 32; q++) mw_store_stream<mw_nt_exchange(N)>(&(Ef + (size_t)T * q * CW)[voff], b[65 * q]);
 }
 
 // =============================== pass 2: transform along j + epilogue ========================
@@ -1050,16 +903,6 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 #ifndef MW_PT1
 #define MW_PT1 16  // pass 1: 16 points/thread (one exchange fewer; 125 VGPRs, 4 workgroups of 4 waves per CU) measured 1 % ahead of 8
 #endif
-// 4096^2 pass 1: 64 points per lane = ONE WAVE PER COLUMN (round 4).  The 16-point plan is one 1024-thread, 137-KiB workgroup per
-// CU whose 16 waves walk through load / VALU / LDS / store phases in lock step behind 7 workgroup barriers per field (0.42 of the
-// HBM peak, round 3).  With 64 points per lane a column is two in-register 64-point transforms around ONE wave-local exchange
-// (+ the transposing exchange of the stores): the four waves of a workgroup drift apart, and so do the workgroups of the chip.
-#ifndef MW_PT1_4096
-#define MW_PT1_4096 64
-#endif
-#ifndef MW_P1_WAVE_4096
-#define MW_P1_WAVE_4096 1  // 1: k_pass1_wave (split exchanges, two workgroups per CU); 0 with MW_PT1_4096 = 64: the generic kernel at 64 points
-#endif
 #ifndef MW_PT2
 #define MW_PT2 MW_PT  // pass 2 (the exchange-buffer layout does not depend on P, so the passes may differ)
 #endif
@@ -1126,7 +969,7 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 #endif
 template <int N> struct Plan {
     static constexpr int P = (N >= 2048) ? 16 : MW_PT_OR;  // OceanRenderer passes
-    static constexpr int P1 = (N >= 4096) ? MW_PT1_4096 : ((N >= 2048) ? 16 : MW_PT1);  // 5 x N/8 threads would exceed 1024 at N = 2048
+    static constexpr int P1 = (N >= 2048) ? 16 : MW_PT1;  // 5 x N/8 threads would exceed 1024 at N = 2048
     static constexpr int P2 = (N >= 4096) ? MW_PT2_4096 : (N == 2048 ? MW_PT2_2048 : (N == 1024 ? MW_PT2_1024 : MW_PT2));
     static constexpr bool HS = (N >= 4096) ? (MW_HS_4096 != 0) : (N == 2048 ? (MW_HS_2048 != 0) : (N == 1024 ? (MW_HS_1024 != 0) : false));
     static constexpr int R2 = (N >= 4096) ? MW_R2_4096 : (N == 2048 ? MW_R2_2048 : (N == 1024 ? MW_R2_1024 : ((N <= MW_R2_SMALL_N) ? 8 : 4)));

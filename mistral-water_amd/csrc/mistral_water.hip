@@ -113,7 +113,7 @@ __device__ __forceinline__ void stage_twiddles(cf* dst, const cf* __restrict__ s
 // columns x T); a workgroup of 4*T/VT lanes runs virtual threads tid, tid + NT, ... of every phase back to back.
 template <int N, int P, int VT>
 __global__ __launch_bounds__((P1Geom<N, P>::NTHREADS / VT))
-__attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : (P == 8 ? MW_WAVES_P1 : (P == 64 ? 1 : 4))))) void k_pass1(P1Args A, StepTimes times) {
+__attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : (P == 8 ? MW_WAVES_P1 : 4)))) void k_pass1(P1Args A, StepTimes times) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = P1Geom<N, P>;
     cf* lds = reinterpret_cast<cf*>(smem);
@@ -192,93 +192,6 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
 #undef MW_VT
 #undef MW_BUF
 #undef MW_U
-}
-
-// Pass 1 with one wave per column (fftmesh_kernels.h "ONE WAVE PER COLUMN"): 256 lanes = 4 columns, 64 points per lane, two
-// workgroups per CU.  Per field: spectrum x multiplier -> dft64 -> wave-local exchange (real, then imaginary parts) -> twiddles ->
-// dft64 -> the column's two halves through the transposing exchange to whole 128-B lines.  Four workgroup barriers per field, all
-// around the transposing exchange; none inside the transform.
-template <int N>
-__global__ __launch_bounds__((P1WGeom<N>::NTHREADS)) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pass1_wave(P1Args A, StepTimes times) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using G = P1WGeom<N>;
-    constexpr int P = 64, T = G::T;
-    cf* lds = reinterpret_cast<cf*>(smem);
-    const int tid = threadIdx.x;
-    int jb = blockIdx.x, step = blockIdx.y;
-    if (A.tgroup > 0 && !p1_block_map((int)blockIdx.x, G::GRID_X, A.nsteps, A.tgroup, &jb, &step)) return;
-    const float t = times.t[step];
-    MW_STAMP(0, 0);
-    stage_twiddles<N, P, G::NTHREADS>(lds, A.TW, tid);  // visible after the first barrier below
-    const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
-    cf* xch = lds + G::TW_LDS;
-    const int w = wave_uniform<true>(tid / T), u = tid % T;
-    cf* hbuf = xch + w * G::HBUF;
-    float* fbuf = reinterpret_cast<float*>(hbuf);
-    cf x[P];
-    constexpr int CH = MW_P1W_CHUNK, DEPTH = MW_P1W_DEPTH, NCH = P / CH;
-    P1WRing ring;
-    // fields of this workgroup: {1} or {0, 1, 2} (block-uniform: height and slopes are stored for the columns j <= N/2 only)
-    int f = p1_field_active(N, jb, 0, G::CW) ? 0 : 1;
-#ifndef MW_P1W_XPREFETCH
-#define MW_P1W_XPREFETCH 1
-#endif
-    if (MW_P1W_XPREFETCH) {
-#pragma unroll
-        for (int c = 0; c < DEPTH; c++) p1w_issue<N>(A, jb, tid, c, ring);
-    }
-#pragma unroll 1  // a rolled loop: one copy of the field's code (unrolled, the three copies spilled 236 dwords)
-    while (f < 3) {
-        MW_STAMP(0, 1 + 8 * f);
-        if (!MW_P1W_XPREFETCH) {
-#pragma unroll
-            for (int c = 0; c < DEPTH; c++) p1w_issue<N>(A, jb, tid, c, ring);
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            mw_sched_fence();
-            p1w_consume<N>(A, jb, tid, t, f, c, ring, x);
-            mw_sched_fence();
-            if (c + DEPTH < NCH) p1w_issue<N>(A, jb, tid, c + DEPTH, ring);
-        }
-        mw_sched_fence();
-        p1w_row0<N>(A, jb, tid, t, f, x);
-        MW_STAMP(0, 2 + 8 * f);
-        dft64<+1>(x);
-        MW_STAMP(0, 3 + 8 * f);
-        __syncthreads();  // the previous field's transposed reads of this region are done (first field: the twiddle tables are staged)
-        MW_STAMP(0, 4 + 8 * f);
-        p1w_re_out(x, u, fbuf);
-        mw_wave_sync();
-        p1w_re_in(x, u, fbuf);
-        mw_wave_sync();
-        p1w_im_out(x, u, fbuf);
-        mw_wave_sync();
-        p1w_im_in(x, u, fbuf);
-        mw_wave_sync();
-        MW_STAMP(0, 5 + 8 * f);
-        twiddle_two_level(x, tw.TS[1], u, P);
-        dft64<+1>(x);
-        MW_STAMP(0, 6 + 8 * f);
-        p1w_half_out<N>(x, u, 0, hbuf);
-        __syncthreads();
-        MW_STAMP(0, 7 + 8 * f);
-        p1w_half_store<N>(A, jb, step, tid, f, 0, xch);
-        __syncthreads();  // every wave has read half 0
-        p1w_half_out<N>(x, u, 1, hbuf);
-        __syncthreads();
-        const int fn = (f + 1 < 3 && p1_field_active(N, jb, f + 1, G::CW)) ? f + 1 : 3;
-        if (MW_P1W_XPREFETCH && fn < 3) {  // the next field's first chunks, requested AHEAD of this field's last stores
-            mw_sched_fence();
-#pragma unroll
-            for (int c = 0; c < DEPTH; c++) p1w_issue<N>(A, jb, tid, c, ring);
-            mw_sched_fence();
-        }
-        p1w_half_store<N>(A, jb, step, tid, f, 1, xch);
-        MW_STAMP(0, 8 + 8 * f);
-        f = fn;
-    }
-    MW_STAMP(0, 26);
 }
 
 #ifndef MW_XCD_GROUP
@@ -710,17 +623,6 @@ static bool latency_plan_on() {
 // ---- kernel dispatch over N ----------------------------------------------------------------------
 template <int N>
 static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nsteps, hipStream_t st) {
-    if constexpr (N == 4096 && MW_PT1_4096 == 64 && MW_P1_WAVE_4096) {  // one wave per column
-        using G = P1WGeom<N>;
-        static AttrOnce attrw;
-        hipError_t e = attrw.set(reinterpret_cast<const void*>(&k_pass1_wave<N>), G::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        if (A.tgroup > 0)
-            k_pass1_wave<N><<<dim3(p1_grid_blocks(G::GRID_X, nsteps, A.tgroup)), dim3(G::NTHREADS), G::LDS_BYTES, st>>>(A, tm);
-        else
-            k_pass1_wave<N><<<dim3(G::GRID_X, nsteps), dim3(G::NTHREADS), G::LDS_BYTES, st>>>(A, tm);
-        return hipGetLastError();
-    }
     constexpr int P = Plan<N>::P1, VT = Plan<N>::VT1;
     static AttrOnce attr;  // per device: the attribute belongs to the function on the current device
     {

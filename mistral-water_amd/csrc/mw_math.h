@@ -276,51 +276,6 @@ MW_HD void dft16(cf (&x)[16]) {
     for (int k = 0; k < 16; k++) x[k] = y[k];
 }
 
-// 64-point transform in registers (one wave per 4096-point line: 64 points per lane, Plan<4096>): 8 x 8, the 49 inner twiddles
-// e^{SGN 2 pi i m/64} compile-time constants (multiples of 4 fall back to the rotations of tw16).
-MW_HD constexpr float mw_cos64(int m) {  // cos(2 pi m / 64), m in [0, 64)
-    constexpr float C[17] = {1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f,
-                             8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f,
-                             3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 0.0f};
-    m &= 63;
-    return m <= 16 ? C[m] : (m <= 32 ? -C[32 - m] : (m <= 48 ? -C[m - 32] : C[64 - m]));
-}
-template <int SGN>
-MW_HD cf tw64(cf a, int m) {  // a * e^{SGN 2 pi i m/64}, m compile-time after unrolling
-    m &= 63;
-    if ((m & 3) == 0) return tw16<SGN>(a, m >> 2);
-    return cmul(a, mk(mw_cos64(m), SGN * mw_cos64(m + 48)));  // sin(x) = cos(x - pi/2): index m - 16 = m + 48 (mod 64)
-}
-template <int SGN>
-MW_HD void dft64(cf (&x)[64]) {
-    // n = 8 n1 + n2 ; X[k1 + 8 k2]
-#pragma unroll
-    for (int n2 = 0; n2 < 8; n2++) {  // A[n2][k1] = sum_n1 x[n2 + 8 n1] W8^(n1 k1), left at x[n2 + 8 k1]
-        cf y[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) y[i] = x[n2 + 8 * i];
-        dft8<SGN>(y);
-#pragma unroll
-        for (int i = 0; i < 8; i++) x[n2 + 8 * i] = y[i];
-    }
-#pragma unroll
-    for (int n2 = 1; n2 < 8; n2++)
-#pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) x[n2 + 8 * k1] = tw64<SGN>(x[n2 + 8 * k1], n2 * k1);
-    cf z[64];
-#pragma unroll
-    for (int k1 = 0; k1 < 8; k1++) {  // X[k1 + 8 k2] = sum_n2 (A W64^(n2 k1)) W8^(n2 k2)
-        cf y[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) y[i] = x[8 * k1 + i];
-        dft8<SGN>(y);
-#pragma unroll
-        for (int k2 = 0; k2 < 8; k2++) z[k1 + 8 * k2] = y[k2];
-    }
-#pragma unroll
-    for (int k = 0; k < 64; k++) x[k] = z[k];
-}
-
 // ---- Stockham autosort passes, P points per thread (P = 8 or 16) -------------------------------
 // An N-point transform is carried by T = N/P threads; thread u keeps element u + T*q in slot q before
 // AND after the whole transform.  Passes: S radix-P passes (p = 1, P, P^2, ...) and, when P^S < N, a
@@ -331,7 +286,6 @@ MW_HD void dft64(cf (&x)[64]) {
 template <int P> struct LogP;
 template <> struct LogP<8> { static constexpr int v = 3; };
 template <> struct LogP<16> { static constexpr int v = 4; };
-template <> struct LogP<64> { static constexpr int v = 6; };
 
 constexpr int mw_full_stages(int N, int P) { int s = 0; long long m = 1; while (m * P <= N) { m *= P; s++; } return s; }
 constexpr int mw_ipow(int P, int s) { int m = 1; for (int i = 0; i < s; i++) m *= P; return m; }
@@ -391,10 +345,6 @@ template <int SGN> struct DftP<16, SGN> {
     static MW_HD void run(cf (&x)[16]) { dft16<SGN>(x); }
     static MW_HD cf rot(cf a, int m) { return tw16<SGN>(a, m); }
 };
-template <int SGN> struct DftP<64, SGN> {
-    static MW_HD void run(cf (&x)[64]) { dft64<SGN>(x); }
-    static MW_HD cf rot(cf a, int m) { return tw64<SGN>(a, m); }
-};
 
 // Twiddle tables (built on the host in double, rounded once to f32; SGN baked in):
 //   TS[s][k*(P+1) + r] = e^{SGN 2 pi i r k / P^(s+1)}   k < P^s, r < P   (radix-P pass s >= 1, p = P^s)
@@ -417,19 +367,14 @@ struct Twiddles {
 template <int N, int P>
 struct TwGeom {
     static constexpr int S = FftGeom<N, P>::S;
-    // P = 64 (one wave per line): a row of 63 twiddles per lane would be a 33-KiB table read with a 520-byte lane stride.  Instead
-    // TWO-LEVEL tables: e^{SGN 2 pi i r k / P^(s+1)} = A[k][r >> 3] * B[k][r & 7],  A[k][a] = e^{.. 8 a k ..},  B[k][b] = e^{.. b k ..}
-    // (rows 9 apart: conflict-free b64 reads across a wave), 2 x 9 p entries per pass -- 9 KiB at N = 4096, all of it in LDS; a
-    // lane reads 14 values and forms each twiddle with one product.
-    static constexpr bool TWO_LEVEL = (P == 64);
-    static constexpr int size_ts(int s) { return (s >= 1 && s < S) ? (TWO_LEVEL ? 2 * 9 * mw_ipow(P, s) : mw_ipow(P, s) * (P + 1)) : 0; }
+    static constexpr int size_ts(int s) { return (s >= 1 && s < S) ? mw_ipow(P, s) * (P + 1) : 0; }
     static constexpr int OFF1 = 0;
     static constexpr int OFF2 = OFF1 + size_ts(1);
     static constexpr int OFF3 = OFF2 + size_ts(2);
     static constexpr int OFFF = OFF3 + size_ts(3);
     static constexpr int SIZE_TF = (FftGeom<N, P>::RL > 1) ? FftGeom<N, P>::T * FftGeom<N, P>::RL : 0;
     static constexpr int TOTAL = OFFF + SIZE_TF;
-    static constexpr int LDS_BUDGET_CF = TWO_LEVEL ? 2048 : 1024;  // 8 KiB (16 with the two-level tables of P = 64)
+    static constexpr int LDS_BUDGET_CF = 1024;  // 8 KiB
     static constexpr int LDS_CF = TOTAL <= LDS_BUDGET_CF ? TOTAL
                                   : (OFFF <= LDS_BUDGET_CF ? OFFF : (OFF3 <= LDS_BUDGET_CF ? OFF3 : (OFF2 <= LDS_BUDGET_CF ? OFF2 : 0)));
     static constexpr bool IN_LDS = (LDS_CF == TOTAL);  // the whole table is staged
@@ -522,19 +467,6 @@ MW_HD void load_slots(cf (&x)[P], int u, const cf* buf, int e) {
         for (int q = 0; q < P; q++) x[q] = buf[lds_pad<P>(u + T * q)];
     }
 }
-// x[r] *= e^{SGN 2 pi i r k / (64 p)} from the two-level tables of TwGeom<N, 64> (A rows, then B rows, 9 entries each)
-MW_HD void twiddle_two_level(cf (&x)[64], const cf* __restrict__ tab, int k, int p) {
-    const cf* __restrict__ ta = tab + k * 9;
-    const cf* __restrict__ tb = ta + 9 * p;
-    cf wa[8], wb[8];
-#pragma unroll
-    for (int i = 1; i < 8; i++) { wa[i] = ta[i]; wb[i] = tb[i]; }
-#pragma unroll
-    for (int r = 1; r < 64; r++) {
-        const cf w = (r >> 3) == 0 ? wb[r & 7] : ((r & 7) == 0 ? wa[r >> 3] : cmul(wa[r >> 3], wb[r & 7]));
-        x[r] = cmul(x[r], w);
-    }
-}
 // radix-P pass s (1 <= s < S): p = P^s
 // ALLOW_POW = false keeps the table in every pass (the OceanRenderer kernels: their finite-difference normal amplifies
 // transform rounding at ill-conditioned texels, and a frame is latency- not throughput-bound anyway)
@@ -544,7 +476,7 @@ template <int N, int P, int SGN, bool ALLOW_POW = true>
 MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
     const int p = 1 << (LogP<P>::v * s);
     const int k = u & (p - 1);
-    const cf* __restrict__ row = tw.TS[s] + (TwGeom<N, P>::TWO_LEVEL ? 0 : k * (P + 1));
+    const cf* __restrict__ row = tw.TS[s] + k * (P + 1);
 #ifdef MW_TW_POWERS
     constexpr bool POWERS = true;  // experiment: every pass by powers (+1 % step time at 1024^2: 24 VALU for 6 saved reads)
 #else
@@ -568,9 +500,7 @@ MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
         }
     } else
 #endif
-    if (TwGeom<N, P>::TWO_LEVEL) {
-        if constexpr (P == 64) twiddle_two_level(x, tw.TS[s], k, p);
-    } else if (POWERS) {  // one table read per thread, the other P-2 twiddles as its powers (product tree <= log2 P deep)
+    if (POWERS) {  // one table read per thread, the other P-2 twiddles as its powers (product tree <= log2 P deep)
         cf w[P];
         w[1] = tw.PW ? tw.PW[k] : row[1];
 #pragma unroll
@@ -657,12 +587,6 @@ inline std::vector<cf> build_twiddle_table_host(int N, int P, int sgn) {
     for (int s = 1; s < S; s++) {
         long long p = 1;
         for (int i = 0; i < s; i++) p *= P;
-        if (P == 64) {  // two-level tables (TwGeom::TWO_LEVEL): A[k][a] = e^{8 a k}, then B[k][b] = e^{b k}, rows of 9
-            for (int lvl = 0; lvl < 2; lvl++)
-                for (long long k = 0; k < p; k++)
-                    for (int a = 0; a < 9; a++) push((double)((lvl == 0 ? 8 : 1) * (a % 8) * k), (double)(p * P));
-            continue;
-        }
         for (long long k = 0; k < p; k++)
             for (int r = 0; r < P + 1; r++) push((double)((r % P) * k), (double)(p * P));  // row stride P+1 (one pad entry): see Twiddles
     }

@@ -63,42 +63,6 @@ void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
         }
 }
 
-// k_pass1_wave (one wave per column), phase by phase
-template <int N>
-void run_pass1_wave(const P1Args& A, const StepTimes& tm, int nsteps) {
-    using G = P1WGeom<N>;
-    constexpr int NT = G::NTHREADS, T = G::T;
-    std::vector<cf> xch(G::CW * G::HBUF);
-    const Twiddles tw = TwGeom<N, 64>::view(A.TW);
-    struct St { cf x[64]; P1WRing ring; };
-    std::vector<St> st(NT);
-    auto fb = [&](int tid) { return reinterpret_cast<float*>(xch.data() + (tid / T) * G::HBUF); };
-    for (int step = 0; step < nsteps; step++)
-        for (int jb = 0; jb < G::GRID_X; jb++) {
-            const float t = tm.t[step];
-            for (int f = 0; f < 3; f++) {
-                if (!p1_field_active(N, jb, f, G::CW)) continue;
-                for (int tid = 0; tid < NT; tid++) {
-                    for (int c = 0; c < 64 / MW_P1W_CHUNK; c++) {  // the ring of landing registers: issue, consume, reuse the slot
-                        p1w_issue<N>(A, jb, tid, c, st[tid].ring);
-                        p1w_consume<N>(A, jb, tid, t, f, c, st[tid].ring, st[tid].x);
-                    }
-                    p1w_row0<N>(A, jb, tid, t, f, st[tid].x);
-                    dft64<+1>(st[tid].x);
-                }
-                for (int tid = 0; tid < NT; tid++) p1w_re_out(st[tid].x, tid % T, fb(tid));
-                for (int tid = 0; tid < NT; tid++) p1w_re_in(st[tid].x, tid % T, fb(tid));
-                for (int tid = 0; tid < NT; tid++) p1w_im_out(st[tid].x, tid % T, fb(tid));
-                for (int tid = 0; tid < NT; tid++) p1w_im_in(st[tid].x, tid % T, fb(tid));
-                for (int tid = 0; tid < NT; tid++) { twiddle_two_level(st[tid].x, tw.TS[1], tid % T, 64); dft64<+1>(st[tid].x); }
-                for (int h = 0; h < 2; h++) {
-                    for (int tid = 0; tid < NT; tid++) p1w_half_out<N>(st[tid].x, tid % T, h, xch.data() + (tid / T) * G::HBUF);
-                    for (int tid = 0; tid < NT; tid++) p1w_half_store<N>(A, jb, step, tid, f, h, xch.data());
-                }
-            }
-        }
-}
-
 static bool g_force_hs = false;  // emul_set_variant: run the sequential-halo pass 2 regardless of Plan<N>::HS
 
 template <int N, int P, int R2>
@@ -196,8 +160,7 @@ int evaluate_np(const OceanConsts& C, const cf* h0, const cf* h0c, const float* 
     A1.Cj0 = Cj0.data(); A1.E = E.data(); A1.c = C;
     StepTimes tm;
     for (int k = 0; k < nsteps; k++) tm.t[k] = times[k];
-    if constexpr (N == 4096 && PA == 64 && MW_P1_WAVE_4096) run_pass1_wave<N>(A1, tm, nsteps);
-    else run_pass1<N, PA>(A1, tm, nsteps);
+    run_pass1<N, PA>(A1, tm, nsteps);
     P2Args A2;
     A2.E = E.data(); A2.Cj0 = Cj0.data(); A2.TW = tb2.TW.data(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
     A2.white_stride = white_stride; A2.c = C;
@@ -217,9 +180,6 @@ int evaluate_n(int pts, const OceanConsts& C, const cf* h0, const cf* h0c, const
                float* normals, float* white, int white_stride) {
     if (pts == 0) return evaluate_np<N, Plan<N>::P1, Plan<N>::P2>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
     if (pts == 16) return evaluate_np<N, 16, 16>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
-    if constexpr (N == 4096) {  // one wave per column in pass 1 (64 points per lane), the 16-point pass 2
-        if (pts == 64) return evaluate_np<N, 64, 16>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
-    }
     if constexpr (N <= 1024) {
         if (pts == 8) return evaluate_np<N, 8, 8>(C, h0, h0c, times, nsteps, vertices, normals, white, white_stride);
     }
@@ -394,7 +354,6 @@ int emul_fft1d(int N, int pts, const float* in_xy, float* out_xy) {
 #define RUN(NN)                                              \
     case NN:                                                 \
         if (pts == 8) return fft1d_np<NN, 8>(in_xy, out_xy); \
-        if constexpr (NN == 4096) { if (pts == 64) return fft1d_np<NN, 64>(in_xy, out_xy); } \
         return fft1d_np<NN, 16>(in_xy, out_xy);
     switch (N) {
         RUN(64) RUN(128) RUN(256) RUN(512) RUN(1024) RUN(2048) RUN(4096)
