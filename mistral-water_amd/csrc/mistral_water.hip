@@ -28,6 +28,9 @@
 #ifndef MW_LATENCY_PLAN
 #define MW_LATENCY_PLAN 1  // single-step enqueues at 1024^2: one field per pass-1 workgroup, one wave per pass-2 row (launch_pass*_n)
 #endif
+#ifndef MW_LATENCY_PF
+#define MW_LATENCY_PF 2  // prefetch level of the frame plan's pass 2 (k_pass2_hs<.., VT = 1, PF>)
+#endif
 #ifndef MW_WAVES_P1
 #define MW_WAVES_P1 6  // min waves per SIMD the register allocator must leave room for (measured best)
 #endif
@@ -345,8 +348,11 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
 #ifndef MW_HS_HALO_EARLY_4096
 #define MW_HS_HALO_EARLY_4096 0  // 4096^2 prefetches the displacement rows during the height field instead (PF = 1): the two together spill
 #endif
+    // PF = 2 (the frame-at-a-time plan, one wave per row): EVERY exchange-buffer load of the workgroup -- height, displacement, the
+    // stored half of the slope field, the halo row -- is requested before the first transform.  A single-step launch is one
+    // workgroup per CU: nothing else hides a load.  Measured (profiles/r04_ab_notes.md): pass 2 of a lone step 19.5 -> 18.4 us.
     constexpr bool HALO_EARLY =
-        (N == 2048 ? (MW_HS_HALO_EARLY_2048 != 0) : (N >= 4096 ? (MW_HS_HALO_EARLY_4096 != 0) : (MW_HS_HALO_EARLY != 0))) && VT >= 2;
+        ((N == 2048 ? (MW_HS_HALO_EARLY_2048 != 0) : (N >= 4096 ? (MW_HS_HALO_EARLY_4096 != 0) : (MW_HS_HALO_EARLY != 0))) && VT >= 2) || PF == 2;
     cf xh[HALO_EARLY ? P : 1];  // halo row data parked in registers across the displacement transform
     const int tid = tid0;  // MW_STAMP
     MW_STAMP(1, 0);
@@ -359,7 +365,8 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
     // global memory (TwGeom::PW_CF).  Measured: pass 2 -1.5 % at 4096^2, +1 % at 1024^2 and 2048^2 (off there).  Prefetching the
     // slope rows during the displacement transform as well (all of them: 17 spilled dwords; one virtual thread's: 243
     // VGPRs) made the kernel 4-11 % slower: removed.
-    static_assert(PF == 0 || PF == 1, "prefetch level");
+    static_assert(PF == 0 || PF == 1 || PF == 2, "prefetch level");
+    static_assert(PF != 2 || P2SlopeParts<N, P>::value, "PF = 2 parks the stored half of the slope field");
     constexpr bool SPARTS = P2SlopeParts<N, P>::value;
     // EARLY_SLOPES (experiment, off; profiles/r03_ab_notes.md): the slope field's stored half requested BEFORE the vertex stores
     // -- gfx950 counts stores in vmcnt, in order with loads -- and parked in x while the Jacobians are formed.  Measured: 4096^2
@@ -370,13 +377,14 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
 #endif
     constexpr bool EARLY_SLOPES = SPARTS && N >= MW_EARLY_SLOPES_MIN_N;
     cf xn[PF ? VT : 1][PF ? P : 1], xn_nyq[PF ? VT : 1], xh_nyq = mk(0.f, 0.f);
-    (void)xn; (void)xn_nyq;
+    cf xs[PF == 2 ? VT : 1][PF == 2 ? P : 1];  // PF = 2: the stored half of the slope field, parked from the start
+    (void)xn; (void)xn_nyq; (void)xs;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int f = p2_hs_field(k);
         __syncthreads();  // k = 0: twiddle tables staged; later: the previous phase's LDS reads are done
         MW_STAMP(1, 1 + 8 * k);
-        if (PF == 1 && k == 1) {  // compile-time: k is unrolled
+        if (PF >= 1 && k == 1) {  // compile-time: k is unrolled
             if constexpr (PF != 0) {
 #pragma unroll
                 MW_VT(h) {
@@ -388,7 +396,12 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
                 }
             }
         } else if (f == 2 && SPARTS) {  // the slope half of every virtual thread in flight, then height rows + stage 0 one at a time
-            if constexpr (!EARLY_SLOPES) {
+            if constexpr (PF == 2) {
+#pragma unroll
+                MW_VT(h)
+#pragma unroll
+                for (int q = 0; q < P; q++) x[h][q] = xs[h][q];
+            } else if constexpr (!EARLY_SLOPES) {
 #pragma unroll
                 MW_VT(h) p2_fetch<N, P, R2, 1>(A, ab, step, MW_VTID(h), f, x[h]);
             }
@@ -401,6 +414,10 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
                 mw_sched_fence();
 #pragma unroll
                 MW_VT(h) p2_fetch<N, P, R2>(A, ab, step, MW_VTID(h), p2_hs_field(1), xn[h], &xn_nyq[h]);
+                if constexpr (PF == 2) {
+#pragma unroll
+                    MW_VT(h) p2_fetch<N, P, R2, 1>(A, ab, step, MW_VTID(h), 2, xs[h]);
+                }
             }
         }
         // The halo row's lines are the next row block's own lines: fetched while that block (same XCD, same phase) loads
@@ -540,7 +557,6 @@ struct mw_ocean {
     DirectState direct;
     // OceanRenderer state
     OrState orr;
-    void graph_invalidate() {}
 };
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -659,9 +675,10 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     if constexpr (HS && N == 1024 && VT == 2 && !DUMP && MW_LATENCY_PLAN) {
         if (nsteps == 1 && latency_plan_on()) {
             static AttrOnce attr1;
-            hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, 1, false, 0>), LB);
+            constexpr int PFL = MW_LATENCY_PF;  // 2: every load of the workgroup requested up front
+            hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, 1, false, PFL>), LB);
             if (e != hipSuccess) return e;
-            k_pass2_hs<N, P, R2, 1, false, 0><<<dim3(N / R2, 1), dim3(P2Geom<N, P, R2, true>::NTHREADS), LB, st>>>(A);
+            k_pass2_hs<N, P, R2, 1, false, PFL><<<dim3(N / R2, 1), dim3(P2Geom<N, P, R2, true>::NTHREADS), LB, st>>>(A);
             return hipGetLastError();
         }
     }
@@ -799,7 +816,6 @@ void mw_ocean_destroy(mw_ocean* o) {
     if (!o) return;
     hipSetDevice(o->device);
     if (hipStreamSynchronize(o->stream) != hipSuccess) (void)hipGetLastError();  // a dead caller stream has nothing pending
-    o->graph_invalidate();
     hipFree(o->h0); hipFree(o->h0c); hipFree(o->PQt); hipFree(o->Om); hipFree(o->dPQ_i0); hipFree(o->dPQ_j0);
     hipFree(o->TW); hipFree(o->TW2); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white); hipFree(o->scratch);
     direct_free(o->direct);
@@ -904,7 +920,6 @@ mw_status mw_ocean_set_stream(mw_ocean* o, void* hip_stream) {
     mw_status s = drain_stream(o);
     if (s != MW_OK) return s;
     o->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = HIP's legacy default stream, like the pond entry points
-    o->graph_invalidate();
     return MW_OK;
 }
 mw_status mw_ocean_use_own_stream(mw_ocean* o) {
@@ -913,7 +928,6 @@ mw_status mw_ocean_use_own_stream(mw_ocean* o) {
     mw_status s = drain_stream(o);
     if (s != MW_OK) return s;
     o->stream = o->own_stream;
-    o->graph_invalidate();
     return MW_OK;
 }
 void* mw_ocean_get_stream(mw_ocean* o) { return o ? reinterpret_cast<void*>(o->stream) : nullptr; }
