@@ -410,14 +410,26 @@ MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, const P1State<P>& s
     }
 }
 
+// radix-P passes the pass-1 loop runs between stage 0 and p1_finish (all of them, unless p1_finish runs the last one itself)
+template <int N, int P>
+MW_HD constexpr int p1_mid_passes() { return FftGeom<N, P>::S - (LastInRegs<N, P>::value ? 1 : 0); }
 // final pass in the column-interleaved mapping + coalesced store of the exchange buffer
 template <int N, int P>
 MW_HD void p1_finish(const P1Args& A, const Twiddles& tw, int jb, int step, int tid, int f, cf (&x)[P], const cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
     constexpr int CW = Exch<N>::CW;
     const int w2 = tid % CW, u2 = tid / CW;
-    load_last<N, P>(x, u2, lds + w2 * P1Geom<N, P>::BUFSTRIDE);
-    final_stage<N, P, +1>(x, u2, tw.TF);
+    if (LastInRegs<N, P>::value) {
+        // N = P^S (4096 at 16 points): the LAST radix-P pass itself runs in the column-interleaved mapping -- it reads the previous
+        // exchange (identity layout; the four buffers 8 entries apart mod 32: conflict-free) and its results, element u2 + T q in slot
+        // q, go straight to the exchange buffer in whole lines.  One LDS round trip and two barriers per field less than
+        // stage_store + load_last (the caller's pass loop stops one pass early: p1_mid_passes).
+        load_slots<N, P>(x, u2, lds + w2 * P1Geom<N, P>::BUFSTRIDE, FftGeom<N, P>::S - 2);
+        stage_regs<N, P, +1>(x, u2, tw, FftGeom<N, P>::S - 1);
+    } else {
+        load_last<N, P>(x, u2, lds + w2 * P1Geom<N, P>::BUFSTRIDE);
+        final_stage<N, P, +1>(x, u2, tw.TF);
+    }
     if (jb == N / CW) {
         if (w2 == 0) {
             cf* C = A.Cj0 + ((size_t)step * 3 + f) * N;
@@ -642,7 +654,14 @@ template <int N, int P, int R2>
 MW_HD void p2_mid_store(const Twiddles& tw, int tid, int s, cf (&x)[P], cf* lds) {
     int r1, u1;
     p2_mid_map<N, P, R2>(tid, &r1, &u1);
-    stage_store<N, P, +1>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE, tw, s);
+    if (LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1) stage_regs<N, P, +1>(x, u1, tw, s);  // stays in registers: p2_last_load reads nothing
+    else stage_store<N, P, +1>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE, tw, s);
+}
+// input of the final pass in the row-major mapping: the last exchange, unless the last radix-P pass left it in registers (LastInRegs:
+// the middle passes of an exact layout run in the same row-major mapping, p2_mid_map)
+template <int N, int P>
+MW_HD void p2_last_load(cf (&x)[P], int u, const cf* buf) {
+    if (!LastInRegs<N, P>::value) load_last<N, P>(x, u, buf);
 }
 
 // final pass in the row-major mapping (thread (g,u) owns row a0+g, columns b = u + T q)
@@ -651,7 +670,7 @@ MW_HD void p2_finish(const P2Args& A, const Twiddles& tw, int ab, int step, int 
                      const cf* lds, float* noise_lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
-    load_last<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
+    p2_last_load<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
     final_stage<N, P, +1>(x, u, tw.TF);
     if (f == 2) {  // slopes -> unit normal (S/FFTMesh.cs:218), stored at once
         float* nblk = A.normals + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;  // block-uniform
@@ -799,7 +818,7 @@ template <int N, int P, int R2>
 MW_HD void p2_hs_finish(const Twiddles& tw, int ab, int tid, int f, cf (&x)[P], P2StateHS<P>& st, const cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
-    load_last<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
+    p2_last_load<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
     final_stage<N, P, +1>(x, u, tw.TF);
 #pragma unroll
     for (int q = 0; q < P; q++) {
@@ -846,7 +865,7 @@ MW_HD void p2_hs_finish_slopes(const P2Args& A, const Twiddles& tw, int ab, int 
                                const P2StateHS<P>& st, const cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
-    load_last<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
+    p2_last_load<N, P>(x, u, lds + g * P2Buf<N, P>::BUFSTRIDE);
     final_stage<N, P, +1>(x, u, tw.TF);
     float* nblk = A.normals + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;  // block-uniform
     float* wblk = A.white + ((size_t)step * N * N + (size_t)ab * R2 * N) * A.white_stride;

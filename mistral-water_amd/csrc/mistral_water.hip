@@ -172,7 +172,7 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
         MW_STAMP(0, 3 + 8 * f);
         __syncthreads();
 #pragma unroll
-        for (int s = 1; s < FftGeom<N, P>::S; s++) {
+        for (int s = 1; s < p1_mid_passes<N, P>(); s++) {
 #pragma unroll
             MW_VT(h) load_slots<N, P>(x[h], MW_U(h), MW_BUF(h), s - 1);
             if (s == 1) MW_STAMP(0, 4 + 8 * f);
@@ -270,10 +270,12 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
+            constexpr bool LIR = LastInRegs<N, P>::value && G::NBUF == 1;
+            const bool in_regs = LIR && s == FftGeom<N, P>::S - 1;  // the last pass writes nothing to LDS: no barrier on either side of it
             if (active) p2_mid_load<N, P, R2>(tid, s, x, set0 + cur * G::SETSTRIDE);
-            if (G::NBUF == 1) __syncthreads(); else cur ^= 1;
+            if (!in_regs) { if (G::NBUF == 1) __syncthreads(); else cur ^= 1; }
             if (active) p2_mid_store<N, P, R2>(tw, tid, s, x, set0 + cur * G::SETSTRIDE);
-            __syncthreads();
+            if (!in_regs) __syncthreads();
         }
         MW_STAMP(1, 6 + 8 * k);
         if (active) p2_finish<N, P, R2>(A, tw, ab, step, tid, f, x, st, set0 + cur * G::SETSTRIDE, noise_lds);
@@ -444,12 +446,13 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
+            const bool in_regs = LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1;  // the last pass writes nothing to LDS (LastInRegs)
 #pragma unroll
             MW_VT(h) p2_mid_load<N, P, R2>(MW_VTID(h), s, x[h], set0);
-            __syncthreads();
+            if (!in_regs) __syncthreads();
 #pragma unroll
             MW_VT(h) p2_mid_store<N, P, R2>(tw, MW_VTID(h), s, x[h], set0);
-            __syncthreads();
+            if (!in_regs) __syncthreads();
         }
         MW_STAMP(1, 6 + 8 * k);
         if (f == 2) {
@@ -508,13 +511,14 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
             __syncthreads();
 #pragma unroll
             for (int s = 1; s < FftGeom<N, P>::S; s++) {
+                const bool in_regs = LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1;
                 if (g0 == 0) load_slots<N, P>(xq, u, set0, s - 1);
-                __syncthreads();
-                if (g0 == 0) stage_store<N, P, +1>(xq, u, set0, tw, s);
-                __syncthreads();
+                if (!in_regs) __syncthreads();
+                if (g0 == 0) { if (in_regs) stage_regs<N, P, +1>(xq, u, tw, s); else stage_store<N, P, +1>(xq, u, set0, tw, s); }
+                if (!in_regs) __syncthreads();
             }
             if (g0 == 0) {
-                load_last<N, P>(xq, u, set0);
+                p2_last_load<N, P>(xq, u, set0);
                 final_stage<N, P, +1>(xq, u, tw.TF);
             }
             __syncthreads();

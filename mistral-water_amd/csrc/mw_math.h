@@ -306,6 +306,9 @@ constexpr int mw_ipow(int P, int s) { int m = 1; for (int i = 0; i < s; i++) m *
 #ifndef MW_LDS_LAYOUT
 #define MW_LDS_LAYOUT 2
 #endif
+#ifndef MW_LAST_IN_REGS
+#define MW_LAST_IN_REGS 1  // skip the identity LDS round trip after the last radix-P pass when N = P^S (LastInRegs)
+#endif
 //  * exact, P = 8 (T a multiple of 64): exchange 0 is the 8 x T transpose n -> (n % 8)(T + 4) + n / 8 (reads: lane u at
 //    4 (u % 8) + u / 8 + const); exchange 1 (pass 1 writes n = 64 (u/8) + 8 r + u % 8: two 8-entry runs 64 apart per 16-lane
 //    group) pads 8 entries per 64, n -> n + 8 (n / 64); later exchanges are the identity.
@@ -472,8 +475,10 @@ MW_HD void load_slots(cf (&x)[P], int u, const cf* buf, int e) {
 // transform rounding at ill-conditioned texels, and a frame is latency- not throughput-bound anyway)
 template <int N, int P>
 MW_HD void load_last(cf (&x)[P], int u, const cf* buf) { load_slots<N, P>(x, u, buf, FftGeom<N, P>::S - 1); }  // input of the final pass
+// the arithmetic of radix-P pass s (twiddles + DFT), results left in registers: x[r] = element j + p r of the next sequence,
+// j = ((u - k) << log2 P) + k, k = u mod p
 template <int N, int P, int SGN, bool ALLOW_POW = true>
-MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
+MW_HD void stage_regs(cf (&x)[P], int u, const Twiddles& tw, int s) {
     const int p = 1 << (LogP<P>::v * s);
     const int k = u & (p - 1);
     const cf* __restrict__ row = tw.TS[s] + k * (P + 1);
@@ -512,6 +517,18 @@ MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
         for (int r = 1; r < P; r++) x[r] = cmul(x[r], row[r]);
     }
     DftP<P, SGN>::run(x);
+}
+// When N = P^S (no final partial pass) the LAST radix-P pass has p = T and k = u: its results, element u + T r in slot r, are
+// already the natural "thread u keeps element u + T q in slot q" order -- with the identity layout of the later exchanges a
+// stage_store + load_last pair would write and read back the very same LDS words behind two barriers.  Kernels whose lane mapping
+// does not change after the last pass skip that round trip (4096^2 with 16 points per thread, 512^2 with 8).
+template <int N, int P>
+struct LastInRegs { static constexpr bool value = MW_LAST_IN_REGS && FftGeom<N, P>::RL == 1 && FftGeom<N, P>::S >= 2 && XLay<N, P>::EXACT; };
+template <int N, int P, int SGN, bool ALLOW_POW = true>
+MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
+    stage_regs<N, P, SGN, ALLOW_POW>(x, u, tw, s);
+    const int p = 1 << (LogP<P>::v * s);
+    const int k = u & (p - 1);
     const int j = ((u - k) << LogP<P>::v) + k;
 #ifdef MW_ABLATE_LDS
     if (u == 12345) buf[j] = x[0];

@@ -53,7 +53,7 @@ void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
                     p1_build<N, P>(A, jb, tid, f, st[tid].s, st[tid].x);
                     stage0_store<N, P, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
                 }
-                for (int s = 1; s < FftGeom<N, P>::S; s++) {
+                for (int s = 1; s < p1_mid_passes<N, P>(); s++) {
                     for (int tid = 0; tid < NT; tid++) load_slots<N, P>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, s - 1);
                     for (int tid = 0; tid < NT; tid++)
                         stage_store<N, P, +1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS, tw, s);
@@ -132,9 +132,13 @@ void run_pass2_hs(const P2Args& A, int nsteps) {
                     }
                     for (int s = 1; s < FftGeom<N, P>::S; s++) {
                         for (int u = 0; u < T; u++) load_slots<N, P>(st[u].x, u, lds.data(), s - 1);
-                        for (int u = 0; u < T; u++) stage_store<N, P, +1>(st[u].x, u, lds.data(), tw, s);
+                        const bool in_regs = LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1;  // as k_pass2_hs's halo transform
+                        for (int u = 0; u < T; u++) {
+                            if (in_regs) stage_regs<N, P, +1>(st[u].x, u, tw, s);
+                            else stage_store<N, P, +1>(st[u].x, u, lds.data(), tw, s);
+                        }
                     }
-                    for (int u = 0; u < T; u++) { load_last<N, P>(st[u].x, u, lds.data()); final_stage<N, P, +1>(st[u].x, u, tw.TF); }
+                    for (int u = 0; u < T; u++) { p2_last_load<N, P>(st[u].x, u, lds.data()); final_stage<N, P, +1>(st[u].x, u, tw.TF); }
                     for (int u = 0; u < T; u++) p2_hs_halo_publish<N, P, R2>(ab, u, st[u].x, lds.data());
                 }
                 for (int tid = (R2 - 1) * T; tid < NT; tid++)
