@@ -33,7 +33,31 @@ struct CztArgs {
     const cf* TWi = nullptr;
     int N = 0, rows = 0, in_ld = 0, out_ld = 0;
     long long in_plane = 0, out_plane = 0;
+    // first launch of a step: h0 != nullptr -> the input planes are not read but FORMED from the spectrum on the way in
+    // (czt_spec_value; the five multiplier spectra never exist in memory)
+    const cf* h0 = nullptr;
+    const cf* h0c = nullptr;
+    float t = 0.f;
+    OceanConsts C = {};
 };
+
+// S/FFTMesh.cs:178-190 htilde(t) at (i, j) times the multiplier of field f (:211-215): f = 0 height, 1 kx/|k|, 2 -kz/|k|, 3 kx, 4 kz
+MW_HD cf czt_spec_value(const OceanConsts& C, const cf* h0, const cf* h0c, float t, int i, int j, int f) {
+    const int N = C.N;
+    const size_t idx = (size_t)i * N + j;
+    float s, c;
+    mw_sincos(omega_t_f32(N, C.length, C.gravity, i, j, t), &s, &c);
+    const cf a = h0[idx], b = h0c[idx];
+    const cf h = mk(a.x * c - a.y * s + b.x * c + b.y * s, a.x * s + a.y * c - b.x * s + b.y * c);  // :188
+    if (f == 0) return h;
+    const float kx = wave_k(N, C.length, i), kz = wave_k(N, C.length, j);
+    if (f == 3) return cscale(h, kx);
+    if (f == 4) return cscale(h, kz);
+    const float kl = sqrtf(kx * kx + kz * kz);
+    float ux = 0.f, uzn = 0.f;
+    if (!(kl < MW_EPS_F)) { ux = kx / kl; uzn = -kz / kl; }  // :213-215
+    return cscale(h, f == 1 ? ux : uzn);
+}
 
 // transform size and points per thread for a grid of N points per axis (0: N too large for one workgroup-resident transform)
 inline int czt_size(int N) {
@@ -51,7 +75,7 @@ MW_HD void czt_load(const CztArgs& A, int f, int row, int u, bool live, cf (&x)[
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int n = u + T * q;
-        x[q] = (live && n < A.N) ? cmul(r[n], A.w1[n]) : mk(0.f, 0.f);  // zero padding up to M
+        x[q] = (live && n < A.N) ? cmul(A.h0 ? czt_spec_value(A.C, A.h0, A.h0c, A.t, row, n, f) : r[n], A.w1[n]) : mk(0.f, 0.f);  // zero padding up to M
     }
 }
 template <int M, int P>

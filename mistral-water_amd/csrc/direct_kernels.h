@@ -24,7 +24,7 @@ namespace mw {
 struct CztState {
     int M = 0;
     cf *w1 = nullptr, *w2 = nullptr, *Hh = nullptr, *TWf = nullptr, *TWi = nullptr;
-    cf *F = nullptr, *TT = nullptr, *O = nullptr;  // [5][N][N] each: spectra, after the z sum (transposed), after the x sum
+    cf *TT = nullptr, *O = nullptr;  // [5][N][N] each: after the z sum (transposed), after the x sum (the spectra are formed on the way in)
     float table_length = -1.f, table_unit_width = -1.f;
 };
 
@@ -163,36 +163,27 @@ __global__ void k_direct_white(int N, const cf* hds, const float* normals, float
 }
 
 // ---- chirp-z launches ---------------------------------------------------------------------------------------------------
-// S/FFTMesh.cs:178-190 htilde + the five multiplier spectra of :211-215 as complex planes F[f][i][j]
-__global__ void k_czt_spec(OceanConsts C, const cf* h0, const cf* h0c, float t, cf* F) {
-    const int N = C.N;
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * N) return;
-    int i = idx / N, j = idx % N;
-    float s, c;
-    mw_sincos(omega_t_f32(N, C.length, C.gravity, i, j, t), &s, &c);
-    cf a = h0[idx], b = h0c[idx];
-    cf h = mk(a.x * c - a.y * s + b.x * c + b.y * s, a.x * s + a.y * c - b.x * s + b.y * c);  // :188
-    float kx = wave_k(N, C.length, i), kz = wave_k(N, C.length, j);
-    float kl = sqrtf(kx * kx + kz * kz);
-    float ux = 0.f, uzn = 0.f;
-    if (!(kl < MW_EPS_F)) { ux = kx / kl; uzn = -kz / kl; }  // :213-215
-    const size_t NN = (size_t)N * N;
-    F[idx] = h;
-    F[NN + idx] = cscale(h, ux);
-    F[2 * NN + idx] = cscale(h, uzn);
-    F[3 * NN + idx] = cscale(h, kx);
-    F[4 * NN + idx] = cscale(h, kz);
-}
 // one axis of the sum for RW rows per workgroup: pre-chirp + zero padding, forward transform, kernel product, inverse
 // transform, post-chirp, transposed store (czt_kernels.h).  Twiddles come from global memory (L1 / L2 hits): not a throughput
 // kernel yet.  Barriers are workgroup-uniform: rows past the end compute on zeros and store nothing.
+#ifndef MW_CZT_XCD_GROUP
+#define MW_CZT_XCD_GROUP 1
+#endif
 template <int M, int P, int RW>
 __global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = M / P, BUF = FftGeom<M, P>::LBUF + 4;
-    const int tid = threadIdx.x, w = tid / T, u = tid % T, row = (int)blockIdx.x * RW + w, f = blockIdx.y;
+    // Row blocks of one 128-B line of the TRANSPOSED output (16 consecutive rows = 16 / RW consecutive blocks, 8 B each per column) are
+    // issued on ONE XCD (the dispatcher places block b on XCD b % 8), so that their 8 RW-byte pieces of a line meet in that XCD's L2
+    // instead of leaving four L2s as partial lines.  Any bijection is correct; blocks past the last whole group of 8 x G keep their index.
+    constexpr int G = 16 / RW > 0 ? 16 / RW : 1;
+    int rb = (int)blockIdx.x;
+    if (MW_CZT_XCD_GROUP && G > 1 && rb < (int)gridDim.x / (8 * G) * (8 * G)) {
+        const int grp = rb / (8 * G), in = rb % (8 * G), xcd = in % 8, slot = in / 8;
+        rb = grp * (8 * G) + xcd * G + slot;
+    }
+    const int tid = threadIdx.x, w = tid / T, u = tid % T, row = rb * RW + w, f = blockIdx.y;
     const bool live = row < A.rows;
     const Twiddles twf = TwGeom<M, P>::view(A.TWf), twi = TwGeom<M, P>::view(A.TWi);
     cf* buf = lds + (size_t)w * BUF;
@@ -224,8 +215,10 @@ __global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
     final_stage<M, P, +1>(x, u, twi.TF);
     if (live) czt_store<M, P>(A, f, row, u, x);
 }
-// vertices / normals / hds from the five complex output planes O[f][a][b]: H = Re, Dx Dz Sx Sz = Im (S/FFTMesh.cs:211-218)
-__global__ void k_czt_assemble(OceanConsts C, const cf* O, cf* hds, float* vertices, float* normals) {
+// vertices / normals / whitecap from the five complex output planes O[f][a][b]: H = Re, Dx Dz Sx Sz = Im (S/FFTMesh.cs:211-218),
+// and the forward-difference Jacobian (:258-274) from the displacement planes of the two neighbours -- one launch; hds is written
+// only for the test hook (mw_debug_evaluate_hds)
+__global__ void k_czt_assemble_white(OceanConsts C, const cf* O, cf* hds, float* vertices, float* normals, float* white, int white_stride) {
     const int N = C.N;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * N) return;
@@ -239,13 +232,19 @@ __global__ void k_czt_assemble(OceanConsts C, const cf* O, cf* hds, float* verti
     vertices[3 * idx + 0] = ssub(rest_coord(N, C.unit_width, a), smul(dx, C.choppiness));  // :245
     vertices[3 * idx + 1] = h;                                                             // :243
     vertices[3 * idx + 2] = ssub(rest_coord(N, C.unit_width, b), smul(dz, C.choppiness));  // :244
-    hds[idx] = mk(dx, dz);                                                                 // :247
+    if (hds) hds[idx] = mk(dx, dz);                                                        // :247
+    const bool hi = a != N - 1, hj = b != N - 1;
+    const cf z = mk(0.f, 0.f);
+    const cf di = hi ? mk(O[NN + idx + N].y, O[2 * NN + idx + N].y) : z, dj = hj ? mk(O[NN + idx + 1].y, O[2 * NN + idx + 1].y) : z;
+    const float xx = whitecap(mk(dx, dz), di, dj, hi, hj, nx, nz);
+    if (white_stride == 1) white[idx] = xx;
+    else { white[4 * idx] = xx; white[4 * idx + 1] = xx; white[4 * idx + 2] = xx; white[4 * idx + 3] = xx; }
 }
 
 std::vector<cf> build_twiddle_table(int N, int P, int sgn);  // mistral_water.hip
 
 static inline void czt_free(CztState& z) {
-    hipFree(z.w1); hipFree(z.w2); hipFree(z.Hh); hipFree(z.TWf); hipFree(z.TWi); hipFree(z.F); hipFree(z.TT); hipFree(z.O);
+    hipFree(z.w1); hipFree(z.w2); hipFree(z.Hh); hipFree(z.TWf); hipFree(z.TWi); hipFree(z.TT); hipFree(z.O);
     z = CztState();
 }
 static inline int czt_alloc(CztState& z, int N) {
@@ -256,7 +255,7 @@ static inline int czt_alloc(CztState& z, int N) {
     const size_t NN = (size_t)N * N;
     if (hipMalloc((void**)&z.w1, sizeof(cf) * N) != hipSuccess || hipMalloc((void**)&z.w2, sizeof(cf) * N) != hipSuccess ||
         hipMalloc((void**)&z.Hh, sizeof(cf) * z.M) != hipSuccess || hipMalloc((void**)&z.TWf, sizeof(cf) * tf.size()) != hipSuccess ||
-        hipMalloc((void**)&z.TWi, sizeof(cf) * ti.size()) != hipSuccess || hipMalloc((void**)&z.F, sizeof(cf) * 5 * NN) != hipSuccess ||
+        hipMalloc((void**)&z.TWi, sizeof(cf) * ti.size()) != hipSuccess ||
         hipMalloc((void**)&z.TT, sizeof(cf) * 5 * NN) != hipSuccess || hipMalloc((void**)&z.O, sizeof(cf) * 5 * NN) != hipSuccess ||
         hipMemcpy(z.TWf, tf.data(), sizeof(cf) * tf.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(z.TWi, ti.data(), sizeof(cf) * ti.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -291,16 +290,15 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
         z.table_length = C.length;
         z.table_unit_width = C.unit_width;
     }
-    if (ev) hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL(k_czt_spec, dim3(nb), dim3(128), 0, st, C, h0, h0c, t, z.F);
-    if (ev) hipEventRecord(ev[1], st);
+    if (ev) { hipEventRecord(ev[0], st); hipEventRecord(ev[1], st); }
     CztArgs A;
     A.w1 = z.w1; A.w2 = z.w2; A.Hh = z.Hh; A.TWf = z.TWf; A.TWi = z.TWi;
     A.N = N; A.rows = N; A.in_ld = N; A.out_ld = N; A.in_plane = (long long)N * N; A.out_plane = (long long)N * N;
     hipError_t e = hipSuccess;
     for (int pass = 0; pass < 2 && e == hipSuccess; pass++) {
-        A.in = pass == 0 ? z.F : z.TT;   // along j (rows i) -> TT[f][b][i]; along i (rows b) -> O[f][a][b]
+        A.in = z.TT;                     // along j (rows i, formed from the spectrum) -> TT[f][b][i]; along i (rows b) -> O[f][a][b]
         A.out = pass == 0 ? z.TT : z.O;
+        A.h0 = pass == 0 ? h0 : nullptr; A.h0c = h0c; A.t = t; A.C = C;
         switch (z.M) {
             case 64: e = czt_launch<64>(A, st); break;
             case 128: e = czt_launch<128>(A, st); break;
@@ -314,8 +312,7 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
     }
     if (e != hipSuccess) return e;
     if (ev) hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(k_czt_assemble, dim3(nb), dim3(128), 0, st, C, z.O, d.hds, dv, dn);
-    hipLaunchKernelGGL(k_direct_white, dim3(nb), dim3(128), 0, st, N, d.hds, dn, dw, white_stride);
+    hipLaunchKernelGGL(k_czt_assemble_white, dim3(nb), dim3(128), 0, st, C, z.O, d.hds, dv, dn, dw, white_stride);
     return hipGetLastError();
 }
 

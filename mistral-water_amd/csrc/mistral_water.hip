@@ -1275,7 +1275,7 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
     if (!o->use_fft) {  // direct-sum path: kernel 0 = the four GEMM launches of one step, kernel 1 = spectrum + assembly + whitecap
         if (nsteps != 1) return fail(MW_EINVAL, "mw_ocean_profile_kernels: the direct-sum path evaluates one step per enqueue");
         static const char* gnames[2] = {"k_gemm_f32_mfma (4 launches: z sum, x sum)", "k_direct_spec + k_direct_assemble + k_direct_white"};
-        static const char* znames[2] = {"k_czt (2 launches: chirp-z along j, along i)", "k_czt_spec + k_czt_assemble + k_direct_white"};
+        static const char* znames[2] = {"k_czt (2 launches: spectrum + chirp-z along j, chirp-z along i)", "k_czt_assemble_white"};
         const char* const* dnames = o->direct.use_czt ? znames : gnames;
         hipEvent_t ev[4];
         for (auto& e : ev) hipEventCreate(&e);
