@@ -43,7 +43,7 @@ BYTES_PASS1 = 16 + 24      # read (P,Q) + write 3 packed complex fields
 BYTES_PASS2 = 24 + 28      # read 3 packed complex fields + write vertex 12 + normal 12 + whitecap 4
 BYTES_POND = 24            # read position 12 + write position 12
 BYTES_RENDERER = 120       # see renderer()
-PROFILE_ROUND = "r03"      # profiles/<round>_<workload>_b<B>_pmc.json carry the counters of ONE build (its build_id inside)
+PROFILE_ROUND = "r04"      # profiles/<round>_<workload>_b<B>_pmc.json carry the counters of ONE build (its build_id inside)
 
 
 def parse():
@@ -442,13 +442,14 @@ def main():
     traffic1, _ = pmc_traffic(a.workload, B, "k_pass1", build_id)
     stale = None
     if traffic is None:      # context only, never `traffic`: the last committed counter pass of this kernel, whatever build it was
-        for rnd in ("r02",):
+        for rnd in ("r04", "r02"):
             try:
                 j = json.load(open(os.path.join(REPO, "profiles", f"{rnd}_{a.workload}_b32_pmc.json")))["pmc_mean_per_launch"]
                 k = [v for name, v in j.items() if "k_pass2" in name][0]
                 stale = {"bytes_per_point": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / (NN * 32),
                          "source": f"profiles/{rnd}_{a.workload}_b32_pmc.json",
                          "note": "counters of an EARLIER build of the same kernel (32-step launches): not this build's traffic"}
+                break
             except Exception:
                 pass
     roofline = {"bound": "hbm", "kernel": "k_pass2", "achieved": roof_ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

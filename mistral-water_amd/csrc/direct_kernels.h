@@ -193,12 +193,14 @@ __global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
     __syncthreads();
 #pragma unroll
     for (int s = 1; s < FftGeom<M, P>::S; s++) {
+        const bool in_regs = LastInRegs<M, P>::value && s == FftGeom<M, P>::S - 1;  // M = P^S (4096): no identity round trip through LDS
         load_slots<M, P>(x, u, buf, s - 1);
+        if (in_regs) { stage_regs<M, P, -1, false>(x, u, twf, s); continue; }
         __syncthreads();
         stage_store<M, P, -1, false>(x, u, buf, twf, s);
         __syncthreads();
     }
-    load_last<M, P>(x, u, buf);
+    if (!LastInRegs<M, P>::value) load_last<M, P>(x, u, buf);
     final_stage<M, P, -1>(x, u, twf.TF);
     czt_mul_kernel<M, P>(A, u, x);
     __syncthreads();  // every read of the forward transform's last exchange is done
@@ -206,12 +208,14 @@ __global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
     __syncthreads();
 #pragma unroll
     for (int s = 1; s < FftGeom<M, P>::S; s++) {
+        const bool in_regs = LastInRegs<M, P>::value && s == FftGeom<M, P>::S - 1;
         load_slots<M, P>(x, u, buf, s - 1);
+        if (in_regs) { stage_regs<M, P, +1, false>(x, u, twi, s); continue; }
         __syncthreads();
         stage_store<M, P, +1, false>(x, u, buf, twi, s);
         __syncthreads();
     }
-    load_last<M, P>(x, u, buf);
+    if (!LastInRegs<M, P>::value) load_last<M, P>(x, u, buf);
     final_stage<M, P, +1>(x, u, twi.TF);
     if (live) czt_store<M, P>(A, f, row, u, x);
 }

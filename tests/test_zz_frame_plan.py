@@ -66,7 +66,7 @@ import torch; torch.cuda.is_available()
 import mistral_water as mw, workloads
 from oracle import oracle as O
 for (N, u, L, amp, rel) in ((12, 1.0, 12.39, 0.01, 2e-5), (50, 1.0, 1.0, 1.0, %(inspector_rel)s), (65, 0.5, 40.0, 1e-5, 2e-5), (200, 1.0, 212.5, 4e-7, 2e-5),
-                            (1000, 1.0, 1000.0, 1.6e-8, 2e-5)):
+                            (1000, 1.0, 1000.0, 1.6e-8, 2e-5), (1500, 1.0, 1530.0, 7e-9, 2e-5)):      # 1500: M = 4096 = 16^3 (LastInRegs in k_czt)
     p = O.Params(N=N, unit_width=u, length=L, wind_x=5.0 if N < 100 else 14.45, wind_y=3.0 if N < 100 else 12.0, amplitude=amp, choppiness=0.8)
     h0, h0c = O.generate_spectrum(p, 4)
     rest = O.rest_mesh(p)[0]

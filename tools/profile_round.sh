@@ -18,10 +18,16 @@ run ocean4096 ocean4096 32 128
 run pond pond 32 3200
 run renderer1024 renderer1024 1 2000
 run renderer1024 renderer1024 4 500 --tiles 4
-for n in 50 100 1000; do
+for n in 50 100 1000 2000; do
   timeout 300 python bench.py --workload direct --direct-n $n --steps 200 --warmup 20 2> gpurun_out/${tag}_direct_$n.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_direct_$n.json
 done
+MW_BENCH_FORCE_TILES=1 timeout 300 python bench.py --steps 640 --warmup 64 --gather --no-cpu-baseline --no-latency 2> gpurun_out/${tag}_tiles.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_ocean1024_tiles_gather.json
+timeout 300 python bench.py --steps 640 --warmup 64 --no-cpu-baseline 2> gpurun_out/${tag}_b32.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_ocean1024_b32_steps640.json
+for wl in ocean2048 ocean4096; do timeout 400 python bench.py --workload $wl --steps 128 --warmup 32 --no-cpu-baseline --no-latency 2> gpurun_out/${tag}_$wl.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_$wl.json; done
+timeout 300 python bench.py --workload pond --steps 3200 --warmup 320 2> gpurun_out/${tag}_pond.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_pond.json
+timeout 300 python bench.py --workload renderer1024 --steps 2000 --warmup 200 2> gpurun_out/${tag}_renderer.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_renderer1024.json
+timeout 300 python bench.py --workload renderer1024 --tiles 4 --steps 500 --warmup 50 --no-cpu-baseline 2> gpurun_out/${tag}_renderer4.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_renderer1024_tiles4.json
 timeout 300 python bench.py --steps 20 --warmup 5 2> gpurun_out/${tag}_bench_driver.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_ocean1024_driver_k20.json
-P=gpurun_out/profiles_${tag}; python tools/bench_summary.py $P/${tag}_bench_direct_50.json $P/${tag}_bench_direct_100.json $P/${tag}_bench_direct_1000.json $P/${tag}_bench_ocean1024_driver_k20.json
+P=gpurun_out/profiles_${tag}; python tools/bench_summary.py $P/${tag}_bench_direct_50.json $P/${tag}_bench_direct_100.json $P/${tag}_bench_direct_1000.json $P/${tag}_bench_direct_2000.json $P/${tag}_bench_ocean1024_b32_steps640.json $P/${tag}_bench_ocean2048.json $P/${tag}_bench_ocean4096.json $P/${tag}_bench_pond.json $P/${tag}_bench_renderer1024.json $P/${tag}_bench_renderer1024_tiles4.json $P/${tag}_bench_ocean1024_driver_k20.json
 ls gpurun_out/profiles_${tag}
 # back in the container: cp gpurun_out/profiles_${tag}/* profiles/   (only gpurun_out/ travels back from the GPU box)
