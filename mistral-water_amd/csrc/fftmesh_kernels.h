@@ -351,6 +351,12 @@ MW_HD constexpr int mw_split_slopes(int N) { return N >= 4096 ? MW_SPLIT_SLOPES_
 #ifndef MW_SLOPE_FENCE_Q
 #define MW_SLOPE_FENCE_Q 8
 #endif
+#ifndef MW_KEEP_T1
+#define MW_KEEP_T1 1
+#endif
+#ifndef MW_KEEP_T1_MAX_N
+#define MW_KEEP_T1_MAX_N 2048
+#endif
 MW_HD bool p1_field_active(int N, int jb, int f, int cw = 4) {
     if (f == 1) return true;
     if (f == 2 && (!mw_split_slopes(N) || jb == N / cw)) return true;  // whole field / the Nyquist-column job keeps its cz term
@@ -523,8 +529,16 @@ MW_HD void p2_load_map(int tid, int* r1, int* u1) {
 // time: the height rows' registers are then live for one virtual thread only.
 // nyq != nullptr: the Nyquist-column term is returned there instead of being added to x[0] (a prefetch must not consume any
 // of its loads: the add's s_waitcnt would wait for all of them, vmcnt being in-order); the caller adds it when it uses x.
+// keep (KeepT1, mode 2 of the half-stored slope field): the height fetch (f = 0) leaves the RAW values of its mirrored slots q >= P/2
+// there -- element (a, N - j) of the height rows, before the conjugation --, and the slope assembly (f = 2, PART 0 / 2) takes them from
+// there instead of fetching the same exchange-buffer words a second time (4 B per grid point that had left the L2 by then).
+template <int N, int P>
+struct KeepT1 {
+    static constexpr bool value = MW_KEEP_T1 && mw_split_slopes(N) == 2 && N <= MW_KEEP_T1_MAX_N && (FftGeom<N, P>::T % Exch<N>::CW == 0) &&
+                                  ((N / 2) % FftGeom<N, P>::T == 0);
+};
 template <int N, int P, int R2, int PART = 0>
-MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P], cf* nyq = nullptr) {
+MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P], cf* nyq = nullptr, cf* keep = nullptr) {
     constexpr int T = FftGeom<N, P>::T;
     int r1, u1;
     p2_load_map<N, P, R2>(tid, &r1, &u1);
@@ -573,13 +587,14 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
             const unsigned off = all_mir ? voffm : (edge ? (u1 > 0 ? voffm - (unsigned)chunk : voff + (unsigned)chunk) : voff);
             cf v = (PART == 2) ? x[q] : mw_load_stream(&(all_mir ? Ef - ub : Ef + ub)[off], f != 0);
             if (PART == 1) { x[q] = v; continue; }
+            if (f == 0 && keep && (all_mir || edge)) keep[q - P / 2] = v;  // T q >= N/2  <=>  q >= P/2
             if (mw_split_slopes(N) == 1 && f == 2) {  // T3(a,j) = G'(a,j) + kz(j) T1'(a,j)
                 const cf t = mw_load_stream(&(all_mir ? E0 - ub : E0 + ub)[off], true);
                 const float kz = wave_k_fast(N, kscale, u1 + T * q);
                 v = mk(__builtin_fmaf(kz, t.x, v.x), __builtin_fmaf(kz, t.y, v.y));
             }
             if (mw_split_slopes(N) == 2 && f == 2 && (all_mir || edge)) {  // T3(a,j) = conj(T3(a,m) - 2 kz(m) T1(a,m)), kz(m) = -kz(j)
-                const cf t = mw_load_stream(&(all_mir ? E0 - ub : E0 + ub)[off], true);
+                const cf t = keep ? keep[q - P / 2] : mw_load_stream(&(all_mir ? E0 - ub : E0 + ub)[off], true);
                 const float k2 = 2.0f * wave_k_fast(N, kscale, u1 + T * q);
                 const float c = mir ? k2 : 0.f;  // the edge slot's lane u1 == 0 is j = N/2: plain
                 v = mk(__builtin_fmaf(c, t.x, v.x), __builtin_fmaf(c, t.y, v.y));
@@ -629,8 +644,8 @@ MW_HD void p2_stage0(int tid, cf (&x)[P], cf* lds) {
     stage0_store<N, P, +1>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE);
 }
 template <int N, int P, int R2>
-MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P], cf* lds) {
-    p2_fetch<N, P, R2>(A, ab, step, tid, f, x);
+MW_HD void p2_load(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P], cf* lds, cf* keep = nullptr) {
+    p2_fetch<N, P, R2>(A, ab, step, tid, f, x, nullptr, keep);
     p2_stage0<N, P, R2>(tid, x, lds);
 }
 // the slope field can be loaded in two parts (p2_fetch) when the fast half-field path applies

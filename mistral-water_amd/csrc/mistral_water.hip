@@ -380,7 +380,9 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
     constexpr bool EARLY_SLOPES = SPARTS && N >= MW_EARLY_SLOPES_MIN_N;
     cf xn[PF ? VT : 1][PF ? P : 1], xn_nyq[PF ? VT : 1], xh_nyq = mk(0.f, 0.f);
     cf xs[PF == 2 ? VT : 1][PF == 2 ? P : 1];  // PF = 2: the stored half of the slope field, parked from the start
-    (void)xn; (void)xn_nyq; (void)xs;
+    constexpr bool KEEP = KeepT1<N, P>::value && P2SlopeParts<N, P>::value;
+    cf t1m[KEEP ? VT : 1][KEEP ? P / 2 : 1];   // raw mirrored height-row values, from the height fetch to the slope assembly (KeepT1)
+    (void)xn; (void)xn_nyq; (void)xs; (void)t1m;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int f = p2_hs_field(k);
@@ -409,7 +411,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
             }
         } else {
 #pragma unroll
-            MW_VT(h) p2_fetch<N, P, R2>(A, ab, step, MW_VTID(h), f, x[h]);
+            MW_VT(h) p2_fetch<N, P, R2>(A, ab, step, MW_VTID(h), f, x[h], nullptr, (KEEP && f == 0) ? t1m[h] : nullptr);
         }
         if constexpr (PF != 0) {
             if (k == 0) {
@@ -431,7 +433,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
         if (f == 2 && SPARTS) {
 #pragma unroll
             MW_VT(h) {
-                p2_fetch<N, P, R2, 2>(A, ab, step, MW_VTID(h), f, x[h]);
+                p2_fetch<N, P, R2, 2>(A, ab, step, MW_VTID(h), f, x[h], nullptr, KEEP ? t1m[h] : nullptr);
                 p2_stage0<N, P, R2>(MW_VTID(h), x[h], set0);
 #ifndef MW_SLOPE_STAGE_FENCE
 #define MW_SLOPE_STAGE_FENCE 1

@@ -102,13 +102,15 @@ void run_pass2_hs(const P2Args& A, int nsteps) {
     constexpr int T = FftGeom<N, P>::T, NT = P2Geom<N, P, R2, true>::NTHREADS, BS = P2Buf<N, P>::BUFSTRIDE;
     std::vector<cf> lds(R2 * BS);
     const Twiddles tw = TwGeom<N, P>::view(A.TW);
-    struct St { P2StateHS<P> s; cf x[P]; };
+    struct St { P2StateHS<P> s; cf x[P]; cf t1m[P / 2]; };
     std::vector<St> st(NT);
+    constexpr bool KEEP = KeepT1<N, P>::value && P2SlopeParts<N, P>::value;  // as k_pass2_hs: raw mirrored height values kept for the slopes
     for (int step = 0; step < nsteps; step++)
         for (int ab = 0; ab < N / R2; ab++)
             for (int k = 0; k < 3; k++) {
                 const int f = p2_hs_field(k);
-                for (int tid = 0; tid < NT; tid++) p2_load<N, P, R2>(A, ab, step, tid, f, st[tid].x, lds.data());
+                for (int tid = 0; tid < NT; tid++)
+                    p2_load<N, P, R2>(A, ab, step, tid, f, st[tid].x, lds.data(), (KEEP && f != 1) ? st[tid].t1m : nullptr);
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
                     for (int tid = 0; tid < NT; tid++) p2_mid_load<N, P, R2>(tid, s, st[tid].x, lds.data());
                     for (int tid = 0; tid < NT; tid++) p2_mid_store<N, P, R2>(tw, tid, s, st[tid].x, lds.data());
