@@ -345,8 +345,8 @@ MW_HD void field_coeffs(int f, float kx, float kz, cf* cx, cf* cz) {
 #define MW_SPLIT_SLOPES 2
 #endif
 #ifndef MW_SPLIT_SLOPES_4096
-#define MW_SPLIT_SLOPES_4096 (MW_SPLIT_SLOPES ? 1 : 0)
-#endif
+#define MW_SPLIT_SLOPES_4096 MW_SPLIT_SLOPES  // round 4: mode 2 everywhere -- with KeepT1 its height-row re-read is gone (4096^2: 275.0 -> 265.0 us
+#endif                                        // per step over 512 steps; before KeepT1 mode 1, the G form, was 0.8 % ahead there)
 MW_HD constexpr int mw_split_slopes(int N) { return N >= 4096 ? MW_SPLIT_SLOPES_4096 : MW_SPLIT_SLOPES; }
 #ifndef MW_SLOPE_FENCE_Q
 #define MW_SLOPE_FENCE_Q 8
@@ -355,7 +355,7 @@ MW_HD constexpr int mw_split_slopes(int N) { return N >= 4096 ? MW_SPLIT_SLOPES_
 #define MW_KEEP_T1 1
 #endif
 #ifndef MW_KEEP_T1_MAX_N
-#define MW_KEEP_T1_MAX_N 2048
+#define MW_KEEP_T1_MAX_N 4096
 #endif
 MW_HD bool p1_field_active(int N, int jb, int f, int cw = 4) {
     if (f == 1) return true;
@@ -987,8 +987,8 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 #endif
 // software prefetch level of k_pass2_hs (0 none, 1 displacement rows during the height field, 2 + slope rows during displacement)
 #ifndef MW_PF_4096
-#define MW_PF_4096 1  // 4096^2 (one workgroup per CU): pass 2 -1.5 %; 2048^2 +1 %, 1024^2 +1 % slower with it
-#endif
+#define MW_PF_4096 0  // displacement rows prefetched during the height field: -1.5 % at 4096^2 in round 2; with KeepT1 (round 4) the plan
+#endif                // without it is 1 % ahead (265.0 vs 267.9 us per step), and 2048^2 / 1024^2 were always slower with it
 #ifndef MW_PF_2048
 #define MW_PF_2048 0
 #endif
