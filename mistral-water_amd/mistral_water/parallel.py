@@ -41,24 +41,3 @@ def max_over_ranks(value: float, dist=None, device=None) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
-
-
-def gather_tiles(local, dist, dst: int = 0):
-    """Collect every rank's tile outputs (a flat tensor) on `dst`; returns the list there, None elsewhere."""
-    world = dist.get_world_size()
-    bufs = [local.new_empty(local.shape) for _ in range(world)] if dist.get_rank() == dst else None
-    dist.gather(local, bufs, dst=dst)
-    return bufs
-
-
-def gather_step_blocks(local_rows, nsteps: int, dist):
-    """All-gather variable-length per-rank step blocks back into time order ([nsteps, ...] on every rank)."""
-    import torch
-    world = dist.get_world_size()
-    sizes = [shard_steps(nsteps, world, r) for r in range(world)]
-    longest = max(hi - lo for lo, hi in sizes)
-    pad = local_rows.new_zeros((longest,) + tuple(local_rows.shape[1:]))
-    pad[: local_rows.shape[0]] = local_rows
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
-    return torch.cat([out[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)

@@ -19,6 +19,30 @@ def _free_port():
     return p
 
 
+# ---- test support: a torch.distributed gather of what the ranks computed (the product gathers over RCCL inside the library,
+# mw_tiles_gather; these two stand in for it on the CPU tier so that the SHARDING ARITHMETIC of mistral_water.parallel -- which seed,
+# which step block, which order -- can be checked end to end without a GPU) ------------------------------------------------------
+def gather_tiles(local, dist, dst: int = 0):
+    """Collect every rank's tile outputs (a flat tensor) on `dst`; returns the list there, None elsewhere."""
+    world = dist.get_world_size()
+    bufs = [local.new_empty(local.shape) for _ in range(world)] if dist.get_rank() == dst else None
+    dist.gather(local, bufs, dst=dst)
+    return bufs
+
+
+def gather_step_blocks(local_rows, nsteps: int, dist, shard_steps):
+    """All-gather variable-length per-rank step blocks back into time order ([nsteps, ...] on every rank)."""
+    import torch
+    world = dist.get_world_size()
+    sizes = [shard_steps(nsteps, world, r) for r in range(world)]
+    longest = max(hi - lo for lo, hi in sizes)
+    pad = local_rows.new_zeros((longest,) + tuple(local_rows.shape[1:]))
+    pad[: local_rows.shape[0]] = local_rows
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return torch.cat([out[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
+
+
 def _worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
@@ -37,13 +61,13 @@ def _worker(rank, world, port, q):
         h0, h0c = O.generate_spectrum(p, parallel.tile_seed(1, rank))
         v, n, c = O.eval_f64(p, h0, h0c, 0.5)
         local = torch.from_numpy(np.concatenate([v.ravel(), n.ravel(), c[:, 0]]))
-        tiles = parallel.gather_tiles(local, dist, dst=0)
+        tiles = gather_tiles(local, dist, dst=0)
         # --- time axis: one ocean, contiguous blocks of 5 steps over 2 ranks ----------------------------------
         g0, g0c = O.generate_spectrum(p, 7)
         lo, hi = parallel.shard_steps(5, world, rank)
         rows = np.stack([O.eval_f64(p, g0, g0c, t)[0][:, 1] for t in parallel.step_times(lo, hi)]) if hi > lo \
             else np.zeros((0, 256))
-        allrows = parallel.gather_step_blocks(torch.from_numpy(rows), 5, dist)
+        allrows = gather_step_blocks(torch.from_numpy(rows), 5, dist, parallel.shard_steps)
         slow = parallel.max_over_ranks(1.0 + rank, dist)
         q.put((rank, None if tiles is None else [t.numpy() for t in tiles], allrows.numpy(), slow, (lo, hi)))
     finally:
