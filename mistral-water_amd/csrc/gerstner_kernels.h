@@ -93,6 +93,9 @@ __global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos,
 // from the host in the kernel arguments), joined by the angle-addition formulas: 7 FMAs per vertex, wave and step instead
 // of a sincos.  The positions are read once per launch; per step only the 12-B result leaves.
 #define MW_GERSTNER_PHASES 256  // nsteps * nwaves per launch (2 KiB of kernel arguments)
+#ifndef MW_POND_STEPS_PER_WG
+#define MW_POND_STEPS_PER_WG 8  // time values per workgroup of k_gerstner_steps (environment MW_POND_STEPS_PER_WG overrides: A/B)
+#endif
 struct GerstnerPhases {
     float cb[MW_GERSTNER_PHASES], sb[MW_GERSTNER_PHASES];  // [step * nwaves + i]
 };
@@ -118,45 +121,42 @@ MW_HD void gerstner_step_vertex(const GerstnerWaves& wv, const GerstnerPhases& p
 }
 
 #if defined(__HIPCC__)
+// A wave's 256 vertices as 4 x 64: lane l owns vertices l, l + 64, l + 128, l + 192 of the chunk, so that every load and store
+// instruction is 64 lanes x 12 B = 768 contiguous bytes (global_load / global_store_dwordx3, non-temporal) -- no LDS turn, no fences,
+// no alignment requirement, no scalar tail (round 4; the float4 + LDS-turn form of round 2 measured 0.62-0.63 of the HBM peak, this
+// one 0.67-0.70).  blockIdx.y = a group of `steps_per_wg` consecutive time values: the step axis is cut into workgroups that come
+// and go, issued in address order, instead of one long-lived workgroup walking all 32 slabs -- on this memory system fresh
+// workgroups beat long-lived ones for every store stream (profiles/r03_hbm_probe.txt); 8 steps per workgroup measured best (the
+// position part, 8 sincos per vertex, is then re-formed 4 times per launch: +13 % VALU, still well under the store time).
 template <int NW>
-__global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts, int64_t nvec,
+__global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts,
                                                         GerstnerWaves wv, GerstnerPhases ph, int nsteps, float amplitude,
-                                                        float frequency, float steepness) {
-    const int64_t nquads = nvec >> 2;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // stores through wave_store_3f4; the write-once stream of nsteps x nverts x 12 B goes out non-temporally
-#ifndef MW_GERSTNER_NT
-#define MW_GERSTNER_NT 1
-#endif
-    __shared__ f4 tile[256 * 3];
-    const int lane = threadIdx.x & 63;
-    f4* wt = tile + (threadIdx.x - lane) * 3;  // this wave's 192 float4
-    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); q0 < nquads; q0 += stride) {  // wave-uniform
-        const int64_t qd = q0 + lane;
-        const f4* p = reinterpret_cast<const f4*>(pos) + (qd < nquads ? qd : q0) * 3;  // (idle lanes of the last wave recompute its first quad)
-        f4 a = p[0], b = p[1], c = p[2];
-        const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+                                                        float frequency, float steepness, int steps_per_wg) {
+    const int step_lo = (int)blockIdx.y * steps_per_wg, step_hi = step_lo + steps_per_wg < nsteps ? step_lo + steps_per_wg : nsteps;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t v0 = ((int64_t)blockIdx.x * 4 + wave) * 256; v0 < nverts; v0 += (int64_t)gridDim.x * 1024) {  // wave-uniform chunk of 256 vertices
+        float v[12];
         float sa[4][NW], ca[4][NW];
+        bool ok[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) gerstner_position_part<NW>(wv, frequency, v[3 * k], v[3 * k + 2], sa[k], ca[k]);
-        const int nf4 = (int)(nquads - q0 < 64 ? nquads - q0 : 64) * 3;  // valid float4 of this wave's chunk
-        for (int step = 0; step < nsteps; step++) {
-            float o[12];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                gerstner_step_vertex<NW>(wv, ph, step, amplitude, steepness, sa[k], ca[k], v[3 * k], v[3 * k + 1], v[3 * k + 2], &o[3 * k]);
-            f4 r0 = {o[0], o[1], o[2], o[3]}, r1 = {o[4], o[5], o[6], o[7]}, r2 = {o[8], o[9], o[10], o[11]};
-            wave_store_3f4<MW_GERSTNER_NT != 0>(wt, lane, r0, r1, r2, reinterpret_cast<f4*>(out + (size_t)step * nverts * 3) + q0 * 3, nf4);
+        for (int k = 0; k < 4; k++) {
+            const int64_t vid = v0 + k * 64 + lane;
+            ok[k] = vid < nverts;
+            const float* p = pos + 3 * (ok[k] ? vid : v0);
+            v[3 * k] = p[0]; v[3 * k + 1] = p[1]; v[3 * k + 2] = p[2];
+            gerstner_position_part<NW>(wv, frequency, v[3 * k], v[3 * k + 2], sa[k], ca[k]);
         }
-    }
-    for (int64_t vtx = nvec + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vtx < nverts; vtx += stride) {  // see k_gerstner
-        float sa[NW], ca[NW];
-        gerstner_position_part<NW>(wv, frequency, pos[3 * vtx], pos[3 * vtx + 2], sa, ca);
-        for (int step = 0; step < nsteps; step++) {
-            float o[3];
-            gerstner_step_vertex<NW>(wv, ph, step, amplitude, steepness, sa, ca, pos[3 * vtx], pos[3 * vtx + 1], pos[3 * vtx + 2], o);
-            float* po = out + (size_t)step * nverts * 3 + 3 * vtx;
-            po[0] = o[0]; po[1] = o[1]; po[2] = o[2];
+        for (int step = step_lo; step < step_hi; step++) {
+            float* dst = out + (size_t)step * nverts * 3 + 3 * v0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float o[3];
+                gerstner_step_vertex<NW>(wv, ph, step, amplitude, steepness, sa[k], ca[k], v[3 * k], v[3 * k + 1], v[3 * k + 2], o);
+                if (ok[k]) {
+                    float* q = dst + 3 * (k * 64 + lane);
+                    mw_store_stream<true>(&q[0], o[0]); mw_store_stream<true>(&q[1], o[1]); mw_store_stream<true>(&q[2], o[2]);
+                }
+            }
         }
     }
 }
@@ -180,16 +180,14 @@ static inline hipError_t gerstner_launch_steps(const float* d_pos, int64_t nvert
             ph.cb[k * nwaves + i] = (float)cos(b);
             ph.sb[k * nwaves + i] = (float)sin(b);
         }
-    // the step stride of the output is nverts * 12 B: 16-B aligned for every step only when nverts % 4 == 0
-    const bool vec = mw_aligned16(d_pos) && mw_aligned16(d_out) && (nsteps == 1 || (nverts & 3) == 0);
-    const int64_t nvec = vec ? (nverts & ~(int64_t)3) : 0;
-    int64_t blocks = ((vec ? (nverts >> 2) : nverts) + 255) / 256;
+    int64_t blocks = (nverts + 1023) / 1024;  // 1024 vertices per 256-thread workgroup and trip
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (nwaves == 4)
-        k_gerstner_steps<4><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, nverts, nvec, wv, ph, nsteps, amplitude, frequency, steepness);
-    else
-        k_gerstner_steps<8><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(d_pos, d_out, nverts, nvec, wv, ph, nsteps, amplitude, frequency, steepness);
+    static const int spw_env = [] { const char* e = std::getenv("MW_POND_STEPS_PER_WG"); return e ? std::atoi(e) : 0; }();
+    const int spw = spw_env > 0 ? (spw_env < nsteps ? spw_env : nsteps) : (MW_POND_STEPS_PER_WG < nsteps ? MW_POND_STEPS_PER_WG : nsteps);
+    const dim3 grid((unsigned)blocks, (unsigned)((nsteps + spw - 1) / spw));
+    if (nwaves == 4) k_gerstner_steps<4><<<grid, dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness, spw);
+    else k_gerstner_steps<8><<<grid, dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness, spw);
     return hipGetLastError();
 }
 #endif
