@@ -5,4 +5,5 @@ tag=${1:-r04}
 mkdir -p gpurun_out/$tag
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -15 > gpurun_out/$tag/pytest_gpu.txt
 tail -6 gpurun_out/$tag/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 bash tools/profile_round.sh $tag 2>&1 | tail -30
