@@ -97,6 +97,24 @@ def test_lds_exchange_layouts(oracle, layout):
     assert rp.M == 512 and all((u == v).all() for u, v in zip(ra, rb))
 
 
+def test_round4_shortcuts_change_no_bit(oracle):
+    """Round-4 kernel changes that remove work without touching arithmetic, against builds with them switched off -- bit for bit:
+    LastInRegs (N = P^S: the last radix-P pass stays in registers instead of an identity round trip through LDS; 512 = 8^3 here, the
+    product's 4096 = 16^3 is covered on the GPU) and KeepT1 (the slope assembly takes the mirrored height-row values from the height
+    fetch instead of loading them a second time; sequential-halo kernel)."""
+    import emul_build
+    base = emul_build.load()
+    for defs in (("MW_LAST_IN_REGS=0",), ("MW_KEEP_T1=0",)):
+        alt = emul_build.Emul(defs=defs)
+        for N, pts, hs in ((512, 8, False), (512, 8, True), (256, 16, True)):
+            p = workloads.fftmesh_params(N)
+            h0, h0c = oracle.generate_spectrum(p, 11)
+            base.set_variant(force_hs=hs); alt.set_variant(force_hs=hs)
+            a, b = base.evaluate(p, h0, h0c, [2.75], pts=pts), alt.evaluate(p, h0, h0c, [2.75], pts=pts)
+            assert all((u == v).all() for u, v in zip(a, b)), (defs, N, pts, hs)
+        base.set_variant(force_hs=False)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_slope_field_storage_modes(oracle, mode):
     """MW_SPLIT_SLOPES: the slope field crosses the exchange buffer whole (0), as the kx part G for j <= N/2 with
