@@ -654,15 +654,15 @@ def direct(a, mw, torch, dev, stream, barrier, dist, rank, world):
         step_ms = kern[0][1] + kern[1][1]
         if czt:
             # chirp-z form (csrc/czt_kernels.h; the default for N <= 2048): O(N^2 log N), memory-bound.  Algorithmic bytes per grid point by
-            # SURVEY 8d's general formula 16 + 16 F + out with F = 5 unpacked complex fields crossing between the two axis passes:
-            # 16 (h0, h0conj) + 80 (5 fields written + read once) + 28 (vertex, normal, whitecap) = 124 B.
-            bpp = 16 + 16 * 5 + 28
+            # SURVEY 8d's general formula 16 + 16 F + out with F = 3 Hermitian-packed complex planes crossing between the two axis passes
+            # (round 4; five unpacked fields before): 16 (h0, h0conj) + 48 (3 planes written + read once) + 28 (vertex, normal, whitecap) = 92 B.
+            bpp = 16 + 16 * 3 + 28
             roof = {"bound": "hbm", "kernel": "k_czt (2 launches) + spectrum / assembly kernels = one step", "achieved": bpp * NN / (step_ms * 1e-3) / 1e9,
                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bpp * NN / (step_ms * 1e-3) / HBM_PEAK, "traffic": None,
                     "algorithmic_bytes_per_point": bpp, "bytes_per_launch_group": bpp * NN, "launch_group_us": step_ms * 1e3,
                     "kernels": [{"name": nm, "us_per_step": ms * 1e3} for nm, ms in kern],
-                    "note": "achieved = 124 B x N^2 / the mean duration of one step's five launches (HIP events on the launch stream).  Small "
-                            "grids are launch-latency-bound (N = 50: five launches of a few workgroups), and up to N ~ 1500 the whole working "
+                    "note": "achieved = 92 B x N^2 / the mean duration of one step's three launches (HIP events on the launch stream).  Small "
+                            "grids are launch-latency-bound (N = 50: three launches of a few workgroups), and up to N ~ 1500 the whole working "
                             "set sits in the 256-MiB Infinity Cache: the fraction says how far one step is from streaming at HBM rate"}
             path = f"chirp-z: two Stockham transforms of size {1 << max(6, (2 * N - 2).bit_length())} per line and axis (k_czt x 2)"
         else:

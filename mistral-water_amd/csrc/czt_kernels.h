@@ -31,40 +31,58 @@ struct CztArgs {
     const cf* Hh = nullptr;   // [M] forward transform of the wrapped kernel g
     const cf* TWf = nullptr;  // twiddle tables of the size-M forward (sign -1) and inverse (+1) transforms, TwGeom<M, P> layout
     const cf* TWi = nullptr;
-    int N = 0, rows = 0, in_ld = 0, out_ld = 0;
+    int nin = 0, nout = 0;    // values per input row (zero-padded up to M), values per output row
+    int rows = 0, in_ld = 0, out_ld = 0;
     long long in_plane = 0, out_plane = 0;
     // first launch of a step: h0 != nullptr -> the input planes are not read but FORMED from the spectrum on the way in
-    // (czt_spec_value; the five multiplier spectra never exist in memory)
+    // (czt_packed_value; the multiplier spectra never exist in memory)
     const cf* h0 = nullptr;
     const cf* h0c = nullptr;
     float t = 0.f;
     OceanConsts C = {};
 };
 
-// S/FFTMesh.cs:178-190 htilde(t) at (i, j) times the multiplier of field f (:211-215): f = 0 height, 1 kx/|k|, 2 -kz/|k|, 3 kx, 4 kz
-MW_HD cf czt_spec_value(const OceanConsts& C, const cf* h0, const cf* h0c, float t, int i, int j, int f) {
+// HERMITIAN PACKING ON ANY GRID (round 4): five real outputs in THREE complex sums.  The outputs are real / imaginary parts of
+// S_f(a,b) = sum_ij F_f(i,j) e^{i theta [(i-c)(a-c') + (j-c)(b-c')]}, c = N/2 (S/FFTMesh.cs:211-218).  conj S runs over the MIRRORED
+// indices i' = N - i, which lie in [1, N]: on the index set [0, N]^2 (N + 1 points per axis, F = 0 outside [0, N)^2) the real part of
+// S_0 is the sum of Hh(i,j) = 1/2 [h~(i,j) + conj h~(N-i, N-j)], and because every multiplier is real and ODD in k (k(N - i) = -k(i)),
+//     H + i Dx = sum Hh (1 + kx/|k|),    Sx + i Sz = sum Hh (kz - i kx),    Dz = sum Hh (i kz/|k|)
+// (checked against the brute-force sums to 1e-14 for even, odd and non-commensurate grids).  Fields of ONE scale share a plane:
+// the slopes carry a factor |k| over height and displacement -- 220 on the Inspector-default grid --, and a float32 transform's
+// error is relative to the plane's largest entry (Dz packed with Sx measured 7e-6 there instead of 2e-7).  omega(N - i, N - j) = omega(i, j) bit for bit, so one sine serves both halves.  Three planes of
+// (N + 1) x (N + 1) go through the chirp-z launches instead of five of N x N: 0.6 of the transform work.
+#define MW_CZT_PLANES 3
+MW_HD cf czt_packed_value(const OceanConsts& C, const cf* h0, const cf* h0c, float t, int i, int j, int plane) {
     const int N = C.N;
-    const size_t idx = (size_t)i * N + j;
     float s, c;
     mw_sincos(omega_t_f32(N, C.length, C.gravity, i, j, t), &s, &c);
-    const cf a = h0[idx], b = h0c[idx];
-    const cf h = mk(a.x * c - a.y * s + b.x * c + b.y * s, a.x * s + a.y * c - b.x * s + b.y * c);  // :188
-    if (f == 0) return h;
+    cf h = mk(0.f, 0.f), hm = mk(0.f, 0.f);
+    if (i < N && j < N) {
+        const cf a = h0[(size_t)i * N + j], b = h0c[(size_t)i * N + j];
+        h = mk(a.x * c - a.y * s + b.x * c + b.y * s, a.x * s + a.y * c - b.x * s + b.y * c);  // :188
+    }
+    if (i > 0 && j > 0) {
+        const size_t m = (size_t)(N - i) * N + (N - j);
+        const cf a = h0[m], b = h0c[m];
+        hm = mk(a.x * c - a.y * s + b.x * c + b.y * s, a.x * s + a.y * c - b.x * s + b.y * c);
+    }
+    const cf Hh = mk(0.5f * (h.x + hm.x), 0.5f * (h.y - hm.y));
     const float kx = wave_k(N, C.length, i), kz = wave_k(N, C.length, j);
-    if (f == 3) return cscale(h, kx);
-    if (f == 4) return cscale(h, kz);
+    if (plane == 1) return cmul(Hh, mk(kz, -kx));  // Hh (kz - i kx): real part Sx (= Im sum kx h~), imaginary part Sz
     const float kl = sqrtf(kx * kx + kz * kz);
-    float ux = 0.f, uzn = 0.f;
-    if (!(kl < MW_EPS_F)) { ux = kx / kl; uzn = -kz / kl; }  // :213-215
-    return cscale(h, f == 1 ? ux : uzn);
+    float ux = 0.f, uz = 0.f;
+    if (!(kl < MW_EPS_F)) { ux = kx / kl; uz = kz / kl; }  // |k| < EPSILON: skipped, :213-215
+    if (plane == 0) return cscale(Hh, 1.0f + ux);  // real part H, imaginary part Dx
+    return mk(-(Hh.y * uz), Hh.x * uz);            // Hh (i kz/|k|): real part Dz (= Im sum (-kz/|k|) h~)
 }
 
 // transform size and points per thread for a grid of N points per axis (0: N too large for one workgroup-resident transform)
-inline int czt_size(int N) {
+inline int czt_size_io(int nin, int nout) {  // the cyclic convolution must hold nin + nout - 1 distinct lags
     int M = 64;
-    while (M < 2 * N - 1) M *= 2;
+    while (M < nin + nout - 1) M *= 2;
     return M <= 4096 ? M : 0;
 }
+inline int czt_size(int N) { return czt_size_io(N + 1, N); }  // the packed planes carry N + 1 points per axis
 constexpr int czt_points(int M) { return M >= 256 ? 16 : 8; }
 constexpr int czt_rows(int M) { return (512 / (M / czt_points(M))) < 1 ? 1 : ((512 / (M / czt_points(M))) > 8 ? 8 : (512 / (M / czt_points(M)))); }
 
@@ -75,7 +93,7 @@ MW_HD void czt_load(const CztArgs& A, int f, int row, int u, bool live, cf (&x)[
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int n = u + T * q;
-        x[q] = (live && n < A.N) ? cmul(A.h0 ? czt_spec_value(A.C, A.h0, A.h0c, A.t, row, n, f) : r[n], A.w1[n]) : mk(0.f, 0.f);  // zero padding up to M
+        x[q] = (live && n < A.nin) ? cmul(A.h0 ? czt_packed_value(A.C, A.h0, A.h0c, A.t, row, n, f) : r[n], A.w1[n]) : mk(0.f, 0.f);  // zero padding up to M
     }
 }
 template <int M, int P>
@@ -91,7 +109,7 @@ MW_HD void czt_store(const CztArgs& A, int f, int row, int u, const cf (&x)[P]) 
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int n = u + T * q;
-        if (n < A.N) o[(size_t)n * A.out_ld] = cmul(x[q], A.w2[n]);
+        if (n < A.nout) o[(size_t)n * A.out_ld] = cmul(x[q], A.w2[n]);
     }
 }
 
@@ -117,22 +135,26 @@ inline void czt_fft_f64(std::vector<double>& re, std::vector<double>& im, int si
             }
     }
 }
-inline void czt_build_tables(int N, int M, float unit_width, float length, std::vector<cf>& w1, std::vector<cf>& w2, std::vector<cf>& Hh) {
+// nin input indices i = 0 .. nin-1 (N, or N + 1 for the packed planes), N outputs a = 0 .. N-1; M >= nin + N - 1
+inline void czt_build_tables(int N, int nin, int M, float unit_width, float length, std::vector<cf>& w1, std::vector<cf>& w2, std::vector<cf>& Hh) {
     const double theta = 2.0 * M_PI * (double)unit_width / (double)length;
     const double c = N / 2.0, cp = (N - 1) / 2.0, delta = cp - c;
     auto chirp = [&](double s) {  // e^{i theta s^2 / 2}, the phase reduced in double
         const double ph = fmod(theta * s * s / 2.0, 2.0 * M_PI);
         return std::pair<double, double>(cos(ph), sin(ph));
     };
-    w1.resize(N); w2.resize(N); Hh.resize(M);
-    for (int i = 0; i < N; i++) {
-        auto a = chirp((double)i - c), b = chirp((double)i - cp);
+    w1.resize(nin); w2.resize(N); Hh.resize(M);
+    for (int i = 0; i < nin; i++) {
+        auto a = chirp((double)i - c);
         w1[i] = mk((float)a.first, (float)a.second);
+    }
+    for (int i = 0; i < N; i++) {
+        auto b = chirp((double)i - cp);
         w2[i] = mk((float)(b.first / M), (float)(b.second / M));
     }
-    // conv[a] = sum_i y[i] h[a - i] with h[m] = g[-m] = e^{-i theta (-m + delta)^2 / 2}, |m| <= N - 1, wrapped modulo M
+    // conv[a] = sum_i y[i] h[a - i] with h[m] = g[-m] = e^{-i theta (-m + delta)^2 / 2}, -(nin - 1) <= m <= N - 1, wrapped modulo M
     std::vector<double> re(M, 0.0), im(M, 0.0);
-    for (int m = -(N - 1); m <= N - 1; m++) {
+    for (int m = -(nin - 1); m <= N - 1; m++) {
         auto g = chirp((double)(-m) + delta);
         re[(m + M) % M] = g.first;
         im[(m + M) % M] = -g.second;

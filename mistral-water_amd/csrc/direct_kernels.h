@@ -219,16 +219,16 @@ __global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
     final_stage<M, P, +1>(x, u, twi.TF);
     if (live) czt_store<M, P>(A, f, row, u, x);
 }
-// vertices / normals / whitecap from the five complex output planes O[f][a][b]: H = Re, Dx Dz Sx Sz = Im (S/FFTMesh.cs:211-218),
-// and the forward-difference Jacobian (:258-274) from the displacement planes of the two neighbours -- one launch; hds is written
-// only for the test hook (mw_debug_evaluate_hds)
+// vertices / normals / whitecap from the three packed output planes O[p][a][b] = (H + i Dx, Sx + i Sz, Dz) (czt_packed_value;
+// S/FFTMesh.cs:211-218), and the forward-difference Jacobian (:258-274) from the displacement of the two neighbours -- one launch;
+// hds also serves the test hook (mw_debug_evaluate_hds)
 __global__ void k_czt_assemble_white(OceanConsts C, const cf* O, cf* hds, float* vertices, float* normals, float* white, int white_stride) {
     const int N = C.N;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * N) return;
     int a = idx / N, b = idx % N;
     const size_t NN = (size_t)N * N;
-    const float h = O[idx].x, dx = O[NN + idx].y, dz = O[2 * NN + idx].y, sx = O[3 * NN + idx].y, sz = O[4 * NN + idx].y;
+    const float h = O[idx].x, dx = O[idx].y, sx = O[NN + idx].x, sz = O[NN + idx].y, dz = O[2 * NN + idx].x;
     const float mag = sqrtf(sx * sx + 1.0f + sz * sz);  // up - n, S/FFTMesh.cs:218
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (mag > 1e-5f) { nx = sx / mag; ny = 1.0f / mag; nz = sz / mag; }
@@ -239,7 +239,7 @@ __global__ void k_czt_assemble_white(OceanConsts C, const cf* O, cf* hds, float*
     if (hds) hds[idx] = mk(dx, dz);                                                        // :247
     const bool hi = a != N - 1, hj = b != N - 1;
     const cf z = mk(0.f, 0.f);
-    const cf di = hi ? mk(O[NN + idx + N].y, O[2 * NN + idx + N].y) : z, dj = hj ? mk(O[NN + idx + 1].y, O[2 * NN + idx + 1].y) : z;
+    const cf di = hi ? mk(O[idx + N].y, O[2 * NN + idx + N].x) : z, dj = hj ? mk(O[idx + 1].y, O[2 * NN + idx + 1].x) : z;
     const float xx = whitecap(mk(dx, dz), di, dj, hi, hj, nx, nz);
     if (white_stride == 1) white[idx] = xx;
     else { white[4 * idx] = xx; white[4 * idx + 1] = xx; white[4 * idx + 2] = xx; white[4 * idx + 3] = xx; }
@@ -257,10 +257,11 @@ static inline int czt_alloc(CztState& z, int N) {
     const int P = czt_points(z.M);
     const std::vector<cf> tf = build_twiddle_table(z.M, P, -1), ti = build_twiddle_table(z.M, P, +1);
     const size_t NN = (size_t)N * N;
-    if (hipMalloc((void**)&z.w1, sizeof(cf) * N) != hipSuccess || hipMalloc((void**)&z.w2, sizeof(cf) * N) != hipSuccess ||
+    if (hipMalloc((void**)&z.w1, sizeof(cf) * (N + 1)) != hipSuccess || hipMalloc((void**)&z.w2, sizeof(cf) * N) != hipSuccess ||
         hipMalloc((void**)&z.Hh, sizeof(cf) * z.M) != hipSuccess || hipMalloc((void**)&z.TWf, sizeof(cf) * tf.size()) != hipSuccess ||
         hipMalloc((void**)&z.TWi, sizeof(cf) * ti.size()) != hipSuccess ||
-        hipMalloc((void**)&z.TT, sizeof(cf) * 5 * NN) != hipSuccess || hipMalloc((void**)&z.O, sizeof(cf) * 5 * NN) != hipSuccess ||
+        hipMalloc((void**)&z.TT, sizeof(cf) * MW_CZT_PLANES * (size_t)N * (N + 1)) != hipSuccess ||
+        hipMalloc((void**)&z.O, sizeof(cf) * MW_CZT_PLANES * NN) != hipSuccess ||
         hipMemcpy(z.TWf, tf.data(), sizeof(cf) * tf.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(z.TWi, ti.data(), sizeof(cf) * ti.size(), hipMemcpyHostToDevice) != hipSuccess) {
         czt_free(z);
@@ -274,7 +275,7 @@ static hipError_t czt_launch(const CztArgs& A, hipStream_t st) {
     static AttrOnce attr;
     hipError_t e = attr.set(reinterpret_cast<const void*>(&k_czt<M, P, RW>), LB);
     if (e != hipSuccess) return e;
-    k_czt<M, P, RW><<<dim3((A.rows + RW - 1) / RW, 5), dim3(RW * M / P), LB, st>>>(A);
+    k_czt<M, P, RW><<<dim3((A.rows + RW - 1) / RW, MW_CZT_PLANES), dim3(RW * M / P), LB, st>>>(A);
     return hipGetLastError();
 }
 // ev (measurement hook): three events recorded before the spectrum kernel, before and after the two k_czt launches
@@ -285,9 +286,9 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
     const unsigned nb = (unsigned)(((size_t)N * N + 127) / 128);
     if (z.table_length != C.length || z.table_unit_width != C.unit_width) {  // chirps and the kernel's transform: once per handle / length
         std::vector<cf> w1, w2, Hh;
-        czt_build_tables(N, z.M, C.unit_width, C.length, w1, w2, Hh);
+        czt_build_tables(N, N + 1, z.M, C.unit_width, C.length, w1, w2, Hh);
         hipError_t e = hipStreamSynchronize(st);  // a step still in flight may be reading the old tables
-        if (e == hipSuccess) e = hipMemcpy(z.w1, w1.data(), sizeof(cf) * N, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(z.w1, w1.data(), sizeof(cf) * (N + 1), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(z.w2, w2.data(), sizeof(cf) * N, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(z.Hh, Hh.data(), sizeof(cf) * z.M, hipMemcpyHostToDevice);
         if (e != hipSuccess) return e;
@@ -297,12 +298,16 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
     if (ev) { hipEventRecord(ev[0], st); hipEventRecord(ev[1], st); }
     CztArgs A;
     A.w1 = z.w1; A.w2 = z.w2; A.Hh = z.Hh; A.TWf = z.TWf; A.TWi = z.TWi;
-    A.N = N; A.rows = N; A.in_ld = N; A.out_ld = N; A.in_plane = (long long)N * N; A.out_plane = (long long)N * N;
+    A.nin = N + 1; A.nout = N;  // the packed planes live on the index set [0, N]^2 (czt_packed_value)
     hipError_t e = hipSuccess;
     for (int pass = 0; pass < 2 && e == hipSuccess; pass++) {
-        A.in = z.TT;                     // along j (rows i, formed from the spectrum) -> TT[f][b][i]; along i (rows b) -> O[f][a][b]
+        // along j: rows i = 0 .. N formed from the spectrum -> TT[p][b][i] (N rows of N + 1); along i: rows b -> O[p][a][b]
+        A.in = z.TT;
         A.out = pass == 0 ? z.TT : z.O;
         A.h0 = pass == 0 ? h0 : nullptr; A.h0c = h0c; A.t = t; A.C = C;
+        A.rows = pass == 0 ? N + 1 : N;
+        A.in_ld = N + 1; A.in_plane = (long long)N * (N + 1);
+        A.out_ld = pass == 0 ? N + 1 : N; A.out_plane = pass == 0 ? (long long)N * (N + 1) : (long long)N * N;
         switch (z.M) {
             case 64: e = czt_launch<64>(A, st); break;
             case 128: e = czt_launch<128>(A, st); break;

@@ -489,18 +489,39 @@ int emul_p1_grid_blocks(int gx, int nsteps, int tgroup) { return p1_grid_blocks(
 // sum_ij F_f(i,j) e^{i(k_i x_a + k_j z_b)} for nfields complex N x N fields through the two chirp-z launches (along j, then
 // along i; each stores transposed), tables from czt_build_tables: in [f][i][j], out [f][a][b], interleaved (re, im) float32
 int emul_czt2d(int N, float unit_width, float length, int nfields, const float* in_xy, float* out_xy) {
-    const int M = czt_size(N);
+    const int M = czt_size_io(N, N);
     if (!M) return 2;
     std::vector<cf> w1, w2, Hh, tmp((size_t)nfields * N * N);
-    czt_build_tables(N, M, unit_width, length, w1, w2, Hh);
+    czt_build_tables(N, N, M, unit_width, length, w1, w2, Hh);
     CztArgs A;
     A.w1 = w1.data(); A.w2 = w2.data(); A.Hh = Hh.data();
-    A.N = N; A.rows = N; A.in_ld = N; A.out_ld = N; A.in_plane = (long long)N * N; A.out_plane = (long long)N * N;
+    A.nin = N; A.nout = N; A.rows = N; A.in_ld = N; A.out_ld = N; A.in_plane = (long long)N * N; A.out_plane = (long long)N * N;
     A.in = reinterpret_cast<const cf*>(in_xy); A.out = tmp.data();          // along j: tmp[f][b][i]
     int r = czt_pass(M, A, nfields);
     if (r) return r;
     A.in = tmp.data(); A.out = reinterpret_cast<cf*>(out_xy);               // along i: out[f][a][b]
     return czt_pass(M, A, nfields);
+}
+// the product's form: the three Hermitian-packed planes formed from (h0, h0conj, t) on the index set [0, N]^2 (czt_packed_value),
+// through the same two launches as czt_evaluate runs them; out [3][a][b] = (H + i Dx, Sx + i Sz, Dz + i 0)
+int emul_czt_packed(int N, float unit_width, float length, float gravity, const float* h0_xy, const float* h0c_xy, float t, float* out_xy) {
+    const int M = czt_size(N);
+    if (!M) return 2;
+    std::vector<cf> w1, w2, Hh, tmp((size_t)MW_CZT_PLANES * N * (N + 1));
+    czt_build_tables(N, N + 1, M, unit_width, length, w1, w2, Hh);
+    CztArgs A;
+    A.w1 = w1.data(); A.w2 = w2.data(); A.Hh = Hh.data();
+    A.nin = N + 1; A.nout = N;
+    A.C.N = N; A.C.length = length; A.C.gravity = gravity; A.C.unit_width = unit_width; A.C.choppiness = 1.f;
+    A.h0 = reinterpret_cast<const cf*>(h0_xy); A.h0c = reinterpret_cast<const cf*>(h0c_xy); A.t = t;
+    A.in = tmp.data(); A.out = tmp.data();
+    A.rows = N + 1; A.in_ld = N + 1; A.in_plane = (long long)N * (N + 1); A.out_ld = N + 1; A.out_plane = (long long)N * (N + 1);
+    int r = czt_pass(M, A, MW_CZT_PLANES);
+    if (r) return r;
+    A.h0 = nullptr;
+    A.out = reinterpret_cast<cf*>(out_xy);
+    A.rows = N; A.out_ld = N; A.out_plane = (long long)N * N;
+    return czt_pass(M, A, MW_CZT_PLANES);
 }
 
 }  // extern "C"

@@ -131,6 +131,15 @@ class Emul:
         assert r == 0, f"emul_czt2d -> {r}"
         return out[..., 0] + 1j * out[..., 1], fin[..., 0].astype(np.float64) + 1j * fin[..., 1]
 
+    def czt_packed(self, p, h0, h0c, t):
+        """The product's chirp-z step: three Hermitian-packed planes formed from (h0, h0conj, t) on the index set [0, N]^2, two
+        launches -> complex [3, N, N] = (H + i Dx, Sx + i Sz, Dz + i 0)."""
+        out = np.empty((3, p.N, p.N, 2), np.float32)
+        r = self.L.emul_czt_packed(int(p.N), C.c_float(p.unit_width), C.c_float(p.length), C.c_float(p.gravity),
+                                   _p(np.ascontiguousarray(h0, np.float32)), _p(np.ascontiguousarray(h0c, np.float32)), C.c_float(t), _p(out))
+        assert r == 0, f"emul_czt_packed -> {r}"
+        return out[..., 0] + 1j * out[..., 1]
+
     def gerstner_steps(self, pos, waves, amplitude, frequency, steepness, times):
         pos = np.ascontiguousarray(pos, np.float32)
         wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)

@@ -304,3 +304,13 @@ def test_chirp_z_form_equals_the_separable_sum(emul, oracle, N, u, L):
     want = oracle.transform_matmul_f64(p, fin)            # of the float32-rounded spectra the kernels see
     for f in range(5):
         assert np.abs(got[f] - want[f]).max() <= 2e-6 * np.abs(want[f]).max(), (f, np.abs(got[f] - want[f]).max() / np.abs(want[f]).max())
+    # the product's form (round 4): five real outputs in THREE Hermitian-packed planes on the index set [0, N]^2 (czt_packed_value):
+    # (H + i Dx, Sx + i Sz, Dz + i 0) against the real / imaginary parts of the five f64 sums (S/FFTMesh.cs:211-218)
+    S = oracle.transform_matmul_f64(p, oracle.htilde_fields_f64(p, h0, h0c, 1.25))
+    pk = emul.czt_packed(p, h0, h0c, 1.25)
+    pairs = ((pk[0].real, S[0].real, "H"), (pk[0].imag, S[1].imag, "Dx"), (pk[1].real, S[3].imag, "Sx"), (pk[1].imag, S[4].imag, "Sz"),
+             (pk[2].real, S[2].imag, "Dz"))
+    for gotr, wantr, nm in pairs:      # each against the scale of ITS plane (fields of one scale share a plane)
+        scale = max(np.abs(wantr).max(), np.abs(S[0].real).max() if nm in ("H", "Dx", "Dz") else np.abs(S[3].imag).max())
+        assert np.abs(gotr - wantr).max() <= 3e-6 * scale, (nm, np.abs(gotr - wantr).max() / scale)
+    assert np.abs(pk[2].imag).max() <= 3e-6 * np.abs(S[0].real).max()
