@@ -7,14 +7,14 @@
 // one axis of the sum is a chirp-modulated CONVOLUTION
 //     out[a] = w2[a] * sum_i (x[i] w1[i]) g[i - a],   w1[i] = e^{i theta (i-c)^2/2},  w2[a] = e^{i theta (a-c')^2/2},
 //                                                      g[d]  = e^{-i theta (d+delta)^2/2}
-// evaluated by two LDS-staged Stockham transforms of size M >= 2N - 1 (the passes of mw_math.h, the same code the FFT path
+// evaluated by two LDS-staged Stockham transforms of size M >= n_in + n_out - 1 (the passes of mw_math.h, the same code the FFT path
 // runs): forward transform of the zero-padded x w1, product with the precomputed transform of the wrapped kernel, inverse
 // transform, post-chirp (the 1/M of the unnormalised inverse folded into w2).  The 2-D sum is this along j, then along i;
 // every launch stores its result transposed, so both launches read contiguous rows and the second one lands in [a][b].
 // All chirps and the kernel's transform are formed in f64 on the host once per handle (they do not depend on t).
 //
 // Phase functions are MW_HD so that tests/emul steps the same code on the host (tests/test_emul.py::test_chirp_z_*).
-// STATUS (round 4): green on hardware at N = 12 ... 1000 and the default for every non-FFT grid with 2N - 1 <= 4096
+// STATUS (round 4): green on hardware at N = 12 ... 1500 and the default for every non-FFT grid with 2N <= 4096
 // (direct_alloc); the MFMA GEMM form (direct_kernels.h) serves larger grids and MW_DIRECT_CZT=0.
 #pragma once
 #include "fftmesh_kernels.h"

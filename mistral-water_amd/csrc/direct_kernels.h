@@ -20,11 +20,11 @@
 
 namespace mw {
 
-// chirp-z form (czt_kernels.h; the default for N <= 2048): tables + the three complex work arrays
+// chirp-z form (czt_kernels.h; the default for N <= 2048): tables + the two complex work arrays
 struct CztState {
     int M = 0;
     cf *w1 = nullptr, *w2 = nullptr, *Hh = nullptr, *TWf = nullptr, *TWi = nullptr;
-    cf *TT = nullptr, *O = nullptr;  // [5][N][N] each: after the z sum (transposed), after the x sum (the spectra are formed on the way in)
+    cf *TT = nullptr, *O = nullptr;  // packed planes (czt_packed_value): [3][N][N + 1] after the z sum (transposed), [3][N][N] after the x sum
     float table_length = -1.f, table_unit_width = -1.f;
 };
 
@@ -164,8 +164,8 @@ __global__ void k_direct_white(int N, const cf* hds, const float* normals, float
 
 // ---- chirp-z launches ---------------------------------------------------------------------------------------------------
 // one axis of the sum for RW rows per workgroup: pre-chirp + zero padding, forward transform, kernel product, inverse
-// transform, post-chirp, transposed store (czt_kernels.h).  Twiddles come from global memory (L1 / L2 hits): not a throughput
-// kernel yet.  Barriers are workgroup-uniform: rows past the end compute on zeros and store nothing.
+// transform, post-chirp, transposed store (czt_kernels.h).  Twiddles beyond the first table come from global memory (L1 / L2 hits).
+// Barriers are workgroup-uniform: rows past the end compute on zeros and store nothing.
 #ifndef MW_CZT_XCD_GROUP
 #define MW_CZT_XCD_GROUP 1
 #endif
@@ -278,7 +278,7 @@ static hipError_t czt_launch(const CztArgs& A, hipStream_t st) {
     k_czt<M, P, RW><<<dim3((A.rows + RW - 1) / RW, MW_CZT_PLANES), dim3(RW * M / P), LB, st>>>(A);
     return hipGetLastError();
 }
-// ev (measurement hook): three events recorded before the spectrum kernel, before and after the two k_czt launches
+// ev (measurement hook): ev[0], ev[1] before and ev[2] after the two k_czt launches (the spectrum is formed inside the first one)
 static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h0, const cf* h0c, float t, float* dv, float* dn, float* dw,
                                       int white_stride, hipStream_t st, hipEvent_t* ev = nullptr) {
     CztState& z = d.czt;
@@ -331,7 +331,7 @@ static inline void direct_free(DirectState& d) {
     d = DirectState();
 }
 static inline int direct_alloc(DirectState& d, int N, hipStream_t st) {
-    // The chirp-z form is the default wherever one workgroup holds the transform (2N - 1 <= 4096, i.e. N <= 2048): first hardware
+    // The chirp-z form is the default wherever one workgroup holds the transform (N + 1 inputs, N outputs: 2N <= 4096): first hardware
     // run in round 4 -- 2.4x (N = 100) to 5.8x (N = 1000) faster than the GEMM form and an order of magnitude more accurate on
     // grids with large phases (profiles/r04a_bench_direct_*).  MW_DIRECT_CZT=0 selects the GEMM form (A/B, and the path of larger N).
     const char* env = std::getenv("MW_DIRECT_CZT");
