@@ -339,8 +339,9 @@ MW_HD void field_coeffs(int f, float kx, float kz, cf* cx, cf* cz) {
 //   mode 2 (stores T3):  T3(a,j) = T3(a,j)                              for j <= N/2
 //                        T3(a,j) = conj(T3(a,m) - 2 kz(m) T1(a,m)), m = N - j   -- only the mirrored half re-reads T1
 // 2.0 instead of 2.5 complex fields cross the exchange buffer and pass 1 transforms a fifth less.
-// Mode 2 issues half as many height-row loads: +2 % at 1024^2, +1 % at 2048^2, -0.8 % at 4096^2 (fetched bytes are equal:
-// either way pass 2 reads the stored half of the height rows a second time, 4 B per grid point, and it comes from beyond L2).
+// Mode 2's T1(a,m) values are exactly what the HEIGHT fetch loaded into the mirrored slots of the same lane: since round 4 they are
+// kept in registers until the slope assembly (KeepT1 below) instead of being fetched a second time (4 B per grid point from beyond
+// L2; up to round 3 both modes paid it and mode 1 was 0.8 % ahead at 4096^2).  Mode 2 is the plan at every size.
 #ifndef MW_SPLIT_SLOPES
 #define MW_SPLIT_SLOPES 2
 #endif

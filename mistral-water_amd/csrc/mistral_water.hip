@@ -360,11 +360,11 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
     MW_STAMP(1, 0);
 #define MW_VT(h) for (int h = 0; h < VT; h++)
 #define MW_VTID(h) (mw_fresh(tid0) + (h) * NT)
-    // PF = 1 (software prefetch; the one-workgroup-per-CU plan, 4096^2): the displacement field's exchange-buffer rows are
+    // PF = 1 (software prefetch; the 4096^2 plan of rounds 2-3, an A/B option since round 4: MW_PF_4096): the displacement field's exchange-buffer rows are
     // requested while the height field -- whose phase holds nothing but x -- is transformed, into a second register set.
     // Three things make the loads really asynchronous: the height field's own loads are issued first (scheduling fence;
     // vmcnt is in-order), the Nyquist-column term is added at use (p2_fetch's nyq), and no pass of the transform reads
-    // global memory (TwGeom::PW_CF).  Measured: pass 2 -1.5 % at 4096^2, +1 % at 1024^2 and 2048^2 (off there).  Prefetching the
+    // global memory (TwGeom::PW_CF).  Measured: pass 2 -1.5 % at 4096^2 (round 2; with KeepT1 the plan without it is 1 % ahead), +1 % at 1024^2 and 2048^2.  Prefetching the
     // slope rows during the displacement transform as well (all of them: 17 spilled dwords; one virtual thread's: 243
     // VGPRs) made the kernel 4-11 % slower: removed.
     static_assert(PF == 0 || PF == 1 || PF == 2, "prefetch level");
