@@ -264,7 +264,9 @@ struct P1Args {
     OceanConsts c;
     int tgroup;        // > 0: 1-D grid, `tgroup` time-steps of one column job kept on one XCD (p1_block_map)
     int nsteps;
-    int field_split = 0;  // 1: grid (column jobs, 3), blockIdx.y = the one field this workgroup transforms (single-step enqueues)
+    int field_split = 0;  // single-step enqueues, ONE field per workgroup: 1 = grid (column jobs, 3); 2 = 1-D grid over `jobs`
+    const int* jobs = nullptr;  // field_split == 2: workgroup id -> (field << 16 | column job), -1 = none (p1_frame_jobs)
+    int njobs = 0;
 };
 
 // Pass-1 block -> (column job, time-step).  All time-steps of a batch read the same PQt/Om rows, so the tgroup
@@ -415,6 +417,34 @@ MW_HD void p1_build(const P1Args& A, int jb, int tid, int f, const P1State<P>& s
         else x[q] = cmul(cscale(cx, fx) + cz, st.hh[q]);
         if (q == 0) x[0] = x[0] + cmul(cx, st.dl0);  // i = 0 correction (dl0 == 0 unless u == 0)
     }
+}
+
+}  // namespace mw
+#include <vector>
+namespace mw {
+// Job list of the single-step plan's pass 1: exactly the ACTIVE (column job, field) pairs, one workgroup each, dealt so that the
+// fields of one column job sit in consecutive slots of ONE XCD (the dispatcher places workgroup b on XCD b % 8): they re-form the
+// same animated spectrum from the same rows at the same time, and one L2 fetches those rows once.  Every XCD gets the column jobs
+// jb = x (mod 8); three-field jobs first, the single-field ones (jb > N / (2 CW): displacement only) after; lists padded with -1.
+// An exact list instead of a (column jobs, 3) grid with early exits: the dispatcher then loads the CUs evenly (2 workgroups each
+// at 1024^2) -- with the exits some CUs ran three and the step waited for those (profiles/r04_ab_notes.md).
+inline std::vector<int> p1_frame_jobs(int N, int cw) {
+    const int gx = N / cw + 1;
+    std::vector<int> per[8];
+    for (int pass = 0; pass < 2; pass++)
+        for (int jb = 0; jb < gx; jb++) {
+            int nf = 0;
+            for (int f = 0; f < 3; f++) nf += p1_field_active(N, jb, f, cw) ? 1 : 0;
+            if ((nf == 3) != (pass == 0)) continue;
+            for (int f = 0; f < 3; f++)
+                if (p1_field_active(N, jb, f, cw)) per[jb % 8].push_back((f << 16) | jb);
+        }
+    size_t len = 0;
+    for (auto& v : per) len = v.size() > len ? v.size() : len;
+    std::vector<int> out(8 * len, -1);
+    for (int x = 0; x < 8; x++)
+        for (size_t k = 0; k < per[x].size(); k++) out[8 * k + x] = per[x][k];
+    return out;
 }
 
 // radix-P passes the pass-1 loop runs between stage 0 and p1_finish (all of them, unless p1_finish runs the last one itself)
@@ -925,6 +955,108 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
     for (int q = 0; q < P; q++) {
         const float sg = post_sign(a, u + T * q);
         buf0[u + T * q] = mk(sg * x[q].x, sg * x[q].y);
+    }
+}
+
+// ---- frame variant (k_pass2_frame, single-step enqueues): the three fields of a row block side by side ----------------
+// One step at 1024^2 is 256 row blocks on 256 CUs: its latency is that of ONE workgroup, and the sequential-halo kernel runs four
+// transforms (height, displacement, halo row, slopes) one after the other in it.  Here a workgroup is 3 R2 + 1 row groups of T
+// threads: group fg * R2 + g transforms row a0 + g of field fg, the last group the halo row, ALL AT ONCE in 3 R2 + 1 row buffers.
+// After the final pass the fields meet through LDS, and the three kinds of group share the stores: the displacement groups
+// publish hds and the slope groups store the normals and leave the whitecap's noise term in their row buffers; one barrier; then
+// the HEIGHT groups store the vertices (h from their registers, hds from the published rows) while the displacement groups form
+// 1 - J and store the whitecap.  Every value is formed by the expressions of the batched plan: the same bits.
+#ifndef MW_FRAME_NT_RESULTS
+#define MW_FRAME_NT_RESULTS 1
+#endif
+template <int N, int P, int R2>
+struct P2FrameGeom {
+    static constexpr int T = FftGeom<N, P>::T;
+    static constexpr int FT = R2 * T;            // threads of one field's row groups
+    static constexpr int NTHREADS = 3 * FT + T;  // + the halo row's group
+    static constexpr int BUFSTRIDE = P2Buf<N, P>::BUFSTRIDE;
+    static constexpr int SETSTRIDE = R2 * BUFSTRIDE;
+    static constexpr int TW_LDS = (TwGeom<N, P>::LDS_ALL + 1) & ~1;
+    static constexpr int LDS_BYTES = (TW_LDS + 3 * SETSTRIDE + BUFSTRIDE) * (int)sizeof(cf);
+    static constexpr bool FITS = NTHREADS <= 1024 && LDS_BYTES <= 160 * 1024 && BUFSTRIDE >= N;
+    static constexpr bool OK = FITS && (T % 64) == 0;  // on the device a row group must be whole waves (its field is treated as wave-uniform)
+};
+// after the final pass, before the barrier.  tl = thread within the field's groups (row g = tl / T), x = its transformed row.
+// A row buffer is read in the final pass by its own row group alone, and that group writes it here.
+template <int N, int P, int R2>
+MW_HD void p2_frame_hds(int ab, int tl, const cf (&x)[P], cf* set_d) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int g = tl / T, u = tl % T, a = ab * R2 + g;
+    cf* drow = set_d + g * P2Buf<N, P>::BUFSTRIDE;
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const float sg = post_sign(a, u + T * q);
+        drow[u + T * q] = mk(sg * x[q].x, sg * x[q].y);
+    }
+}
+// slopes -> unit normal, stored at once -- BEFORE the barrier: the slope groups run at the highest issue priority and their stores
+// overlap the other groups' transforms (all normals stored after the barrier instead: pass 2 of a lone step 15.5 -> 18.1 us) --; the
+// whitecap's noise term |0.3 n.xz| into the float view of the group's row buffer (the expressions of p2_hs_finish_slopes)
+template <int N, int P, int R2>
+MW_HD void p2_frame_normals(const P2Args& A, int ab, int step, int tl, const cf (&x)[P], cf* set_s) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int g = tl / T, u = tl % T, a = ab * R2 + g;
+    float* nblk = A.normals + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;  // block-uniform
+    const unsigned noff = (unsigned)((g * N + u) * 3);
+    float* nrow = reinterpret_cast<float*>(set_s + g * P2Buf<N, P>::BUFSTRIDE);
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int b = u + T * q;
+        float* nq = nblk + (size_t)T * q * 3;
+        const float sg = post_sign(a, b);
+        const float sx = sg * x[q].x, sz = sg * x[q].y;
+        const float inv = mw_rsqrt(__builtin_fmaf(sz, sz, __builtin_fmaf(sx, sx, 1.0f)));
+        const float nx = sx * inv, ny = inv, nz = sz * inv;
+        mw_store_stream<MW_FRAME_NT_RESULTS != 0>(&nq[noff + 0], nx);
+        mw_store_stream<MW_FRAME_NT_RESULTS != 0>(&nq[noff + 1], ny);
+        mw_store_stream<MW_FRAME_NT_RESULTS != 0>(&nq[noff + 2], nz);
+        const float n0 = smul(fabsf(nx), 0.3f), n1 = smul(fabsf(nz), 0.3f);
+        nrow[b] = ssqrt(sadd(smul(n0, n0), smul(n1, n1)));  // :269
+    }
+}
+// after the barrier.  Height groups: the vertices (p2_vertices' expressions; hds from the published row)
+template <int N, int P, int R2>
+MW_HD void p2_frame_vertices(const P2Args& A, int ab, int step, int tl, const cf (&x)[P], const cf* set_d) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int g = tl / T, u = tl % T, a = ab * R2 + g;
+    const cf* drow = set_d + g * P2Buf<N, P>::BUFSTRIDE;
+    float* vblk = A.vertices + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;          // block-uniform
+    const unsigned voff = (unsigned)((g * N + u) * 3);
+    const float rx = rest_coord(N, A.c.unit_width, a);
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int b = u + T * q;
+        const cf d = drow[b];
+        float* vq = vblk + (size_t)T * q * 3;                                              // uniform
+        mw_store_stream<MW_FRAME_NT_RESULTS != 0>(&vq[voff + 0], ssub(rx, smul(d.x, A.c.choppiness)));                                // :245
+        mw_store_stream<MW_FRAME_NT_RESULTS != 0>(&vq[voff + 1], post_sign(a, b) * x[q].x);                                           // :243
+        mw_store_stream<MW_FRAME_NT_RESULTS != 0>(&vq[voff + 2], ssub(rest_coord(N, A.c.unit_width, b), smul(d.y, A.c.choppiness)));  // :244
+    }
+}
+// displacement groups: 1 - J from the published rows (nxt: row a + 1, the halo row's buffer for the block's last row), then the whitecap
+// with the slope group's noise term
+template <int N, int P, int R2>
+MW_HD void p2_frame_white(const P2Args& A, int ab, int step, int tl, const cf* set_d, const cf* halo, const cf* set_s) {
+    constexpr int T = FftGeom<N, P>::T, BS = P2Buf<N, P>::BUFSTRIDE;
+    const int g = tl / T, u = tl % T, a = ab * R2 + g;
+    NbRow nb;
+    nb.row = set_d + g * BS;
+    const cf* nxt = (g + 1 < R2) ? set_d + (g + 1) * BS : halo;
+    const float* nrow = reinterpret_cast<const float*>(set_s + g * BS);
+    float* wblk = A.white + ((size_t)step * N * N + (size_t)ab * R2 * N) * A.white_stride;
+    const unsigned woff = (unsigned)((g * N + u) * A.white_stride);
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int b = u + T * q;
+        P2RowView<P> v;
+        v.d[q] = nb.row[b];
+        const float omj = p2_one_minus_jacobian<N, P, R2>(a, b, q, v, nxt, nb);
+        p2_store_white<MW_FRAME_NT_RESULTS != 0>(wblk + (size_t)T * q * A.white_stride, woff, A.white_stride, omj, nrow[b]);
     }
 }
 

@@ -89,16 +89,42 @@ __global__ void k_omega_t(int N, float length, float gravity, float t, float* ou
 #ifndef MW_STAMP_STEP
 #define MW_STAMP_STEP 3
 #endif
-__device__ long long g_stamps[2][64][8][32];  // [kernel][block slot][wave][stamp]
+__device__ long long g_stamps[2][64][16][32];  // [kernel][block slot][wave][stamp]
 #define MW_STAMP(K, id)                                                                               \
     do {                                                                                              \
-        if ((blockIdx.x % 37) == 5 && blockIdx.x / 37 < 64 && step == MW_STAMP_STEP && (threadIdx.x & 63) == 0 && threadIdx.x < 512) \
+        if ((blockIdx.x % 37) == 5 && blockIdx.x / 37 < 64 && step == MW_STAMP_STEP && (threadIdx.x & 63) == 0 && threadIdx.x < 1024) \
             g_stamps[K][blockIdx.x / 37][threadIdx.x >> 6][id] = __builtin_readcyclecounter();        \
+    } while (0)
+// the constant 100-MHz clock beside the cycle counter (slots 30 / 31: start / end of a kernel): calibrates cycles against kernel time
+#define MW_STAMP_RT(K, id)                                                                            \
+    do {                                                                                              \
+        if ((blockIdx.x % 37) == 5 && blockIdx.x / 37 < 64 && step == MW_STAMP_STEP && (threadIdx.x & 63) == 0 && threadIdx.x < 1024) \
+            g_stamps[K][blockIdx.x / 37][threadIdx.x >> 6][id] = __builtin_amdgcn_s_memrealtime();    \
+    } while (0)
+// where the 4-wave workgroups of a pass-1 launch ran: HW_ID / XCC_ID of EVERY workgroup b < 768, parked in the unused wave slots 4..15
+#define MW_STAMP_HWID(K)                                                                              \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 768 && step == MW_STAMP_STEP) {                          \
+            g_stamps[K][blockIdx.x % 64][4 + blockIdx.x / 64][0] = __builtin_amdgcn_s_getreg(63492);   \
+            g_stamps[K][blockIdx.x % 64][4 + blockIdx.x / 64][1] = __builtin_amdgcn_s_getreg(63508);   \
+            g_stamps[K][blockIdx.x % 64][4 + blockIdx.x / 64][2] = __builtin_amdgcn_s_memrealtime();    \
+        }                                                                                             \
+    } while (0)
+#define MW_STAMP_HWID_END(K)                                                                          \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 768 && step == MW_STAMP_STEP)                            \
+            g_stamps[K][blockIdx.x % 64][4 + blockIdx.x / 64][3] = __builtin_amdgcn_s_memrealtime();    \
     } while (0)
 #elif defined(MW_SCHED_FENCE)
 #define MW_STAMP(K, id) __builtin_amdgcn_sched_barrier(0)
+#define MW_STAMP_RT(K, id) do { } while (0)
+#define MW_STAMP_HWID(K) do { } while (0)
+#define MW_STAMP_HWID_END(K) do { } while (0)
 #else
 #define MW_STAMP(K, id) do { } while (0)
+#define MW_STAMP_RT(K, id) do { } while (0)
+#define MW_STAMP_HWID(K) do { } while (0)
+#define MW_STAMP_HWID_END(K) do { } while (0)
 #endif
 
 // LDS layout of both pass kernels: [twiddle tables, if small] [NBUF sets of exchange buffers].  With
@@ -114,7 +140,37 @@ __device__ __forceinline__ void stage_twiddles(cf* dst, const cf* __restrict__ s
 
 // VT = virtual threads per lane (see k_pass2_hs): the phase functions are written for 4*T virtual threads (4 spectrum
 // columns x T); a workgroup of 4*T/VT lanes runs virtual threads tid, tid + NT, ... of every phase back to back.
-template <int N, int P, int VT>
+// issue priority (s_setprio, 0..3) of the row groups by field once the loads are out: the slope groups -- the longest fetch, then the
+// normals to store -- ahead of displacement and halo row, the height groups (which only wait for hds after their transform) last.
+// Measured on top of the wave-level exchanges: pass 2 of a lone step 17.1 -> 15.6 us (the reverse order 16.6; profiles/r04_ab_notes.md).
+#ifndef MW_FRAME_PRIO_S
+#define MW_FRAME_PRIO_S 3
+#endif
+#ifndef MW_FRAME_PRIO_D
+#define MW_FRAME_PRIO_D 2
+#endif
+#ifndef MW_FRAME_PRIO_X
+#define MW_FRAME_PRIO_X 2
+#endif
+#ifndef MW_FRAME_PRIO_H
+#define MW_FRAME_PRIO_H 1
+#endif
+__device__ __forceinline__ void mw_setprio(int p) {  // the builtin wants a literal
+    switch (p) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+#ifndef MW_P1_FRAME_WAVE_SYNC
+#define MW_P1_FRAME_WAVE_SYNC 1  // single-step plan: a column's exchanges stay inside its own wave up to the last one
+#endif
+#ifndef MW_P1_FRAME_PRIO
+#define MW_P1_FRAME_PRIO 0       // single-step plan: issue priority by field (1: f = 0 highest; 2: f = 1 highest; 3: f = 2 highest)
+#endif
+// FS = the single-step (frame-at-a-time) instantiation: one FIELD per workgroup (A.field_split says which grid decodes it)
+template <int N, int P, int VT, bool FS = false>
 __global__ __launch_bounds__((P1Geom<N, P>::NTHREADS / VT))
 __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : (P == 8 ? MW_WAVES_P1 : 4)))) void k_pass1(P1Args A, StepTimes times) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -129,12 +185,29 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
     // 1024^2 where the device has 1024 slots, so its latency is that of ONE workgroup: a third of the work each cuts it
     // accordingly.  The arithmetic of a field does not depend on which workgroup runs it: same bits as the batched plan.
     int f_lo = 0, f_hi = 3;
-    if (A.field_split) {
-        f_lo = (int)blockIdx.y;
+    if constexpr (FS) {
+        if (A.field_split == 2) {  // 1-D grid over the list of active (column job, field) pairs (p1_frame_jobs)
+            const int job = A.jobs[blockIdx.x];
+            if (job < 0) return;
+            jb = job & 0xffff;
+            f_lo = job >> 16;
+        } else {
+            f_lo = (int)blockIdx.y;
+        }
         f_hi = f_lo + 1;
         step = 0;
         if (!p1_field_active(N, jb, f_lo, G::CW)) return;  // block-uniform, before any barrier
+        if (MW_P1_FRAME_PRIO) mw_setprio(3 - (f_lo + 4 - MW_P1_FRAME_PRIO) % 3);
     } else if (A.tgroup > 0 && !p1_block_map((int)blockIdx.x, G::GRID_X, A.nsteps, A.tgroup, &jb, &step)) return;
+    // Up to its last exchange a column's buffer is written and read by the column's own T threads: where those are one wave (the
+    // single-step plan at T == 64) the exchanges need that wave's LDS operations in order and no workgroup barrier -- the four columns
+    // drift apart; the last exchange feeds the column-interleaved final pass and keeps the barrier.
+    constexpr bool WS = FS && MW_P1_FRAME_WAVE_SYNC && VT == 1 && T == 64;
+    auto col_sync = [&](bool whole_group) {
+        if (WS && !whole_group) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
+    (void)col_sync;
     const float t = times.t[step];
     if (TwGeom<N, P>::LDS_ALL) stage_twiddles<N, P, NT>(lds, A.TW, tid);  // visible after the first barrier
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
@@ -146,6 +219,8 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
 #define MW_BUF(h) (set0 + cur * G::SETSTRIDE + ((tid + (h) * NT) / T) * G::BUFSTRIDE)
 #define MW_U(h) ((tid + (h) * NT) % T)
     MW_STAMP(0, 0);
+    MW_STAMP_RT(0, 30);
+    if constexpr (FS) MW_STAMP_HWID(0);
 #pragma unroll
     MW_VT(h) p1_animate<N, P>(A, jb, tid + h * NT, t, st[h]);
     MW_STAMP(0, 1);
@@ -170,20 +245,20 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
 #pragma unroll
         MW_VT(h) stage0_store<N, P, +1>(x[h], MW_U(h), MW_BUF(h));
         MW_STAMP(0, 3 + 8 * f);
-        __syncthreads();
+        __syncthreads();  // the first barrier of the kernel also publishes the staged twiddle tables: always the whole group
 #pragma unroll
         for (int s = 1; s < p1_mid_passes<N, P>(); s++) {
 #pragma unroll
             MW_VT(h) load_slots<N, P>(x[h], MW_U(h), MW_BUF(h), s - 1);
             if (s == 1) MW_STAMP(0, 4 + 8 * f);
 #ifndef MW_ABLATE_WAR  // timing experiment (wrong results): no write-after-read barrier (4096^2: pass 1 -2 %)
-            if (G::NBUF == 1) __syncthreads(); else cur ^= 1;
+            if (G::NBUF == 1) col_sync(false); else cur ^= 1;
 #endif
             if (s == 1) MW_STAMP(0, 5 + 8 * f);
 #pragma unroll
             MW_VT(h) stage_store<N, P, +1>(x[h], MW_U(h), MW_BUF(h), tw, s);
             if (s == 1) MW_STAMP(0, 6 + 8 * f);
-            __syncthreads();
+            col_sync(s == p1_mid_passes<N, P>() - 1);
         }
         MW_STAMP(0, 7 + 8 * f);
 #pragma unroll
@@ -192,6 +267,8 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
         MW_STAMP(0, 8 + 8 * f);
     }
     MW_STAMP(0, 26);
+    MW_STAMP_RT(0, 31);
+    if constexpr (FS) MW_STAMP_HWID_END(0);
 #undef MW_VT
 #undef MW_BUF
 #undef MW_U
@@ -536,6 +613,80 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
 #undef MW_VTID
 }
 
+// Pass 2 of a single-step enqueue (the frame-at-a-time plan, P2FrameGeom in fftmesh_kernels.h): 3 R2 + 1 row groups transform the
+// three fields of the block's rows and the halo row at the same time; the latency of the workgroup -- which IS the latency of the
+// step, 256 workgroups on 256 CUs -- is one transform instead of four.
+#ifndef MW_FRAME_WAVE_SYNC
+#define MW_FRAME_WAVE_SYNC 1  // the middle passes of a row stay inside its own wave: no workgroup barrier between them
+#endif
+template <int N, int P, int R2>
+__global__ __launch_bounds__((P2FrameGeom<N, P, R2>::NTHREADS)) void k_pass2_frame(P2Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = P2FrameGeom<N, P, R2>;
+    static_assert(G::OK, "frame variant: geometry");
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = G::T;
+    const int tid = threadIdx.x, step = blockIdx.y;
+    const int ab = p2_row_block<N / R2>((int)blockIdx.x);
+    const int fg = wave_uniform<true>(tid / G::FT);  // 0 height, 1 displacement, 2 slopes, 3 the halo row (displacement of row a0 + R2)
+    const int tl = tid - fg * G::FT;
+    const bool has_halo = (ab * R2 + R2 < N);        // block-uniform
+    const bool row = fg < 3, halo = (fg == 3) && has_halo;
+    cf* set0 = lds + G::TW_LDS;
+    cf* set_d = set0 + G::SETSTRIDE;
+    cf* hbuf = set0 + 3 * G::SETSTRIDE;
+    cf* mine = set0 + fg * G::SETSTRIDE;  // fg == 3: the halo row's buffer
+    cf x[P];
+    MW_STAMP(1, 0);
+    MW_STAMP_RT(1, 30);
+    if (row) p2_fetch<N, P, R2>(A, ab, step, tl, fg, x);
+    else if (halo) p2_hs_halo_fetch<N, P, R2>(A, ab, step, tl, x);
+    if (TwGeom<N, P>::LDS_ALL) stage_twiddles<N, P, G::NTHREADS>(lds, A.TW, tid);
+    const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
+    if (row) p2_stage0<N, P, R2>(tl, x, mine);
+    else if (halo) stage0_store<N, P, +1>(x, tl, mine);
+    MW_STAMP(1, 1);
+    __syncthreads();  // stage 0 was written in the row-interleaved mapping of the loads: every wave of a field into all of its rows
+    // From here to the final pass a row buffer belongs to ONE wave (exact layouts: row-major mapping, T == 64): its exchanges need the
+    // wave's own LDS operations in order, nothing else -- the row groups drift apart, and the first to finish starts its stores while
+    // the others still transform.
+    static_assert(T == 64, "one wave per row buffer");
+    constexpr bool WSYNC = MW_FRAME_WAVE_SYNC && XLay<N, P>::EXACT;
+    auto row_sync = [&]() {
+        if constexpr (WSYNC) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
+    mw_setprio(fg == 0 ? MW_FRAME_PRIO_H : (fg == 1 ? MW_FRAME_PRIO_D : (fg == 2 ? MW_FRAME_PRIO_S : MW_FRAME_PRIO_X)));
+#pragma unroll
+    for (int s = 1; s < FftGeom<N, P>::S; s++) {
+        const bool in_regs = LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1;
+        if (row) p2_mid_load<N, P, R2>(tl, s, x, mine);
+        else if (halo) load_slots<N, P>(x, tl, mine, s - 1);
+        if (!in_regs) row_sync();
+        if (row) p2_mid_store<N, P, R2>(tw, tl, s, x, mine);
+        else if (halo) { if (in_regs) stage_regs<N, P, +1>(x, tl, tw, s); else stage_store<N, P, +1>(x, tl, mine, tw, s); }
+        if (!in_regs) row_sync();
+    }
+    MW_STAMP(1, 2);
+    // the final pass reads a row buffer by its own row group alone, too: that group may write it again without a barrier
+    cf* set_s = set0 + 2 * G::SETSTRIDE;
+    if (row || halo) {
+        p2_last_load<N, P>(x, tl % T, mine + (row ? tl / T : 0) * G::BUFSTRIDE);
+        final_stage<N, P, +1>(x, tl % T, tw.TF);
+    }
+    MW_STAMP(1, 3);
+    if (fg == 1) p2_frame_hds<N, P, R2>(ab, tl, x, set_d);
+    else if (fg == 2) p2_frame_normals<N, P, R2>(A, ab, step, tl, x, set_s);
+    else if (halo) p2_hs_halo_publish<N, P, R2>(ab, tl, x, hbuf);
+    MW_STAMP(1, 4);
+    __syncthreads();
+    MW_STAMP(1, 5);
+    if (fg == 0) p2_frame_vertices<N, P, R2>(A, ab, step, tl, x, set_d);
+    else if (fg == 1) p2_frame_white<N, P, R2>(A, ab, step, tl, set_d, hbuf, set_s);
+    MW_STAMP(1, 6);
+    MW_STAMP_RT(1, 31);
+}
+
 // ------------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------------
@@ -555,6 +706,8 @@ struct mw_ocean {
     f4 *PQt = nullptr, *dPQ_i0 = nullptr, *dPQ_j0 = nullptr;
     float* Om = nullptr;
     cf *TW = nullptr, *TW2 = nullptr, *Wpre = nullptr;  // twiddle tables of pass 1 / pass 2
+    int* p1_jobs = nullptr;  // single-step plan: pass-1 job list (p1_frame_jobs)
+    int p1_njobs = 0;
     cf *E = nullptr, *Cj0 = nullptr;
     int e_cap = 0;  // steps the exchange buffer holds
     float *s_vert = nullptr, *s_norm = nullptr, *s_white = nullptr;  // 1-step scratch for the host API
@@ -622,6 +775,12 @@ static mw_status upload_twiddles(mw_ocean* o) {
     HIP_TRY(hipMemcpy(o->TW, tab.data(), sizeof(cf) * tab.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(o->TW2, tab2.data(), sizeof(cf) * tab2.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(o->Wpre, Wpre.data(), sizeof(cf) * 2 * N, hipMemcpyHostToDevice));
+    if (N == 1024 && MW_LATENCY_PLAN) {
+        const std::vector<int> jobs = p1_frame_jobs(N, Exch<1024>::CW);
+        if ((st = dmalloc(&o->p1_jobs, jobs.size())) != MW_OK) return st;
+        HIP_TRY(hipMemcpy(o->p1_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
+        o->p1_njobs = (int)jobs.size();
+    }
     return MW_OK;
 }
 
@@ -642,6 +801,17 @@ static bool latency_plan_on() {
     return on;
 }
 
+// MW_FRAME_KERNEL=0: pass 2 of a single step by the sequential-halo kernel with one wave per row (round 3's frame plan) instead of
+// k_pass2_frame; MW_P1_FRAME_XCD=0: its pass 1 on the plain (column jobs, 3) grid.  Run-time A/B switches, same bits either way.
+static bool frame_kernel_on() {
+    static const bool on = [] { const char* e = std::getenv("MW_FRAME_KERNEL"); return !e || std::atoi(e) != 0; }();
+    return on;
+}
+static bool p1_frame_xcd_on() {
+    static const bool on = [] { const char* e = std::getenv("MW_P1_FRAME_XCD"); return !e || std::atoi(e) != 0; }();
+    return on;
+}
+
 // ---- kernel dispatch over N ----------------------------------------------------------------------
 template <int N>
 static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nsteps, hipStream_t st) {
@@ -652,9 +822,17 @@ static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nstep
         if (e != hipSuccess) return e;
     }
     constexpr int NT = P1Geom<N, P>::NTHREADS / VT, LB = P1Geom<N, P>::LDS_BYTES, GX = P1Geom<N, P>::GRID_X;
-    if (A.field_split)
-        k_pass1<N, P, VT><<<dim3(GX, 3), dim3(NT), LB, st>>>(A, tm);
-    else if (A.tgroup > 0)
+    if constexpr (N == 1024 && MW_LATENCY_PLAN) {
+        if (A.field_split) {
+            static AttrOnce attrf;
+            hipError_t e = attrf.set(reinterpret_cast<const void*>(&k_pass1<N, P, VT, true>), LB);
+            if (e != hipSuccess) return e;
+            if (A.field_split == 2) k_pass1<N, P, VT, true><<<dim3(A.njobs), dim3(NT), LB, st>>>(A, tm);
+            else k_pass1<N, P, VT, true><<<dim3(GX, 3), dim3(NT), LB, st>>>(A, tm);
+            return hipGetLastError();
+        }
+    }
+    if (A.tgroup > 0)
         k_pass1<N, P, VT><<<dim3(p1_grid_blocks(GX, nsteps, A.tgroup)), dim3(NT), LB, st>>>(A, tm);
     else
         k_pass1<N, P, VT><<<dim3(GX, nsteps), dim3(NT), LB, st>>>(A, tm);
@@ -680,6 +858,20 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
     // results are the bit patterns of the batched plan.
     if constexpr (HS && N == 1024 && VT == 2 && !DUMP && MW_LATENCY_PLAN) {
         if (nsteps == 1 && latency_plan_on()) {
+#ifndef MW_FRAME_R2
+#define MW_FRAME_R2 4  // rows per workgroup of k_pass2_frame
+#endif
+            constexpr int RF = MW_FRAME_R2;
+            if constexpr (P2FrameGeom<N, P, RF>::OK) {
+                if (frame_kernel_on()) {  // the three fields of a row block side by side (k_pass2_frame)
+                    static AttrOnce attrf;
+                    constexpr int LBF = P2FrameGeom<N, P, RF>::LDS_BYTES;
+                    hipError_t e = attrf.set(reinterpret_cast<const void*>(&k_pass2_frame<N, P, RF>), LBF);
+                    if (e != hipSuccess) return e;
+                    k_pass2_frame<N, P, RF><<<dim3(N / RF, 1), dim3(P2FrameGeom<N, P, RF>::NTHREADS), LBF, st>>>(A);
+                    return hipGetLastError();
+                }
+            }
             static AttrOnce attr1;
             constexpr int PFL = MW_LATENCY_PF;  // 2: every load of the workgroup requested up front
             hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, 1, false, PFL>), LB);
@@ -721,7 +913,8 @@ static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipS
     A.c = consts_of(o);
     A.nsteps = nsteps;
     A.tgroup = p1_time_group(o, nsteps);
-    A.field_split = (latency_plan_on() && nsteps == 1 && o->N == 1024) ? 1 : 0;  // the frame-at-a-time plan (k_pass1)
+    A.field_split = (latency_plan_on() && nsteps == 1 && o->N == 1024) ? ((p1_frame_xcd_on() && o->p1_jobs) ? 2 : 1) : 0;
+    if (A.field_split == 2) { A.jobs = o->p1_jobs; A.njobs = o->p1_njobs; }
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass1_n<NN>(A, tm, nsteps, st));
     if (e != hipSuccess) return fail(MW_EDEVICE, std::string("pass1 launch: ") + hipGetErrorString(e));
@@ -823,7 +1016,7 @@ void mw_ocean_destroy(mw_ocean* o) {
     hipSetDevice(o->device);
     if (hipStreamSynchronize(o->stream) != hipSuccess) (void)hipGetLastError();  // a dead caller stream has nothing pending
     hipFree(o->h0); hipFree(o->h0c); hipFree(o->PQt); hipFree(o->Om); hipFree(o->dPQ_i0); hipFree(o->dPQ_j0);
-    hipFree(o->TW); hipFree(o->TW2); hipFree(o->Wpre); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white); hipFree(o->scratch);
+    hipFree(o->TW); hipFree(o->TW2); hipFree(o->Wpre); hipFree(o->p1_jobs); hipFree(o->E); hipFree(o->Cj0); hipFree(o->s_vert); hipFree(o->s_norm); hipFree(o->s_white); hipFree(o->scratch);
     direct_free(o->direct);
     or_free(o->orr);
     if (o->own_stream) hipStreamDestroy(o->own_stream);
@@ -1469,7 +1662,7 @@ mw_status mw_debug_get_omega(mw_ocean* o, float* out_host) {  // [j][i] layout
 
 #ifdef MW_TIMING
 mw_status mw_debug_get_stamps(long long* out_host) {
-    HIP_TRY(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(long long) * 2 * 64 * 8 * 32));
+    HIP_TRY(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(long long) * 2 * 64 * 16 * 32));
     return MW_OK;
 }
 #endif

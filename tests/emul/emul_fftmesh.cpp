@@ -64,6 +64,7 @@ void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
 }
 
 static bool g_force_hs = false;  // emul_set_variant: run the sequential-halo pass 2 regardless of Plan<N>::HS
+static bool g_frame = false;     // emul_set_variant(2): the frame variant (k_pass2_frame) wherever its geometry exists
 
 template <int N, int P, int R2>
 void run_pass2(const P2Args& A, int nsteps) {
@@ -148,6 +149,59 @@ void run_pass2_hs(const P2Args& A, int nsteps) {
             }
 }
 
+// the frame variant (k_pass2_frame): 3 R2 + 1 row groups, the three fields and the halo row side by side
+template <int N, int P, int R2>
+void run_pass2_frame(const P2Args& A, int nsteps) {
+    using G = P2FrameGeom<N, P, R2>;
+    constexpr int T = G::T, FT = G::FT, NT = G::NTHREADS, BS = G::BUFSTRIDE, SS = G::SETSTRIDE;
+    std::vector<cf> lds(3 * SS + BS);
+    const Twiddles tw = TwGeom<N, P>::view(A.TW);
+    struct St { cf x[P]; };
+    std::vector<St> st(NT);
+    cf* set_d = lds.data() + SS;
+    cf* set_s = lds.data() + 2 * SS;
+    cf* hbuf = lds.data() + 3 * SS;
+    for (int step = 0; step < nsteps; step++)
+        for (int ab = 0; ab < N / R2; ab++) {
+            const bool has_halo = ab * R2 + R2 < N;
+            auto each = [&](auto&& fn) {
+                for (int tid = 0; tid < NT; tid++) {
+                    const int fg = tid / FT, tl = tid - fg * FT;
+                    if (fg == 3 && !has_halo) continue;
+                    fn(fg, tl, st[tid], lds.data() + fg * SS);
+                }
+            };
+            each([&](int fg, int tl, St& t, cf* mine) {
+                if (fg < 3) { p2_fetch<N, P, R2>(A, ab, step, tl, fg, t.x); p2_stage0<N, P, R2>(tl, t.x, mine); }
+                else { p2_hs_halo_fetch<N, P, R2>(A, ab, step, tl, t.x); stage0_store<N, P, +1>(t.x, tl, mine); }
+            });
+            for (int s = 1; s < FftGeom<N, P>::S; s++) {
+                const bool in_regs = LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1;
+                each([&](int fg, int tl, St& t, cf* mine) {
+                    if (fg < 3) p2_mid_load<N, P, R2>(tl, s, t.x, mine); else load_slots<N, P>(t.x, tl, mine, s - 1);
+                });
+                each([&](int fg, int tl, St& t, cf* mine) {
+                    if (fg < 3) p2_mid_store<N, P, R2>(tw, tl, s, t.x, mine);
+                    else if (in_regs) stage_regs<N, P, +1>(t.x, tl, tw, s);
+                    else stage_store<N, P, +1>(t.x, tl, mine, tw, s);
+                });
+            }
+            each([&](int fg, int tl, St& t, cf* mine) {
+                p2_last_load<N, P>(t.x, tl % T, mine + (fg < 3 ? tl / T : 0) * BS);
+                final_stage<N, P, +1>(t.x, tl % T, tw.TF);
+            });
+            each([&](int fg, int tl, St& t, cf*) {
+                if (fg == 1) p2_frame_hds<N, P, R2>(ab, tl, t.x, set_d);
+                else if (fg == 2) p2_frame_normals<N, P, R2>(A, ab, step, tl, t.x, set_s);
+                else if (fg == 3) p2_hs_halo_publish<N, P, R2>(ab, tl, t.x, hbuf);
+            });
+            each([&](int fg, int tl, St& t, cf*) {
+                if (fg == 0) p2_frame_vertices<N, P, R2>(A, ab, step, tl, t.x, set_d);
+                else if (fg == 1) p2_frame_white<N, P, R2>(A, ab, step, tl, set_d, hbuf, set_s);
+            });
+        }
+}
+
 // PA / PB: points per thread of pass 1 / pass 2 (the exchange-buffer layout does not depend on them)
 template <int N, int PA, int PB>
 int evaluate_np(const OceanConsts& C, const cf* h0, const cf* h0c, const float* times, int nsteps, float* vertices,
@@ -170,7 +224,10 @@ int evaluate_np(const OceanConsts& C, const cf* h0, const cf* h0c, const float* 
     P2Args A2;
     A2.E = E.data(); A2.Cj0 = Cj0.data(); A2.TW = tb2.TW.data(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
     A2.white_stride = white_stride; A2.c = C;
-    if (hs) {
+    if (g_frame) {
+        if constexpr (P2FrameGeom<N, PB, R2>::FITS) run_pass2_frame<N, PB, R2>(A2, nsteps);
+        else return 5;
+    } else if (hs) {
         run_pass2_hs<N, PB, R2>(A2, nsteps);
     } else {
         if constexpr ((R2 + 1) * (N / PB) <= 1024) run_pass2<N, PB, R2>(A2, nsteps);  // the halo-group kernel exists for this plan
@@ -436,7 +493,7 @@ void emul_gerstner(const float* pos, long nverts, const float* waves, int nwaves
                         &out[3 * v + 1], &out[3 * v + 2]);
 }
 
-void emul_set_variant(int force_hs) { g_force_hs = force_hs != 0; }
+void emul_set_variant(int v) { g_force_hs = (v == 1); g_frame = (v == 2); }
 
 // the time-batched Gerstner path: position part once, angle addition per step (cb/sb as the launcher forms them)
 void emul_gerstner_steps(const float* pos, long nverts, const float* waves, int nwaves, float amplitude, float frequency,
@@ -485,6 +542,14 @@ int emul_p1_block_map(int bid, int gx, int nsteps, int tgroup, int* jb, int* ste
     return p1_block_map(bid, gx, nsteps, tgroup, jb, step) ? 1 : 0;
 }
 int emul_p1_grid_blocks(int gx, int nsteps, int tgroup) { return p1_grid_blocks(gx, nsteps, tgroup); }
+// job list of the single-step plan's pass 1 (p1_frame_jobs): returns its length, copies up to cap entries
+int emul_p1_frame_jobs(int N, int* out, int cap) {
+    const int cw = N >= MW_CW2_MIN_N ? 2 : 4;
+    const std::vector<int> j = p1_frame_jobs(N, cw);
+    for (int i = 0; i < (int)j.size() && i < cap; i++) out[i] = j[i];
+    return (int)j.size();
+}
+int emul_p1_field_active(int N, int jb, int f) { return p1_field_active(N, jb, f, N >= MW_CW2_MIN_N ? 2 : 4) ? 1 : 0; }
 
 // sum_ij F_f(i,j) e^{i(k_i x_a + k_j z_b)} for nfields complex N x N fields through the two chirp-z launches (along j, then
 // along i; each stores transposed), tables from czt_build_tables: in [f][i][j], out [f][a][b], interleaved (re, im) float32

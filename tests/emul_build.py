@@ -42,9 +42,10 @@ class Emul:
     def __init__(self, defs=()):
         self.L = C.CDLL(build(defs))
 
-    def set_variant(self, force_hs=False):
-        """force_hs: run the sequential-halo pass 2 (the product's N >= 4096 kernel) at every grid size."""
-        self.L.emul_set_variant(1 if force_hs else 0)
+    def set_variant(self, force_hs=False, frame=False):
+        """force_hs: run the sequential-halo pass 2 (the product's N >= 4096 kernel) at every grid size.
+        frame: run the single-step plan's pass 2 (k_pass2_frame: the three fields of a row block side by side)."""
+        self.L.emul_set_variant(2 if frame else (1 if force_hs else 0))
 
     def evaluate(self, p, h0, h0c, times, white_stride=4, pts=0):
         """p: oracle.Params.  Returns (vertices, normals, white) with a leading step axis."""

@@ -314,3 +314,49 @@ def test_chirp_z_form_equals_the_separable_sum(emul, oracle, N, u, L):
         scale = max(np.abs(wantr).max(), np.abs(S[0].real).max() if nm in ("H", "Dx", "Dz") else np.abs(S[3].imag).max())
         assert np.abs(gotr - wantr).max() <= 3e-6 * scale, (nm, np.abs(gotr - wantr).max() / scale)
     assert np.abs(pk[2].imag).max() <= 3e-6 * np.abs(S[0].real).max()
+
+
+@pytest.mark.parametrize("N,pts", [(64, 8), (128, 16), (256, 8), (512, 8), (1024, 0)])
+def test_frame_variant_of_pass2_equals_the_shipped_plan(emul, oracle, N, pts):
+    """k_pass2_frame (the single-step plan at 1024^2: 3 R2 + 1 row groups transform the three fields of a row block and the halo
+    row side by side and meet through LDS -- hds published, noise term parked, vertices stored by the height groups, whitecap by the
+    displacement groups) stepped phase by phase on the host, at small grids too: the bit patterns of the plan Plan<N> ships
+    (halo-group kernel up to 512^2, sequential-halo kernel at 1024^2 = pts 0, the product's points per thread)."""
+    p = workloads.fftmesh_params(N)
+    h0, h0c = oracle.generate_spectrum(p, 11)
+    times = [0.4, 9.75] if N < 1024 else [3.25]
+    try:
+        emul.set_variant()
+        v0, n0, w0 = emul.evaluate(p, h0, h0c, times, pts=pts)
+        emul.set_variant(frame=True)
+        v1, n1, w1 = emul.evaluate(p, h0, h0c, times, pts=pts, white_stride=1)
+    finally:
+        emul.set_variant()
+    assert (v0 == v1).all() and (n0 == n1).all() and (w0[..., 0] == w1[..., 0]).all() and np.abs(w0).max() > 0
+
+
+def test_frame_plan_pass1_job_list(emul):
+    """p1_frame_jobs (the 1-D grid of the single-step plan's pass 1): every ACTIVE (column job, field) pair exactly once, nothing
+    else; workgroup b runs on XCD b % 8, and the fields of one column job sit in consecutive slots of one XCD."""
+    import ctypes as C
+    N = 1024
+    buf = (C.c_int * 4096)()
+    n = emul.L.emul_p1_frame_jobs(N, buf, 4096)
+    jobs = list(buf[:n])
+    assert n % 8 == 0 and n <= 4096
+    seen = {}
+    for b, j in enumerate(jobs):
+        if j < 0:
+            continue
+        f, jb = j >> 16, j & 0xffff
+        assert emul.L.emul_p1_field_active(N, jb, f) == 1 and (f, jb) not in seen
+        seen[(f, jb)] = b
+        assert b % 8 == jb % 8
+    want = {(f, jb) for jb in range(N // 4 + 1) for f in range(3) if emul.L.emul_p1_field_active(N, jb, f)}
+    assert set(seen) == want and len(want) == 516
+    for (f, jb), b in seen.items():      # the other active fields of the same column job: the neighbouring slots of the same XCD
+        for g in range(3):
+            if (g, jb) in seen:
+                assert abs(seen[(g, jb)] - b) <= 16
+    per_xcd = [sum(1 for b, j in enumerate(jobs) if j >= 0 and b % 8 == x) for x in range(8)]
+    assert max(per_xcd) - min(per_xcd) <= 4

@@ -1,10 +1,16 @@
 """GPU tier, run last: the frame-at-a-time plan of the 1024^2 FFT path (FFTMesh.Update drives ONE step per call,
 S/FFTMesh.cs:60-73) against the batched plan, bit for bit.
 
-A single-step enqueue at 1024^2 launches pass 1 with one FIELD per workgroup (grid 257 x 3 instead of 257 workgroups doing
-three fields in turn) and pass 2 with one wave per row (VT = 1) instead of two rows per fat wave: more, shorter workgroups
-where a step cannot fill the device.  Neither changes the arithmetic of a row or a column, so every output of a step must
-be the same bit pattern whichever plan produced it (csrc/mistral_water.hip, MW_LATENCY_PLAN)."""
+A single-step enqueue at 1024^2 is two launches of their own (csrc/mistral_water.hip, MW_LATENCY_PLAN): pass 1 with one FIELD
+per workgroup over the list of active (column job, field) pairs, a column job's fields on one XCD (k_pass1<.., FS>,
+p1_frame_jobs); pass 2 with the three fields of a row block and the halo row transformed side by side by 13 row groups that
+meet through LDS (k_pass2_frame).  Neither changes the arithmetic of a row or a column, so every output of a step must be
+the same bit pattern whichever plan produced it.  MW_FRAME_KERNEL=0 / MW_P1_FRAME_XCD=0 select round 3's forms of the two
+launches (run-time A/B switches): the same bits again."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -12,25 +18,60 @@ import workloads
 
 pytestmark = pytest.mark.gpu
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-def test_single_step_plan_equals_batched_plan_bit_for_bit_1024(mw):
+
+def _frames_against_batch(mw, p, seed, nframes, device_frames):
     import torch
-    p = workloads.fftmesh_params(1024)
-    NN = 1024 * 1024
-    times = [0.25 + 0.37 * k for k in range(5)]
+    NN = p.N * p.N
+    times = [0.25 + 0.37 * k for k in range(nframes)]
     with mw.Ocean(resolution=p.N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude,
-                  choppiness=p.choppiness, gravity=p.gravity, seed=3) as o:
-        dv = torch.empty((5, NN, 3), dtype=torch.float32, device="cuda")
-        dn = torch.empty((5, NN, 3), dtype=torch.float32, device="cuda")
-        dw = torch.empty((5, NN), dtype=torch.float32, device="cuda")
-        o.evaluate_device(times, dv.data_ptr(), dn.data_ptr(), dw.data_ptr())      # batched plan (5 steps per enqueue)
+                  choppiness=p.choppiness, gravity=p.gravity, seed=seed) as o:
+        dv = torch.empty((nframes, NN, 3), dtype=torch.float32, device="cuda")
+        dn = torch.empty((nframes, NN, 3), dtype=torch.float32, device="cuda")
+        dw = torch.empty((nframes, NN), dtype=torch.float32, device="cuda")
+        o.evaluate_device(times, dv.data_ptr(), dn.data_ptr(), dw.data_ptr())      # batched plan (all steps in one enqueue)
         o.synchronize()
         bv, bn, bw = dv.cpu().numpy(), dn.cpu().numpy(), dw.cpu().numpy()
-        for k in (0, 2, 4):
-            v, n, c = o.evaluate(times[k])                                          # frame plan (one step per call)
+        assert np.abs(bw).max() > 0 and np.isfinite(bv).all()
+        if device_frames:      # frame plan, device pointers, back to back on the handle's stream: no host round trip between frames
+            fv, fn, fw = torch.zeros_like(dv), torch.zeros_like(dn), torch.zeros_like(dw)
+            torch.cuda.synchronize()
+            for k in range(nframes):
+                o.evaluate_device([times[k]], fv[k].data_ptr(), fn[k].data_ptr(), fw[k].data_ptr())
+            o.synchronize()
+            assert (fv.cpu().numpy() == bv).all() and (fn.cpu().numpy() == bn).all() and (fw.cpu().numpy() == bw).all()
+        for k in (0, nframes // 2, nframes - 1):
+            v, n, c = o.evaluate(times[k])                                          # frame plan (one step per call, Color whitecap)
             assert (bv[k] == v).all(), k
             assert (bn[k] == n).all(), k
-            assert (bw[k] == c[:, 0]).all(), k
+            assert (bw[k] == c[:, 0]).all() and (c[:, 0] == c[:, 3]).all(), k
+
+
+def test_single_step_plan_equals_batched_plan_bit_for_bit_1024(mw):
+    """Twelve consecutive frames enqueued back to back (a missing barrier or a stale LDS word shows up as a frame that differs) on
+    the scaled sea and on BASELINE configs[1]'s literal sea (amplitude 0.41: saturated whitecaps, large slopes)."""
+    _frames_against_batch(mw, workloads.fftmesh_params(1024), 3, 12, True)
+    _frames_against_batch(mw, workloads.fftmesh_config2(1024), 1, 5, True)
+
+
+_FRAME_CHILD = r'''
+import sys
+sys.path[:0] = [%(repo)r, %(repo)r + "/mistral-water_amd", %(repo)r + "/tests"]
+import torch; torch.cuda.init()
+import mistral_water as mw, workloads
+import test_zz_frame_plan as T
+T._frames_against_batch(mw, workloads.fftmesh_params(1024), 5, 4, True)
+print("FRAME_OK")
+'''
+
+
+@pytest.mark.parametrize("frame_kernel,p1_xcd", [("0", "1"), ("1", "0"), ("0", "0")])
+def test_single_step_plan_switches_select_the_same_bits(frame_kernel, p1_xcd):
+    """The run-time A/B switches of the two single-step launches, each combination in a child process (they are read once)."""
+    r = subprocess.run([sys.executable, "-c", _FRAME_CHILD % {"repo": REPO}],
+                       env=dict(os.environ, MW_FRAME_KERNEL=frame_kernel, MW_P1_FRAME_XCD=p1_xcd), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FRAME_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_cpp_host_mirror_runs_and_agrees_with_the_python_mirror(mw):
@@ -38,9 +79,7 @@ def test_cpp_host_mirror_runs_and_agrees_with_the_python_mirror(mw):
     toolchain in the image): host_demo drives FFTMesh.Awake() / Update() x 3, an OceanRenderer frame with the RGBA targets and
     the mesh vertex stage, and the pond material.  Its FFTMesh numbers must be those of the Python mirror with the same
     Inspector fields (same seed rule, same float32 timer arithmetic, S/FFTMesh.cs:60-73)."""
-    import os
     import re
-    import subprocess
     host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mistral-water_amd", "host")
     subprocess.run(["make", "-C", host, "-s"], check=True)
     r = subprocess.run([os.path.join(host, "host_demo")], capture_output=True, text=True, timeout=300)
@@ -87,10 +126,7 @@ def test_both_forms_of_the_direct_sum(form):
     A/B) -- the shipped scene, the Inspector defaults, an odd grid, a non-commensurate grid and N = 1000 against the f64 oracle.
     Chirp-z: the FFT path's tolerance class everywhere (2e-5 stated; measured 2-5e-7), also on the Inspector-default grid, where a
     phase reaches 3900 rad and the float32 GEMM form needs 2e-4."""
-    import os
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    repo = REPO
     r = subprocess.run([sys.executable, "-c", _CZT_CHILD % {"repo": repo, "inspector_rel": "2e-5" if form == "chirp-z" else "2e-4"}],
                        env=dict(os.environ, MW_DIRECT_CZT="1" if form == "chirp-z" else "0"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "CZT_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -16,7 +16,7 @@ dv = torch.empty((B, NN, 3), device="cuda"); dn = torch.empty((B, NN, 3), device
 for _ in range(5):
     o.evaluate_device([0.1 * k for k in range(B)], dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
 o.synchronize()
-st = np.zeros((2, 64, 8, 32), np.int64)
+st = np.zeros((2, 64, 16, 32), np.int64)
 L = nat.lib()
 L.mw_debug_get_stamps.argtypes = [C.c_void_p]
 assert L.mw_debug_get_stamps(st.ctypes.data) == 0
