@@ -1,5 +1,5 @@
-"""Cycle stamps of the single-step plan's pass 2 (k_pass2_frame), per row-group kind.  Needs a -DMW_TIMING -DMW_STAMP_STEP=0 build:
-   bash tools/build_variant.sh timing0 -DMW_TIMING -DMW_STAMP_STEP=0; MW_LIB=variants/timing0.so python tools/frame_stamps.py"""
+"""Cycle stamps of the single-step plan's kernels: k_pass2_frame per row-group kind, k_pass1<.., FS> per workgroup with the CU each one ran on.
+Needs a -DMW_TIMING -DMW_STAMP_STEP=0 build: run tools/frame_stamps.sh on the GPU box (it builds the variant there)."""
 import os, sys, ctypes as C
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -28,6 +28,11 @@ timeout 300 python bench.py --workload pond --steps 3200 --warmup 320 2> gpurun_
 timeout 300 python bench.py --workload renderer1024 --steps 2000 --warmup 200 2> gpurun_out/${tag}_renderer.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_renderer1024.json
 timeout 300 python bench.py --workload renderer1024 --tiles 4 --steps 500 --warmup 50 --no-cpu-baseline 2> gpurun_out/${tag}_renderer4.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_renderer1024_tiles4.json
 timeout 300 python bench.py --steps 20 --warmup 5 2> gpurun_out/${tag}_bench_driver.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_ocean1024_driver_k20.json
+# one step per call (the frame-at-a-time plan): latency probe, kernel trace of it, cycle stamps + placement
+timeout 300 python tools/frame_probe.py 2> /dev/null | tail -1 > gpurun_out/profiles_${tag}/${tag}_frame_probe.json
+rm -rf /tmp/fp_${tag}; TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/fp_${tag} -o fp --output-format csv -- python tools/frame_probe.py > /dev/null 2>&1
+f=$(find /tmp/fp_${tag} -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" > gpurun_out/profiles_${tag}/${tag}_frame_kernel_stats.csv
+bash tools/frame_stamps.sh > /dev/null 2>&1; cp gpurun_out/frame_ab/stamps.txt gpurun_out/profiles_${tag}/${tag}_frame_stamps.txt 2> /dev/null
 P=gpurun_out/profiles_${tag}; python tools/bench_summary.py $P/${tag}_bench_direct_50.json $P/${tag}_bench_direct_100.json $P/${tag}_bench_direct_1000.json $P/${tag}_bench_direct_2000.json $P/${tag}_bench_ocean1024_b32_steps640.json $P/${tag}_bench_ocean2048.json $P/${tag}_bench_ocean4096.json $P/${tag}_bench_pond.json $P/${tag}_bench_renderer1024.json $P/${tag}_bench_renderer1024_tiles4.json $P/${tag}_bench_ocean1024_driver_k20.json
 ls gpurun_out/profiles_${tag}
 # back in the container: cp gpurun_out/profiles_${tag}/* profiles/   (only gpurun_out/ travels back from the GPU box)
