@@ -969,6 +969,16 @@ MW_HD void p2_hs_halo_publish(int ab, int u, const cf (&x)[P], cf* buf0) {
 #ifndef MW_FRAME_NT_RESULTS
 #define MW_FRAME_NT_RESULTS 1
 #endif
+#ifndef MW_FRAME_R2
+#define MW_FRAME_R2 4  // rows per workgroup of k_pass2_frame at 1024^2 (2: 16.9 against 15.6 us)
+#endif
+#ifndef MW_FRAME_R2_SMALL
+#define MW_FRAME_R2_SMALL 2
+#endif
+// grids whose single-step enqueues run the frame plan (a wave must hold whole row groups: N / P2 == 64 or 32), and the rows per
+// workgroup there: 512^2 has 128 4-row blocks for 256 CUs, so 2 rows (256 workgroups of 7 waves); 256^2: 128 workgroups of 3.5 waves
+MW_HD constexpr bool mw_frame_plan_n(int N) { return N == 256 || N == 512 || N == 1024; }
+MW_HD constexpr int mw_frame_r2(int N) { return N <= 512 ? MW_FRAME_R2_SMALL : MW_FRAME_R2; }
 template <int N, int P, int R2>
 struct P2FrameGeom {
     static constexpr int T = FftGeom<N, P>::T;
@@ -979,7 +989,9 @@ struct P2FrameGeom {
     static constexpr int TW_LDS = (TwGeom<N, P>::LDS_ALL + 1) & ~1;
     static constexpr int LDS_BYTES = (TW_LDS + 3 * SETSTRIDE + BUFSTRIDE) * (int)sizeof(cf);
     static constexpr bool FITS = NTHREADS <= 1024 && LDS_BYTES <= 160 * 1024 && BUFSTRIDE >= N;
-    static constexpr bool OK = FITS && (T % 64) == 0;  // on the device a row group must be whole waves (its field is treated as wave-uniform)
+    // on the device a wave must hold whole row groups of ONE field (the field is treated as wave-uniform, and a row buffer is owned by one
+    // wave from the final pass on): one wave per row (T == 64), or two rows per wave (T == 32, R2 even)
+    static constexpr bool OK = FITS && (T == 64 || T == 32) && (FT % 64) == 0;
 };
 // after the final pass, before the barrier.  tl = thread within the field's groups (row g = tl / T), x = its transformed row.
 // A row buffer is read in the final pass by its own row group alone, and that group writes it here.

@@ -26,7 +26,7 @@
 #include "pond_kernels.h"
 
 #ifndef MW_LATENCY_PLAN
-#define MW_LATENCY_PLAN 1  // single-step enqueues at 1024^2: one field per pass-1 workgroup, one wave per pass-2 row (launch_pass*_n)
+#define MW_LATENCY_PLAN 1  // single-step enqueues at 512^2 / 1024^2 (mw_frame_plan_n): k_pass1<.., FS> + k_pass2_frame (launch_pass*_n)
 #endif
 #ifndef MW_LATENCY_PF
 #define MW_LATENCY_PF 2  // prefetch level of the frame plan's pass 2 (k_pass2_hs<.., VT = 1, PF>)
@@ -650,8 +650,8 @@ __global__ __launch_bounds__((P2FrameGeom<N, P, R2>::NTHREADS)) void k_pass2_fra
     // From here to the final pass a row buffer belongs to ONE wave (exact layouts: row-major mapping, T == 64): its exchanges need the
     // wave's own LDS operations in order, nothing else -- the row groups drift apart, and the first to finish starts its stores while
     // the others still transform.
-    static_assert(T == 64, "one wave per row buffer");
-    constexpr bool WSYNC = MW_FRAME_WAVE_SYNC && XLay<N, P>::EXACT;
+    static_assert((T == 64 || T == 32) && G::FT % 64 == 0, "a wave holds whole row groups of one field");
+    constexpr bool WSYNC = MW_FRAME_WAVE_SYNC && XLay<N, P>::EXACT;  // (the padded layouts' middle passes run row-interleaved: barriers)
     auto row_sync = [&]() {
         if constexpr (WSYNC) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
@@ -775,8 +775,8 @@ static mw_status upload_twiddles(mw_ocean* o) {
     HIP_TRY(hipMemcpy(o->TW, tab.data(), sizeof(cf) * tab.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(o->TW2, tab2.data(), sizeof(cf) * tab2.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(o->Wpre, Wpre.data(), sizeof(cf) * 2 * N, hipMemcpyHostToDevice));
-    if (N == 1024 && MW_LATENCY_PLAN) {
-        const std::vector<int> jobs = p1_frame_jobs(N, Exch<1024>::CW);
+    if (mw_frame_plan_n(N) && MW_LATENCY_PLAN) {
+        const std::vector<int> jobs = p1_frame_jobs(N, N >= MW_CW2_MIN_N ? 2 : 4);
         if ((st = dmalloc(&o->p1_jobs, jobs.size())) != MW_OK) return st;
         HIP_TRY(hipMemcpy(o->p1_jobs, jobs.data(), sizeof(int) * jobs.size(), hipMemcpyHostToDevice));
         o->p1_njobs = (int)jobs.size();
@@ -822,7 +822,7 @@ static hipError_t launch_pass1_n(const P1Args& A, const StepTimes& tm, int nstep
         if (e != hipSuccess) return e;
     }
     constexpr int NT = P1Geom<N, P>::NTHREADS / VT, LB = P1Geom<N, P>::LDS_BYTES, GX = P1Geom<N, P>::GRID_X;
-    if constexpr (N == 1024 && MW_LATENCY_PLAN) {
+    if constexpr (mw_frame_plan_n(N) && MW_LATENCY_PLAN) {
         if (A.field_split) {
             static AttrOnce attrf;
             hipError_t e = attrf.set(reinterpret_cast<const void*>(&k_pass1<N, P, VT, true>), LB);
@@ -852,18 +852,15 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
         hipError_t e = attr.set(fn, LB);
         if (e != hipSuccess) return e;
     }
-    // Frame-at-a-time plan (FFTMesh.Update, S/FFTMesh.cs:60-73: ONE step per call): 256 row blocks of two fat waves leave half
-    // of the device's 1024 SIMDs without a wave.  The same kernel with one virtual thread per lane (VT = 1: one wave per row,
-    // four waves per workgroup) puts a wave on every SIMD; the arithmetic of a row does not depend on the lane mapping, so the
-    // results are the bit patterns of the batched plan.
-    if constexpr (HS && N == 1024 && VT == 2 && !DUMP && MW_LATENCY_PLAN) {
+    // Frame-at-a-time plan (FFTMesh.Update, S/FFTMesh.cs:60-73: ONE step per call; 512^2 and 1024^2): a step cannot fill the device,
+    // its latency is that of one workgroup.  k_pass2_frame transforms the three fields of a row block side by side; MW_FRAME_KERNEL=0
+    // selects round 3's form at 1024^2 -- the sequential-halo kernel with one virtual thread per lane (one wave per row, every load up
+    // front) -- and the batched kernel at 512^2.  The arithmetic of a row does not depend on which kernel runs it: same bits.
+    if constexpr (mw_frame_plan_n(N) && !DUMP && MW_LATENCY_PLAN) {
         if (nsteps == 1 && latency_plan_on()) {
-#ifndef MW_FRAME_R2
-#define MW_FRAME_R2 4  // rows per workgroup of k_pass2_frame
-#endif
-            constexpr int RF = MW_FRAME_R2;
+            constexpr int RF = mw_frame_r2(N);
             if constexpr (P2FrameGeom<N, P, RF>::OK) {
-                if (frame_kernel_on()) {  // the three fields of a row block side by side (k_pass2_frame)
+                if (frame_kernel_on()) {
                     static AttrOnce attrf;
                     constexpr int LBF = P2FrameGeom<N, P, RF>::LDS_BYTES;
                     hipError_t e = attrf.set(reinterpret_cast<const void*>(&k_pass2_frame<N, P, RF>), LBF);
@@ -872,12 +869,14 @@ static hipError_t launch_pass2_n(const P2Args& A, int nsteps, hipStream_t st) {
                     return hipGetLastError();
                 }
             }
-            static AttrOnce attr1;
-            constexpr int PFL = MW_LATENCY_PF;  // 2: every load of the workgroup requested up front
-            hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, 1, false, PFL>), LB);
-            if (e != hipSuccess) return e;
-            k_pass2_hs<N, P, R2, 1, false, PFL><<<dim3(N / R2, 1), dim3(P2Geom<N, P, R2, true>::NTHREADS), LB, st>>>(A);
-            return hipGetLastError();
+            if constexpr (HS && VT == 2) {
+                static AttrOnce attr1;
+                constexpr int PFL = MW_LATENCY_PF;  // 2: every load of the workgroup requested up front
+                hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_pass2_hs<N, P, R2, 1, false, PFL>), LB);
+                if (e != hipSuccess) return e;
+                k_pass2_hs<N, P, R2, 1, false, PFL><<<dim3(N / R2, 1), dim3(P2Geom<N, P, R2, true>::NTHREADS), LB, st>>>(A);
+                return hipGetLastError();
+            }
         }
     }
     if constexpr (HS)
@@ -913,7 +912,7 @@ static mw_status launch_pass1(mw_ocean* o, const StepTimes& tm, int nsteps, hipS
     A.c = consts_of(o);
     A.nsteps = nsteps;
     A.tgroup = p1_time_group(o, nsteps);
-    A.field_split = (latency_plan_on() && nsteps == 1 && o->N == 1024) ? ((p1_frame_xcd_on() && o->p1_jobs) ? 2 : 1) : 0;
+    A.field_split = (latency_plan_on() && nsteps == 1 && mw_frame_plan_n(o->N)) ? ((p1_frame_xcd_on() && o->p1_jobs) ? 2 : 1) : 0;
     if (A.field_split == 2) { A.jobs = o->p1_jobs; A.njobs = o->p1_njobs; }
     hipError_t e = hipSuccess;
     MW_DISPATCH_N(o->N, e = launch_pass1_n<NN>(A, tm, nsteps, st));

@@ -225,7 +225,8 @@ int evaluate_np(const OceanConsts& C, const cf* h0, const cf* h0c, const float* 
     A2.E = E.data(); A2.Cj0 = Cj0.data(); A2.TW = tb2.TW.data(); A2.vertices = vertices; A2.normals = normals; A2.white = white;
     A2.white_stride = white_stride; A2.c = C;
     if (g_frame) {
-        if constexpr (P2FrameGeom<N, PB, R2>::FITS) run_pass2_frame<N, PB, R2>(A2, nsteps);
+        constexpr int RF = mw_frame_r2(N);      // the product's rows per workgroup of the frame variant
+        if constexpr (P2FrameGeom<N, PB, RF>::FITS) run_pass2_frame<N, PB, RF>(A2, nsteps);
         else return 5;
     } else if (hs) {
         run_pass2_hs<N, PB, R2>(A2, nsteps);

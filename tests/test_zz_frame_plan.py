@@ -1,7 +1,7 @@
 """GPU tier, run last: the frame-at-a-time plan of the 1024^2 FFT path (FFTMesh.Update drives ONE step per call,
 S/FFTMesh.cs:60-73) against the batched plan, bit for bit.
 
-A single-step enqueue at 1024^2 is two launches of their own (csrc/mistral_water.hip, MW_LATENCY_PLAN): pass 1 with one FIELD
+A single-step enqueue at 256^2 / 512^2 / 1024^2 is two launches of their own (csrc/mistral_water.hip, MW_LATENCY_PLAN): pass 1 with one FIELD
 per workgroup over the list of active (column job, field) pairs, a column job's fields on one XCD (k_pass1<.., FS>,
 p1_frame_jobs); pass 2 with the three fields of a row block and the halo row transformed side by side by 13 row groups that
 meet through LDS (k_pass2_frame).  Neither changes the arithmetic of a row or a column, so every output of a step must be
@@ -55,6 +55,14 @@ def test_single_step_plan_equals_batched_plan_bit_for_bit_1024(mw):
     _frames_against_batch(mw, workloads.fftmesh_config2(1024), 1, 5, True)
 
 
+@pytest.mark.parametrize("N", [512, 256])
+def test_single_step_plan_equals_batched_plan_bit_for_bit_small_grids(mw, N):
+    """The same at 512^2 (one wave per row at 8 points per thread) and 256^2 (BASELINE configs[0]; two rows of one field per wave):
+    2-row workgroups of 7 row groups there."""
+    _frames_against_batch(mw, workloads.fftmesh_params(N), 7, 12, True)
+    _frames_against_batch(mw, workloads.fftmesh_config2(N), 2, 5, True)
+
+
 _FRAME_CHILD = r'''
 import sys
 sys.path[:0] = [%(repo)r, %(repo)r + "/mistral-water_amd", %(repo)r + "/tests"]
@@ -62,6 +70,8 @@ import torch; torch.cuda.init()
 import mistral_water as mw, workloads
 import test_zz_frame_plan as T
 T._frames_against_batch(mw, workloads.fftmesh_params(1024), 5, 4, True)
+T._frames_against_batch(mw, workloads.fftmesh_params(512), 5, 4, True)
+T._frames_against_batch(mw, workloads.fftmesh_params(256), 5, 4, True)
 print("FRAME_OK")
 '''
 
