@@ -250,6 +250,16 @@ __global__ void k_or_phase_transpose(int M, const float* src, float* dst) {
 #ifndef MW_OR_STREAM_E_TILES
 #define MW_OR_STREAM_E_TILES 2
 #endif
+#ifndef MW_OR_BIG_N
+#define MW_OR_BIG_N 2048  // from this texture size up ONE tile is what several 1024^2 tiles are: it fills the device and its exchange buffer the caches
+#endif
+// a call is "bandwidth-bound" (three fields per pass-1 block from one read of the spectrum, streaming stores) when it carries several tiles or
+// one big one; a single 1024^2 texture is latency-bound (one field per block, cacheable stores)
+#ifndef MW_OR_STREAM_BIG_N
+#define MW_OR_STREAM_BIG_N MW_OR_BIG_N
+#endif
+template <int N>
+static inline bool or_call_is_big(const OrState& s) { return s.tiles >= MW_OR_STREAM_E_TILES || N >= MW_OR_STREAM_BIG_N; }
 template <int N>
 static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
     constexpr int P = Plan<N>::P;
@@ -262,9 +272,9 @@ static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
     }
     OrP1Args A1;
     A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.E = s.E; A1.c = s.c; A1.dt = dt;
-    A1.stream_E = (s.tiles >= MW_OR_STREAM_E_TILES) ? 1 : 0;
+    A1.stream_E = or_call_is_big<N>(s) ? 1 : 0;
     constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
-    k_or_pass1<N, P><<<dim3(N / 4, s.tiles > 1 ? 1 : 3, s.tiles), dim3(NT1), LB1, st>>>(A1);
+    k_or_pass1<N, P><<<dim3(N / 4, (s.tiles > 1 || N >= MW_OR_BIG_N) ? 1 : 3, s.tiles), dim3(NT1), LB1, st>>>(A1);
     std::swap(s.phaseT, s.phaseT2);
     OrP2Args A2;
     A2.E = s.E; A2.TW = s.TW; A2.height = s.out_height; A2.disp = s.out_disp_cf; A2.disp_g = s.out_disp_g; A2.c = s.c;
@@ -301,7 +311,7 @@ static inline mw_status or_generate(OrState& s, float delta_time, float* d_heigh
     if (e != hipSuccess) { g_or_err = std::string("OceanRenderer pass launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
     const size_t MM = (size_t)s.M * s.M, TM = MM * (size_t)s.tiles;
     const unsigned nb = (unsigned)((MM + 255) / 256);
-    if (s.tiles >= MW_OR_STREAM_E_TILES)
+    if (s.tiles >= MW_OR_STREAM_E_TILES || s.M >= MW_OR_STREAM_BIG_N)
         k_or_normal_white<true><<<dim3(nb, s.tiles), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white);
     else
         k_or_normal_white<false><<<dim3(nb, s.tiles), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white);

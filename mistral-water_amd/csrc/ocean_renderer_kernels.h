@@ -111,14 +111,19 @@ struct OrP1Geom {
 template <int N, int P>
 MW_HD void or_p1_animate(const OrP1Args& A, int jb, int tid, bool write_phase, cf (&h)[P]) {
     constexpr int T = FftGeom<N, P>::T;
-    const int w = tid / T, u = tid % T, px = 4 * jb + w;
+    const int w = wave_uniform<(T % 64) == 0>(tid / T), u = tid % T, px = 4 * jb + w;
+    // column bases stay uniform (SGPRs when columns are whole waves), element py = u + T q is base + T q + a 32-bit lane offset
+    const size_t col = (size_t)px * N;
+    const float* const c_om = A.omT + col;
+    const float* const c_pi = A.phase_in + col;
+    float* const c_po = A.phase_out + col;
+    const f4* const c_in = A.initT + col;
+    const unsigned uo = (unsigned)u;
 #pragma unroll
     for (int q = 0; q < P; q++) {
-        const int py = u + T * q;
-        const size_t idx = (size_t)px * N + py;
-        const float ph = or_phase_step(A.omT[idx], A.phase_in[idx], A.dt);
-        if (write_phase) A.phase_out[idx] = ph;
-        const f4 v = A.initT[idx];
+        const float ph = or_phase_step((c_om + T * q)[uo], (c_pi + T * q)[uo], A.dt);
+        if (write_phase) (c_po + T * q)[uo] = ph;
+        const f4 v = (c_in + T * q)[uo];
         float s, c;
         mw_sincos(ph, &s, &c);
         h[q] = animate(v.x, v.y, v.z, v.w, c, s);  // h0*pv + h0conj*Conj(pv), F/Spectrum.shader:45
@@ -146,12 +151,14 @@ MW_HD void or_p1_finish(const OrP1Args& A, const Twiddles& tw, int jb, int tid, 
     load_last<N, P>(x, u2, lds + w2 * OrP1Geom<N, P>::BUFSTRIDE);
     final_stage<N, P, -1>(x, u2, tw.TF);
     cf* Ef = A.E + (size_t)f * N * N + (size_t)jb * N * 4;
-    if (A.stream_E) {  // batched handle: the tiles' exchange buffers together exceed the caches -- write-once stream
+    // element (u2 + T q, w2) of the block's 4-column slab = Ef[(u2 + T q) * 4 + w2] = (Ef + 4 T q)[tid]: block-uniform base + lane offset
+    const unsigned to = (unsigned)tid;
+    if (A.stream_E) {  // several tiles or one big one: the exchange buffers exceed the caches -- write-once stream
 #pragma unroll
-        for (int q = 0; q < P; q++) mw_store_stream<true>(&Ef[(size_t)(u2 + T * q) * 4 + w2], x[q]);
-    } else {           // one texture: 24 MB, pass 2 finds most of it in L2 / the Infinity Cache
+        for (int q = 0; q < P; q++) mw_store_stream<true>(&(Ef + (size_t)4 * T * q)[to], x[q]);
+    } else {           // one 1024^2 texture: 24 MB, pass 2 finds most of it in L2 / the Infinity Cache
 #pragma unroll
-        for (int q = 0; q < P; q++) Ef[(size_t)(u2 + T * q) * 4 + w2] = x[q];
+        for (int q = 0; q < P; q++) (Ef + (size_t)4 * T * q)[to] = x[q];
     }
 }
 
@@ -191,16 +198,23 @@ template <int N, int P>
 MW_HD void or_p2_finish(const OrP2Args& A, const Twiddles& tw, int ab, int tid, int f, cf (&x)[P], float (&dx)[P],
                         const cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
-    const int g = tid / T, u = tid % T, a = ab * 4 + g;  // a = py', b = px'
+    // the row of a wave is wave-uniform when rows are whole waves: row bases stay in SGPRs and every store is base + 32-bit lane offset
+    // (per-element 64-bit addresses of five arrays, hoisted out of the field loop, took k_or_pass2<2048> to 228 VGPRs and <4096> past its 128)
+    const int g = wave_uniform<(T % 64) == 0>(tid / T), u = tid % T, a = ab * 4 + g;  // a = py', b = px'
     load_last<N, P>(x, u, lds + g * OrP2Geom<N, P>::BUFSTRIDE);
     final_stage<N, P, -1>(x, u, tw.TF);
     const size_t rowoff = (size_t)a * N;
+    float* const r_dg = A.disp_g + rowoff;
+    cf* const r_d = A.disp + rowoff;
+    float* const r_da = A.disp_a ? A.disp_a + rowoff : nullptr;
+    float* const r_h = A.height + rowoff;
+    float* const r_hg = A.height_g ? A.height_g + rowoff : nullptr;
+    const unsigned uo = (unsigned)u;
 #pragma unroll
     for (int q = 0; q < P; q++) {
-        const int b = u + T * q;
-        if (f == 1) { dx[q] = x[q].x; A.disp_g[rowoff + b] = x[q].y; }
-        else if (f == 2) { A.disp[rowoff + b] = mk(dx[q], x[q].x); if (A.disp_a) A.disp_a[rowoff + b] = x[q].y; }
-        else { A.height[rowoff + b] = x[q].x; if (A.height_g) A.height_g[rowoff + b] = x[q].y; }
+        if (f == 1) { dx[q] = x[q].x; (r_dg + T * q)[uo] = x[q].y; }
+        else if (f == 2) { (r_d + T * q)[uo] = mk(dx[q], x[q].x); if (r_da) (r_da + T * q)[uo] = x[q].y; }
+        else { (r_h + T * q)[uo] = x[q].x; if (r_hg) (r_hg + T * q)[uo] = x[q].y; }
     }
 }
 
