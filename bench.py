@@ -102,17 +102,37 @@ def pmc_traffic(workload, B, kernel, build_id):
     counter file was taken on THIS build of the library (the bench line stored in it carries mw_build_id())."""
     path = os.path.join(REPO, "profiles", f"{PROFILE_ROUND}_{workload}_b{B}_pmc.json")
     rel = os.path.relpath(path, REPO)
+    scale, scaled_note = 1.0, ""
     try:
         j = json.load(open(path))
     except Exception:
-        return None, f"no committed PMC pass for this workload/batch ({rel})"
+        # No counter pass at exactly this batch size (the passes are taken at the batch sizes the default and the driver's command
+        # use): quote the nearest one PER STEP -- a launch's workgroups are independent per time-step, the counters say 45.2 B per
+        # point at 20 and at 32 steps per launch alike -- and say so in the note.
+        import glob
+        import re
+        cands = []
+        for f in glob.glob(os.path.join(REPO, "profiles", f"{PROFILE_ROUND}_{workload}_b*_pmc.json")):
+            m = re.search(r"_b(\d+)_pmc\.json$", f)
+            if m:
+                cands.append((abs(int(m.group(1)) - B), int(m.group(1)), f))
+        if not cands:
+            return None, f"no committed PMC pass for this workload/batch ({rel})"
+        _, b_file, path = min(cands)
+        rel = os.path.relpath(path, REPO)
+        try:
+            j = json.load(open(path))
+        except Exception:
+            return None, f"unreadable PMC pass ({rel})"
+        scale = B / float(b_file)
+        scaled_note = f"; no pass at {B} steps per launch: the {b_file}-step pass scaled per step (x {scale:.3f})"
     theirs = (j.get("bench_line") or {}).get("build_id")
     if theirs != build_id:
         return None, f"{rel} was measured on build {theirs!r}, this run is build {build_id!r}: not quoted"
     ks = [v for name, v in j["pmc_mean_per_launch"].items() if kernel in name]
     if not ks or any("FETCH_SIZE" not in k or "WRITE_SIZE" not in k for k in ks):
         return None, f"{rel} has no FETCH_SIZE / WRITE_SIZE for {kernel}"
-    return sum((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 for k in ks), f"rocprofv3 --pmc, {rel} (same build)"
+    return scale * sum((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 for k in ks), f"rocprofv3 --pmc, {rel} (same build){scaled_note}"
 
 
 _hip = None

@@ -43,7 +43,12 @@ def test_counter_file_is_only_quoted_for_the_build_it_was_measured_on(tmp_path, 
     t, note = bench.pmc_traffic("ocean1024", 32, "k_pass", "0123456789abcdef default")
     assert t == (2 * 1010.0 + 3030.0) * 1024.0                               # several kernels of one call: their sum
     t, note = bench.pmc_traffic("ocean1024", 20, "k_pass2", "0123456789abcdef default")
-    assert t is None and "no committed PMC pass" in note                     # another batch size: another file
+    # another batch size without a pass of its own: the nearest pass of the SAME build, per step, and the note says so
+    assert t == (2 * 1000.0 + 3000.0) * 1024.0 * 20 / 32 and "scaled per step" in note and "b32" in note
+    t, note = bench.pmc_traffic("ocean1024", 20, "k_pass2", "fedcba9876543210 default")
+    assert t is None and "not quoted" in note                                # ... never across builds
+    t, note = bench.pmc_traffic("ocean2048", 32, "k_pass2", "0123456789abcdef default")
+    assert t is None and "no committed PMC pass" in note                     # another workload: nothing to quote
     rec["bench_line"] = None                                                 # a round-2 style file without a build id
     path.write_text(json.dumps(rec))
     t, note = bench.pmc_traffic("ocean1024", 32, "k_pass2", "0123456789abcdef default")
