@@ -13,6 +13,11 @@ bytes broadcast through torch.distributed, mw_tiles_create_rank everywhere).  to
 the barriers and the max-over-ranks of the timing; `--gather` adds the library's own gather of the last step of every
 batch to rank 0 (ncclSend/ncclRecv on a side stream behind an event), overlapped with the next batch.
 
+The default run (no --workload; what the driver runs) times the 1024^2 headline and then, at N = 1, BASELINE configs[3] (4096^2, 64 steps
+in 32-step enqueues) and configs[4] (the pond, 1M vertices x 8 waves) -- each with its own parity gate, `roofline` and bounded
+`cpu_baseline` -- under "configs": {"ocean4096": {...}, "pond": {...}} of the same line (--workload ocean1024 = the headline alone).
+Every K-step timed region is repeated until at least --min-timed-ms (50 ms) of timed work exist, whatever K the driver passes.
+
 Extra objects on the same line:
   roofline      dominant kernel (k_pass2) ALGORITHMIC bytes / its mean launch duration measured live with hipEvents on the
                 launch stream, against the 8 TB/s HBM peak (`frac`); `real_frac` = the HBM-side bytes the committed rocprofv3
@@ -43,7 +48,7 @@ BYTES_PASS1 = 16 + 24      # read (P,Q) + write 3 packed complex fields
 BYTES_PASS2 = 24 + 28      # read 3 packed complex fields + write vertex 12 + normal 12 + whitecap 4
 BYTES_POND = 24            # read position 12 + write position 12
 BYTES_RENDERER = 120       # see renderer()
-PROFILE_ROUND = "r04"      # profiles/<round>_<workload>_b<B>_pmc.json carry the counters of ONE build (its build_id inside)
+PROFILE_ROUND = "r05"      # profiles/<round>_<workload>_b<B>_pmc.json carry the counters of ONE build (its build_id inside)
 
 
 def parse():
@@ -51,7 +56,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", default="ocean1024", choices=["ocean1024", "ocean4096", "ocean2048", "ocean512", "ocean256", "pond", "renderer1024", "direct"])
+    ap.add_argument("--workload", default="all", choices=["all", "ocean1024", "ocean4096", "ocean2048", "ocean512", "ocean256", "pond", "renderer1024", "direct"],
+                    help="all (default) = the ocean1024 headline + at N = 1 BASELINE configs[3] (ocean4096) and [4] (pond) under `configs`")
     ap.add_argument("--direct-n", type=int, default=1000,
                     help="direct: grid size of the non-FFT FFTMesh case (50 = the Inspector default S/FFTMesh.cs:13, 100, 1000)")
     ap.add_argument("--batch", type=int, default=32, help="time-steps per enqueue (FFTMesh steps are independent in t)")
@@ -61,6 +67,8 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step timed region is run this many times (each between its own barrier + synchronize pairs); "
                          "`value` / `ms_per_step` are the MEDIAN region, min / max are printed beside it")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0,
+                    help="the K-step region is repeated at least until this much timed work exists (R = max(--repeats, ceil(this / region)))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-latency", action="store_true",
@@ -94,21 +102,23 @@ def host_cores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
-def pmc_traffic(workload, B, kernel, build_id):
+def pmc_traffic_ex(workload, B, kernel, build_id, tgroup=None):
     """HBM-side bytes per launch of `kernel` (a substring; several kernels: their sum) from the committed rocprofv3 PMC passes
     (tools/prof_workload.sh -> profiles/<round>_<workload>_b<B>_pmc.json): (2 * FETCH_SIZE + WRITE_SIZE) KiB, i.e. with the gfx950
     correction the micro-architecture guide prescribes (FETCH_SIZE counts 128-B requests at 64 B).  Counters cannot be read from
     inside this process: this is the value measured by the same command under the profiler -- and it is only quoted when the
-    counter file was taken on THIS build of the library (the bench line stored in it carries mw_build_id())."""
+    counter file was taken on THIS build of the library (the bench line stored in it carries mw_build_id()).
+    Returns {"traffic", "note", "scaled_from_b"}: scaled_from_b = the batch size of the pass that was scaled per step (None = a pass at
+    exactly this batch size).  Scaling holds for kernels whose workgroups are independent per time-step (pass 2, the pond, the renderer);
+    pass 1 reads the spectrum once per TIME GROUP, so its counters are only quoted from a pass with the same group size (`tgroup`)."""
     path = os.path.join(REPO, "profiles", f"{PROFILE_ROUND}_{workload}_b{B}_pmc.json")
     rel = os.path.relpath(path, REPO)
-    scale, scaled_note = 1.0, ""
+    scale, scaled_note, b_file = 1.0, "", None
     try:
         j = json.load(open(path))
     except Exception:
         # No counter pass at exactly this batch size (the passes are taken at the batch sizes the default and the driver's command
-        # use): quote the nearest one PER STEP -- a launch's workgroups are independent per time-step, the counters say 45.2 B per
-        # point at 20 and at 32 steps per launch alike -- and say so in the note.
+        # use): quote the nearest one PER STEP and say so in the note.
         import glob
         import re
         cands = []
@@ -117,22 +127,50 @@ def pmc_traffic(workload, B, kernel, build_id):
             if m:
                 cands.append((abs(int(m.group(1)) - B), int(m.group(1)), f))
         if not cands:
-            return None, f"no committed PMC pass for this workload/batch ({rel})"
+            return {"traffic": None, "note": f"no committed PMC pass for this workload/batch ({rel})", "scaled_from_b": None}
         _, b_file, path = min(cands)
         rel = os.path.relpath(path, REPO)
         try:
             j = json.load(open(path))
         except Exception:
-            return None, f"unreadable PMC pass ({rel})"
+            return {"traffic": None, "note": f"unreadable PMC pass ({rel})", "scaled_from_b": None}
         scale = B / float(b_file)
         scaled_note = f"; no pass at {B} steps per launch: the {b_file}-step pass scaled per step (x {scale:.3f})"
     theirs = (j.get("bench_line") or {}).get("build_id")
     if theirs != build_id:
-        return None, f"{rel} was measured on build {theirs!r}, this run is build {build_id!r}: not quoted"
+        return {"traffic": None, "note": f"{rel} was measured on build {theirs!r}, this run is build {build_id!r}: not quoted", "scaled_from_b": None}
+    if b_file is not None and "k_pass1" in kernel:
+        theirs_tg = ((j.get("bench_line") or {}).get("config") or {}).get("pass1_time_group")
+        if tgroup is None or theirs_tg != tgroup:
+            return {"traffic": None, "scaled_from_b": None,
+                    "note": f"{rel}: pass 1 reads the spectrum once per time group ({theirs_tg} there, {tgroup} here): its counters do not scale per step, not quoted"}
     ks = [v for name, v in j["pmc_mean_per_launch"].items() if kernel in name]
     if not ks or any("FETCH_SIZE" not in k or "WRITE_SIZE" not in k for k in ks):
-        return None, f"{rel} has no FETCH_SIZE / WRITE_SIZE for {kernel}"
-    return scale * sum((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 for k in ks), f"rocprofv3 --pmc, {rel} (same build){scaled_note}"
+        return {"traffic": None, "note": f"{rel} has no FETCH_SIZE / WRITE_SIZE for {kernel}", "scaled_from_b": None}
+    return {"traffic": scale * sum((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 for k in ks),
+            "note": f"rocprofv3 --pmc, {rel} (same build){scaled_note}", "scaled_from_b": b_file}
+
+
+def pmc_traffic(workload, B, kernel, build_id, tgroup=None):
+    r = pmc_traffic_ex(workload, B, kernel, build_id, tgroup)
+    return r["traffic"], r["note"]
+
+
+def pcts(xs):
+    """median / p10 / p90 / min / max of a list (nearest rank)."""
+    v = sorted(xs)
+    n = len(v)
+
+    def q(f):
+        return v[min(n - 1, int(round(f * (n - 1))))]
+    return {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "min": v[0], "max": v[-1], "n": n}
+
+
+def scaled_repeats(region_s, repeats, min_timed_ms, cap=2000):
+    """How many times the K-step region is run: at least `repeats`, and enough for `min_timed_ms` of timed work in total."""
+    import math
+    need = int(math.ceil(min_timed_ms * 1e-3 / max(region_s, 1e-7)))
+    return int(max(1, repeats, min(cap, need)))
 
 
 _hip = None
@@ -175,16 +213,17 @@ def preheat(enqueue, torch, ms):
     return (time.perf_counter() - t0) * 1e3
 
 
-def cpu_baseline_ocean(p, h0, h0c, gpu_step, budget_s=12.0):
+def cpu_baseline_ocean(p, h0, h0c, gpu_step, budget_s=12.0, quick=False):
     """CPU legs of an FFTMesh workload, all on the same (h0, h0conj, t = 1.0) step the GPU parity gate evaluated:
-      value         the literal O(N^4) port (oracle/fftmesh_oracle.c, one core) on a vertex sample sized for ~10-20 s;
+      value         the literal O(N^4) port (oracle/fftmesh_oracle.c, one core) on a vertex sample sized for ~budget_s seconds;
       literal_f32_distance   GPU output vs that literal float32 sum at the sampled vertices (the north star's "match the
                     reference C# CPU path": measured, not assumed);
-      fft_port*     numpy ifft2 in f64, and the float32 radix-2 Stockham port in C on 1 and on the best number of host threads."""
+      fft_port*     numpy ifft2 in f64, and the float32 radix-2 Stockham port in C on 1 and on the best number of host threads.
+    quick (the extra configs of the default line): fewer thread counts tried, one repetition each."""
     from oracle import oracle as O
     N = p.N
     rng = np.random.default_rng(0)
-    probe = rng.choice(N * N, 4, replace=False).astype(np.int32)
+    probe = rng.choice(N * N, 2 if quick else 4, replace=False).astype(np.int32)
     t0 = time.perf_counter()
     O.displacement_subset_f32(p, h0, h0c, 1.0, probe)
     per_vertex = (time.perf_counter() - t0) / probe.size
@@ -205,6 +244,7 @@ def cpu_baseline_ocean(p, h0, h0c, gpu_step, budget_s=12.0):
                 "normal_abs": float(np.abs(n[idx] - nor).max()),
                 "note": "relative to max |displacement| of the sample; the literal float32 sum of N^2 terms is itself only "
                         "~1e-4 accurate (tests/test_gpu_parity.py bounds it at 3e-4)"}
+        del rest
     t1 = time.perf_counter()
     O.eval_fft_f64(p, h0, h0c, 1.0)
     el_fft = time.perf_counter() - t1
@@ -216,10 +256,13 @@ def cpu_baseline_ocean(p, h0, h0c, gpu_step, budget_s=12.0):
             O.cpu_fft_step_f32(p, h0, h0c, 1.0 + r / 60.0, nthreads)
         return (time.perf_counter() - t2) / reps
     cores = host_cores()
-    el_c1 = time_c(1, 2 if N <= 1024 else 1)
+    el_c1 = time_c(1, 2 if (N <= 1024 and not quick) else 1)
     # more threads than the memory system can feed only add barrier cost: report the best thread count, name it
-    cands = sorted({c for c in (cores, cores // 2, cores // 4, cores // 8, 32, 16, 8) if 1 <= c <= cores})
-    el_call, best_threads = min((time_c(c, 3 if N <= 1024 else 1), c) for c in cands)
+    if quick:
+        cands = sorted({c for c in (cores // 2, cores // 4, 32) if 1 <= c <= cores})
+    else:
+        cands = sorted({c for c in (cores, cores // 2, cores // 4, cores // 8, 32, 16, 8) if 1 <= c <= cores})
+    el_call, best_threads = min((time_c(c, 3 if (N <= 1024 and not quick) else 1), c) for c in cands)
     return {
         "value": count / el, "unit": "grid-points/s", "cores": 1, "kind": "port",
         "sample": f"{count} of {N * N} vertices of one {N}x{N} step through the literal O(N^4) "
@@ -235,54 +278,105 @@ def cpu_baseline_ocean(p, h0, h0c, gpu_step, budget_s=12.0):
     }
 
 
-def main():
-    a = parse()
+class Env:
+    """What every workload needs from the process: torch, the package, the process group and this rank's device and stream."""
+    pass
+
+
+def setup(a):
     import torch
     import mistral_water as mw
-    import workloads
-    from oracle import oracle as O
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    dist = None
-    same_device = os.environ.get("MW_BENCH_SAME_DEVICE") == "1"
-    if world > 1:
+    e = Env()
+    e.torch, e.mw = torch, mw
+    e.world = int(os.environ.get("WORLD_SIZE", "1"))
+    e.rank = int(os.environ.get("RANK", "0"))
+    e.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != e.world and e.world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={e.world}")
+    e.dist = None
+    e.same_device = os.environ.get("MW_BENCH_SAME_DEVICE") == "1"
+    if e.world > 1:
         import torch.distributed as dist
+        e.dist = dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # test hooks for a 1-GPU box (never set by the driver): MW_BENCH_BACKEND=gloo + MW_BENCH_SAME_DEVICE=1 run the
         # N > 1 control flow (barriers, max-over-ranks, rank-0 reporting) with every rank on cuda:0; an RCCL communicator
         # cannot hold one device twice, so that mode drives plain mw_ocean handles instead of the tile API
         backend = os.environ.get("MW_BENCH_BACKEND", "nccl")
-        if same_device:
-            local_rank = 0
+        if e.same_device:
+            e.local_rank = 0
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", e.local_rank))
         else:
             dist.init_process_group(backend)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    red_dev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
-    stream = torch.cuda.current_stream()
+    torch.cuda.set_device(e.local_rank)
+    e.dev = torch.device("cuda", e.local_rank)
+    e.red_dev = e.dev if (e.dist is None or e.dist.get_backend() == "nccl") else torch.device("cpu")
+    e.stream = torch.cuda.current_stream()
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if e.dist is not None:
+            e.dist.barrier()
         torch.cuda.synchronize()
+    e.barrier = barrier
+    e.hung = False
+    return e
 
+
+def main():
+    a = parse()
+    e = setup(a)
+    extra = (a.workload == "all")
     if a.workload == "pond":
-        return pond(a, mw, torch, dev, stream, barrier, dist, rank, world)
-    if a.workload == "renderer1024":
-        return renderer(a, mw, torch, dev, stream, barrier, dist, rank, world)
-    if a.workload == "direct":
-        return direct(a, mw, torch, dev, stream, barrier, dist, rank, world)
+        out = pond(a, e)
+    elif a.workload == "renderer1024":
+        out = renderer(a, e)
+    elif a.workload == "direct":
+        out = direct(a, e)
+    else:
+        N = {"all": 1024, "ocean1024": 1024, "ocean4096": 4096, "ocean2048": 2048, "ocean512": 512, "ocean256": 256}[a.workload]
+        out = ocean(a, e, N)
+        if extra and e.world == 1 and e.rank == 0:
+            # BASELINE configs[3] and [4] on the same line (VERDICT r4 item 1): their own step counts (the driver's K belongs to the
+            # headline), their own parity gates, roofline objects and bounded CPU baselines; a failure of one is reported in its
+            # place and never takes the headline down
+            import copy
+            cfgs = {}
+            t_extra = time.perf_counter()
+            for name, fn, over in (("ocean4096", lambda aa: ocean(aa, e, 4096, extra=True), dict(steps=64, warmup=32, batch=32)),
+                                   ("pond", lambda aa: pond(aa, e, extra=True), dict(steps=3200, warmup=320, batch=32))):
+                aa = copy.copy(a)
+                for k, v in over.items():
+                    setattr(aa, k, v)
+                t0 = time.perf_counter()
+                try:
+                    cfgs[name] = fn(aa)
+                except Exception as ex:      # noqa: BLE001 -- reported in the line
+                    import traceback
+                    cfgs[name] = {"error": repr(ex), "trace": traceback.format_exc()[-800:]}
+                cfgs[name]["bench_wall_s"] = time.perf_counter() - t0
+                e.torch.cuda.empty_cache()
+            out["configs"] = cfgs
+            out["configs_wall_s"] = time.perf_counter() - t_extra
+        elif extra and e.rank == 0:
+            out["configs"] = None      # N > 1: the headline only (configs[3] / [4] are single-GPU configurations)
+    if e.dist is not None:
+        e.dist.destroy_process_group()
+    emit(out if e.rank == 0 else None)
+    if e.hung:            # a worker thread is still blocked inside the communicator bootstrap: do not wait for it at exit
+        os._exit(0)
 
+
+def ocean(a, e, N, extra=False):
+    """One FFTMesh-semantics ocean workload (SURVEY 8d config 2 at N = 1024, config 4 at N = 4096): returns the result object.
+    extra = True: one of the additional configs of the default line (compact CPU baseline, no host-pointer frames)."""
+    torch, mw, dist, rank, world, local_rank = e.torch, e.mw, e.dist, e.rank, e.world, e.local_rank
+    dev, red_dev, stream, barrier, same_device = e.dev, e.red_dev, e.stream, e.barrier, e.same_device
+    import workloads
+    from oracle import oracle as O
     from mistral_water import parallel as par
     from mistral_water import _native as nat
-    N = {"ocean1024": 1024, "ocean4096": 4096, "ocean2048": 2048, "ocean512": 512, "ocean256": 256}[a.workload]
     NN = N * N
     p = workloads.fftmesh_config2(N)      # SURVEY 8d config 2 / 4, literally: amplitude 0.41, choppiness 0.46, wind (14.45, 12)
     shard_steps = (a.shard == "steps" and world > 1)
@@ -295,8 +389,9 @@ def main():
     lo, hi = par.shard_steps(a.steps, world, rank) if shard_steps else (0, a.steps)
     k_local = hi - lo
     # MW_BENCH_FORCE_TILES=1 (test hook): the tile API path with a one-rank communicator on a 1-GPU box
-    use_tiles = ((world > 1 and not same_device) or os.environ.get("MW_BENCH_FORCE_TILES") == "1") and not shard_steps
+    use_tiles = ((world > 1 and not same_device) or os.environ.get("MW_BENCH_FORCE_TILES") == "1") and not shard_steps and not extra
     tiles = ocean = None
+    tiles_note = None
     B, sizes = batch_plan(max(k_local, 1), max(1, min(a.batch, 32)))
     if use_tiles:
         # the product's tile API: the LIBRARY owns the RCCL communicator; torch.distributed only carries its 128-byte id
@@ -304,8 +399,8 @@ def main():
         if rank == 0:
             try:
                 box[0] = mw.Tiles.unique_id()
-            except mw.MistralWaterError as e:      # RCCL not loadable: say so in the result instead of dying on every rank
-                box[0] = "ERR:" + str(e)
+            except mw.MistralWaterError as ex:      # RCCL not loadable: say so in the result instead of dying on every rank
+                box[0] = "ERR:" + str(ex)
         if dist is not None:
             dist.broadcast_object_list(box, src=0)
         if isinstance(box[0], str):
@@ -320,8 +415,8 @@ def main():
             def _make():
                 try:
                     made["tiles"] = mw.Tiles(max_steps=B, seed=1, comm_id=box[0], rank=rank, nranks=world, device=local_rank, **kw)
-                except Exception as e:      # noqa: BLE001 -- reported in the result line
-                    made["err"] = repr(e)
+                except Exception as ex:      # noqa: BLE001 -- reported in the result line
+                    made["err"] = repr(ex)
             th = threading.Thread(target=_make, daemon=True)
             th.start()
             th.join(timeout=float(os.environ.get("MW_BENCH_TILES_TIMEOUT", "120")))
@@ -339,9 +434,7 @@ def main():
                 tiles_note = made.get("err", "mw_tiles_create_rank did not return in time on some rank" if ok_local else "timed out")
                 if "tiles" in made:
                     made["tiles"].close()
-                hung = th.is_alive()
-    tiles_note = locals().get("tiles_note")
-    hung = locals().get("hung", False)
+                e.hung = e.hung or th.is_alive()
     if not use_tiles:
         ocean = mw.Ocean(seed=seed, device=local_rank, **kw)
         ocean.set_stream(stream.cuda_stream)
@@ -456,10 +549,15 @@ def main():
         barrier()
         return par.max_over_ranks(el, dist, red_dev) if dist is not None else el
 
-    R = max(1, a.repeats)
+    # R: at least --repeats regions and at least --min-timed-ms of timed work in total (at the driver's K = 20 a
+    # region is 0.27 ms -- five of them were 1.4 ms of evidence).  The pilot region sizes R and is not counted; every rank uses
+    # rank 0's figure (wall_region already returns the max over ranks, identical everywhere).
+    pilot = wall_region()
+    R = scaled_repeats(pilot, a.repeats, a.min_timed_ms)
     regions = [wall_region() for _ in range(R)]
     el = float(np.median(regions))
-    ev_regions = [event_region() for _ in range(R)] if not use_tiles else None
+    R_ev = min(R, 64)
+    ev_regions = [event_region() for _ in range(R_ev)] if not use_tiles else None
     el_events = float(np.median(ev_regions)) if ev_regions else None
     el_gather = gather_regions = None
     if a.gather and use_tiles:      # the same K steps again, now with the per-batch gather to rank 0 overlapped
@@ -470,7 +568,6 @@ def main():
 
     # ---- kernel-level timing with HIP events on the launch stream (rank 0) ----------------------------
     prof = tiles_ocean = None
-    import ctypes as C
     if use_tiles:
         # the tile's own mw_ocean handle (borrowed) runs the in-situ profile on the tile's compute stream
         tiles_ocean = mw.Ocean.__new__(mw.Ocean)
@@ -479,33 +576,43 @@ def main():
     else:
         prof = ocean
     preheat(lambda: run([B], 0), torch, a.preheat_ms)     # the all-reduce above may have let the clocks drop
-    kern = prof.profile_kernels(nsteps=B, iters=100)       # in situ: pass1/pass2 alternate as in the timed loop, SAME batch size
+    iters = 100 if N <= 1024 else (40 if N == 2048 else 16)
+    kstats = prof.profile_kernels_stats(nsteps=B, iters=iters)     # in situ: pass1/pass2 alternate as in the timed loop, SAME batch size
+    kern = [(nm, st["mean"]) for nm, st in kstats]
     tgroup = int(mw.lib().mw_debug_pass1_time_group(prof._h, B))
-    kern32 = prof.profile_kernels(nsteps=32, iters=50) if B != 32 else None   # context only: the same kernels at the full batch
+    kern32 = prof.profile_kernels(nsteps=32, iters=50) if (B != 32 and not extra) else None   # context only: the same kernels at the full batch
     if tiles_ocean is not None:
         tiles_ocean._h = None                            # borrowed: the tiles own it
+    wl_name = f"ocean{N}"
     k2_ms = kern[1][1]
+    k2_med = kstats[1][1]["median"]
     roof_ach = BYTES_PASS2 * NN * B / (k2_ms * 1e-3)
-    traffic, traffic_note = pmc_traffic(a.workload, B, "k_pass2", build_id)
-    traffic1, _ = pmc_traffic(a.workload, B, "k_pass1", build_id)
+    tr2 = pmc_traffic_ex(wl_name, B, "k_pass2", build_id)
+    tr1 = pmc_traffic_ex(wl_name, B, "k_pass1", build_id, tgroup=tgroup)
+    traffic, traffic_note, traffic1 = tr2["traffic"], tr2["note"], tr1["traffic"]
     stale = None
     if traffic is None:      # context only, never `traffic`: the last committed counter pass of this kernel, whatever build it was
-        for rnd in ("r04", "r02"):
+        for rnd in ("r05", "r04", "r02"):
             try:
-                j = json.load(open(os.path.join(REPO, "profiles", f"{rnd}_{a.workload}_b32_pmc.json")))["pmc_mean_per_launch"]
+                j = json.load(open(os.path.join(REPO, "profiles", f"{rnd}_{wl_name}_b32_pmc.json")))["pmc_mean_per_launch"]
                 k = [v for name, v in j.items() if "k_pass2" in name][0]
                 stale = {"bytes_per_point": (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 / (NN * 32),
-                         "source": f"profiles/{rnd}_{a.workload}_b32_pmc.json",
+                         "source": f"profiles/{rnd}_{wl_name}_b32_pmc.json",
                          "note": "counters of an EARLIER build of the same kernel (32-step launches): not this build's traffic"}
                 break
             except Exception:
                 pass
     roofline = {"bound": "hbm", "kernel": "k_pass2", "achieved": roof_ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": roof_ach / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
+                "frac": roof_ach / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note, "traffic_scaled_from_b": tr2["scaled_from_b"],
                 "real_frac": (traffic / (k2_ms * 1e-3) / HBM_PEAK) if traffic else None,
                 "traffic_previous_build": stale,
                 "physical_bytes_per_point": (traffic / (NN * B)) if traffic else None,
                 "bytes_per_launch": BYTES_PASS2 * NN * B, "algorithmic_bytes_per_point": BYTES_PASS2, "launch_us": k2_ms * 1e3,
+                # the same launches as a distribution (mw_ocean_profile_kernels_stats): `frac` above is bytes / the MEAN launch duration as
+                # the contract prescribes; a rocprofv3 kernel trace of this command (profiles/<round>_*_kernel_pcts.json: median, p10, p90
+                # after warm-up) reproduces the median
+                "launch_us_stats": {k: v * 1e3 for k, v in kstats[1][1].items()}, "launches_timed": iters,
+                "frac_at_median_launch": BYTES_PASS2 * NN * B / (k2_med * 1e-3) / HBM_PEAK,
                 "steps_per_launch": B,
                 "at_full_batch": None if kern32 is None else {
                     "steps_per_launch": 32, "launch_us": kern32[1][1] * 1e3, "frac": BYTES_PASS2 * NN * 32 / (kern32[1][1] * 1e-3) / HBM_PEAK,
@@ -516,12 +623,14 @@ def main():
                 # say it physically moved.  Pass 1 does not move its 40-B share (the spectrum is read once per time group and two of
                 # its three fields are half-stored: 18.6 B physical), so share / time exceeds the HBM peak BY CONSTRUCTION there: it is
                 # printed as `share_GBps_bookkeeping`, never as a bandwidth; `physical_GBps` is the bandwidth.
-                "kernels": [{"name": nm, "us_per_launch": ms * 1e3,
+                "kernels": [{"name": nm, "us_per_launch": ms * 1e3, "us_per_launch_median": kstats[i][1]["median"] * 1e3,
+                             "us_per_launch_p10": kstats[i][1]["p10"] * 1e3, "us_per_launch_p90": kstats[i][1]["p90"] * 1e3,
                              "share_bytes_per_point": (BYTES_PASS1 if i == 0 else BYTES_PASS2),
                              "share_GBps_bookkeeping": (BYTES_PASS1 if i == 0 else BYTES_PASS2) * NN * B / (ms * 1e-3) / 1e9,
                              "physical_bytes_per_point": (tr / (NN * B)) if tr else None,
-                             "physical_GBps": (tr / (ms * 1e-3) / 1e9) if tr else None}
-                            for i, ((nm, ms), tr) in enumerate(zip(kern, (traffic1, traffic)))]}
+                             "physical_GBps": (tr / (ms * 1e-3) / 1e9) if tr else None,
+                             "traffic_scaled_from_b": sc}
+                            for i, ((nm, ms), tr, sc) in enumerate(zip(kern, (traffic1, traffic), (tr1["scaled_from_b"], tr2["scaled_from_b"])))]}
 
     # ---- the frame-at-a-time path (what FFTMesh.Update, S/FFTMesh.cs:60-73, drives): untimed region, rank 0 ------------
     frame = None
@@ -529,37 +638,41 @@ def main():
         for _ in range(20):
             enqueue([1.0])
         torch.cuda.synchronize()
+        nfr = 200 if N <= 1024 else 50
         t2 = time.perf_counter()
-        for k in range(200):
+        for k in range(nfr):
             enqueue([(k + 1) / 60.0])
         torch.cuda.synchronize()
-        single_us = (time.perf_counter() - t2) / 200 * 1e6
-        hv, hn, hc = (np.empty((NN, 3), np.float32), np.empty((NN, 3), np.float32), np.empty((NN, 4), np.float32))
-
-        def host_frames(n):
-            ocean.evaluate_into(1.0, hv, hn, hc)
-            t3 = time.perf_counter()
-            for k in range(n):
-                ocean.evaluate_into((k + 1) / 60.0, hv, hn, hc)
-            return (time.perf_counter() - t3) / n * 1e3
-        reps = 10 if N <= 1024 else 2
-        ms_pageable = host_frames(reps)
-        for arr in (hv, hn, hc):
-            mw.host_register(arr)
-        ms_registered = host_frames(reps)
-        for arr in (hv, hn, hc):
-            mw.host_unregister(arr)
+        single_us = (time.perf_counter() - t2) / nfr * 1e6
         frame = {"device_us_per_step": single_us, "device_points_per_s": NN / (single_us * 1e-6),
                  "device_frac_of_hbm_roofline": NN * BYTES_PER_POINT / (single_us * 1e-6) / HBM_PEAK,
-                 "host_ms_per_frame_pageable": ms_pageable, "host_ms_per_frame_registered": ms_registered,
-                 "what": "one time-step per call: device pointers, 200 calls back to back (mw_ocean_evaluate_device, nsteps = 1); "
-                         "host pointers = mw_ocean_evaluate into Vector3[] / Vector3[] / Color[] arrays (40 B per point over PCIe), "
-                         "pageable and page-locked once with mw_host_register"}
+                 "what": f"one time-step per call: device pointers, {nfr} calls back to back (mw_ocean_evaluate_device, nsteps = 1)"}
+        if not extra:
+            hv, hn, hc = (np.empty((NN, 3), np.float32), np.empty((NN, 3), np.float32), np.empty((NN, 4), np.float32))
+
+            def host_frames(n):
+                ocean.evaluate_into(1.0, hv, hn, hc)
+                t3 = time.perf_counter()
+                for k in range(n):
+                    ocean.evaluate_into((k + 1) / 60.0, hv, hn, hc)
+                return (time.perf_counter() - t3) / n * 1e3
+            reps = 10 if N <= 1024 else 2
+            ms_pageable = host_frames(reps)
+            for arr in (hv, hn, hc):
+                mw.host_register(arr)
+            ms_registered = host_frames(reps)
+            for arr in (hv, hn, hc):
+                mw.host_unregister(arr)
+            del hv, hn, hc
+            frame.update({"host_ms_per_frame_pageable": ms_pageable, "host_ms_per_frame_registered": ms_registered,
+                          "what": frame["what"] + "; host pointers = mw_ocean_evaluate into Vector3[] / Vector3[] / Color[] arrays (40 B per point "
+                                                  "over PCIe), pageable and page-locked once with mw_host_register"})
 
     k_total = a.steps if shard_steps else world * a.steps
     value = k_total * NN / el
     per_gpu = value / world
     phys_pt = ((traffic or 0) + (traffic1 or 0)) / (NN * B) if (traffic and traffic1) else None
+    rp = pcts(regions)
     out = {
         "metric": BASELINE_METRIC if N == 1024
         else f"ocean grid-points/sec (full spectrum->IFFT->disp->Jacobian), {N}^2 grid",
@@ -567,12 +680,17 @@ def main():
         "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard_steps else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "preheat_ms": preheat_ms, "build_id": build_id,
         "event_ms_per_step": (el_events / a.steps * 1e3) if el_events is not None else None,
-        "repeats": R, "region_ms": [round(x * 1e3, 5) for x in regions],
+        "repeats": R, "timed_ms_total": sum(regions) * 1e3,
+        "region_ms": [round(x * 1e3, 5) for x in regions[:8]] + (["..."] if R > 8 else []),
+        "region_ms_stats": {k: (round(v * 1e3, 5) if k != "n" else v) for k, v in rp.items()},
         "ms_per_step_min": min(regions) / a.steps * 1e3, "ms_per_step_max": max(regions) / a.steps * 1e3,
-        "event_region_ms": [round(x * 1e3, 5) for x in ev_regions] if ev_regions else None,
+        "ms_per_step_p10": rp["p10"] / a.steps * 1e3, "ms_per_step_p90": rp["p90"] / a.steps * 1e3,
+        "event_region_ms": [round(x * 1e3, 5) for x in ev_regions[:8]] if ev_regions else None,
+        "event_region_ms_stats": {k: (round(v * 1e3, 5) if k != "n" else v) for k, v in pcts(ev_regions).items()} if ev_regions else None,
         "wall_over_events": (el / el_events) if el_events else None,
-        "timing": f"median of {R} runs of the K-step region, each between barrier + torch.cuda.synchronize() pairs (wall clock, max over "
-                  f"ranks); event_* = the same region by HIP events on the launch stream, {R} separate runs",
+        "timing": f"median of {R} runs of the K-step region (>= --repeats {a.repeats} and >= {a.min_timed_ms:g} ms of timed work in total), each "
+                  f"between barrier + torch.cuda.synchronize() pairs (wall clock, max over ranks); event_* = the same region by HIP events on "
+                  f"the launch stream, {R_ev} separate runs",
         "config": {"workload": f"SURVEY 8d config {2 if N == 1024 else 4 if N == 4096 else '2 at another N'}, literally: "
                                f"FFTMesh-semantics ocean {N}x{N}, height+choppy+normals+Jacobian whitecap, "
                                f"unit_width {p.unit_width:g}, length {p.length:g}, wind ({p.wind_x:g}, {p.wind_y:g}), "
@@ -598,30 +716,36 @@ def main():
     if el_gather is not None:
         out["with_gather"] = {"value": world * a.steps * NN / el_gather, "ms_per_step": el_gather / a.steps * 1e3,
                               "gathers": gathers[0], "bytes_per_gather_per_tile": NN * 28,
-                              "region_ms": [round(x * 1e3, 5) for x in gather_regions],
+                              "region_ms": [round(x * 1e3, 5) for x in gather_regions[:8]],
                               "what": "the same K steps with the library's RCCL gather of every batch's last step to rank 0 "
                                       "(mw_tiles_gather: ncclSend/ncclRecv on the side stream behind an event)"}
+    # free the device before the CPU legs (and before the next config of the default line)
+    if tiles is not None:
+        tiles.close()
+    if not use_tiles:
+        del dv, dn, dw
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         if h0 is None:
             h0, h0c = ocean.get_spectrum()
-        out["cpu_baseline"] = cpu_baseline_ocean(p, h0, h0c, gpu_step)
+        if ocean is not None:
+            ocean.close()
+            ocean = None
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline_ocean(p, h0, h0c, gpu_step, budget_s=(6.0 if extra else 12.0), quick=extra)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if tiles is not None:
-        tiles.close()
     if ocean is not None:
         ocean.close()
-    if dist is not None:
-        dist.destroy_process_group()
-    emit(out if rank == 0 else None)
-    if hung:            # a worker thread is still blocked inside the communicator bootstrap: do not wait for it at exit
-        os._exit(0)
+    _prepared.clear()
+    _plans.clear()
+    torch.cuda.empty_cache()
+    return out
 
 
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, v_mfma_f32_32x32x2_f32 = the f32 vector rate (MI355X_MICROARCH.md)
 
 
-def direct(a, mw, torch, dev, stream, barrier, dist, rank, world):
+def direct(a, e):
     """FFTMesh grids the FFT cannot express (non-power-of-two N, unit_width != length / N: the reference's
     shipped scene and its Inspector defaults) through the separable direct sum as matrix products on v_mfma_f32_32x32x2_f32.
     One step = one EvaluateWaves(t) of an N x N grid; algorithmic work 60 N^3 flop per step (csrc/direct_kernels.h): compute-
@@ -630,6 +754,7 @@ def direct(a, mw, torch, dev, stream, barrier, dist, rank, world):
     from oracle import oracle as O
     import workloads
     from mistral_water import _native as nat
+    mw, torch, dev, stream, barrier, dist, rank, world = e.mw, e.torch, e.dev, e.stream, e.barrier, e.dist, e.rank, e.world
     N = a.direct_n
     if N == 50:
         p = O.Params(N=50, unit_width=1.0, length=1.0, wind_x=1.0, wind_y=1.0, amplitude=1.0, choppiness=1.0, gravity=9.81)
@@ -696,6 +821,7 @@ def direct(a, mw, torch, dev, stream, barrier, dist, rank, world):
                          f"(oracle/fftmesh_oracle.c), {elc:.1f} s; host has {os.cpu_count()} cores",
                "separable_f64_blas": {"value": NN / elm, "unit": "grid-points/s", "cores": host_cores(),
                                       "what": "the same step as two complex128 matrix products through numpy/BLAS (oracle.eval_matmul_f64), all host cores"}}
+    out = None
     if rank == 0:
         v = world * a.steps * NN / el
         czt = "k_czt" in kern[0][0]
@@ -722,7 +848,7 @@ def direct(a, mw, torch, dev, stream, barrier, dist, rank, world):
                     "note": "achieved = 60 N^3 algorithmic flop of one step / the mean duration of that step's four GEMM launches "
                             "(HIP events on the launch stream); the GEMMs execute the zero-padded size"}
             path = f"direct sum as 4 MFMA GEMM launches (MW_DIRECT_CZT=0 or N > 2048), operands padded to {(N + 63) // 64 * 64}"
-        emit({
+        out = {
             "metric": f"FFTMesh direct-sum grid-points/sec (non-FFT grid, spectrum -> separable sum -> disp -> Jacobian), {N}^2 grid",
             "value": v, "unit": "grid-points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "build_id": nat.build_id(),
@@ -730,11 +856,12 @@ def direct(a, mw, torch, dev, stream, barrier, dist, rank, world):
                                    f"amplitude {p.amplitude:.3g}, choppiness {p.choppiness:g}: not FFT-expressible, one step per call "
                                    f"(SURVEY 8f rank 2; N = 50 is the reference's Inspector default, S/FFTMesh.cs:13-19)",
                        "grid": N, "semantics": "MW_SEM_FFTMESH", "path": path},
-            "roofline": roof, "parity": parity, "cpu_baseline": cpu})
+            "roofline": roof, "parity": parity, "cpu_baseline": cpu}
     o.close()
+    return out
 
 
-def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):
+def renderer(a, e):
     """OceanRenderer semantics at the reference's shipped configuration (D/Ocean Demo.unity:296-302): 1024^2 textures,
     one GenerateTexture() per step.  The phase is stateful, so steps cannot be batched (F/FFTCommon.cginc:101-104).
     Algorithmic bytes per texel: 20 (spectrum + phase in) + 4 (phase out) + 24 + 24 (exchange) + 16 (height, disp.rgb out)
@@ -742,6 +869,7 @@ def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):
     import ctypes as C
     from mistral_water import _native as nat
     from oracle import oracle as O
+    mw, torch, dev, stream, barrier, dist, rank, world = e.mw, e.torch, e.dev, e.stream, e.barrier, e.dist, e.rank, e.world
     T = max(1, a.tiles)
     o = mw.Ocean(resolution=128, length=434.48, wind=(14.45, 12.0), amplitude=0.41, choppiness=0.46, mult=1.5,
                  seed=1 + 64 * rank, semantics=mw.MW_SEM_OCEANRENDERER, device=dev.index, ntiles=T)
@@ -776,12 +904,13 @@ def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):
         cpu = {"value": M * M / elc, "unit": "texels/s", "cores": 1, "kind": "port",
                "sample": f"{frames} whole GenerateTexture() frames of the same 1024^2 texture through oracle/ocean_renderer_oracle.c "
                          f"(+ numpy fft2 for the Stockham blits), {elc:.2f} s per frame; host has {os.cpu_count()} cores"}
+    out = None
     if rank == 0:
         v = world * a.steps * M * M * T / el
         from mistral_water import _native as nat2
         build_id = nat2.build_id()
         traffic, traffic_note = pmc_traffic("renderer1024", T, "k_or_", build_id)     # the frame's three kernels together
-        print(json.dumps({
+        out = ({
             "metric": "OceanRenderer-semantics texels/sec (dispersion+spectrum -> 2-D Stockham -> normal -> whitecap), 1024^2",
             "value": v, "unit": "texels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -794,15 +923,19 @@ def renderer(a, mw, torch, dev, stream, barrier, dist, rank, world):
             "roofline": {"bound": "hbm", "kernel": "whole frame (3 kernels)", "achieved": v * BYTES_RENDERER / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": v * BYTES_RENDERER / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
                          "traffic_what": f"HBM-side bytes of one call = {T} tile-frame(s), all three kernels",
-                         "physical_bytes_per_texel": (traffic / (M * M * T)) if traffic else None}, "cpu_baseline": cpu}))
+                         "physical_bytes_per_texel": (traffic / (M * M * T)) if traffic else None}, "cpu_baseline": cpu})
     o.close()
+    return out
 
 
-def pond(a, mw, torch, dev, stream, barrier, dist, rank, world):
-    """BASELINE configs[4]: 1M-vertex, 8-wave Gerstner displacement; 24 B/vertex algorithmic."""
+def pond(a, e, extra=False):
+    """BASELINE configs[4]: 1M-vertex, 8-wave Gerstner displacement; 24 B/vertex algorithmic (positions read once per launch of B time
+    values, results written per step: (12 / B + 12) B per vertex-step)."""
     import ctypes as C
     import workloads
     from mistral_water import _native as nat
+    from mistral_water import parallel as par
+    mw, torch, dev, stream, barrier, dist, rank, world = e.mw, e.torch, e.dev, e.stream, e.barrier, e.dist, e.rank, e.world
     nv = 1000 * 1000
     g = torch.linspace(-50, 50, 1001, device=dev)[:-1]
     pos = torch.stack(torch.meshgrid(g, g, indexing="ij"), -1)
@@ -811,22 +944,31 @@ def pond(a, mw, torch, dev, stream, barrier, dist, rank, world):
     P = workloads.POND
     B = max(1, min(a.batch, nat.lib().mw_gerstner_max_steps(8)))   # time values per launch (steps are independent in t)
     out_t = torch.empty((B, nv, 3), dtype=torch.float32, device=dev)
+    lib = nat.lib()
+    _calls = {}
+
+    def call(k, nb):      # the C-ABI call of the launch that covers steps k .. k + nb - 1, marshalled once
+        if (k, nb) not in _calls:
+            tt = np.array([(kk + 1) / 60.0 for kk in range(k, k + nb)], np.float32)
+            if nb == 1:     # the single-step entry point (one sincos per wave and vertex)
+                c = (lib.mw_gerstner_displace_device,
+                     (C.c_void_p(pos.data_ptr()), nv, W.ctypes.data_as(C.c_void_p), 8, C.c_float(P["amplitude"]),
+                      C.c_float(P["frequency"]), C.c_float(P["steepness"]), C.c_float(float(tt[0])), C.c_void_p(out_t.data_ptr()),
+                      C.c_void_p(stream.cuda_stream)))
+            else:
+                c = (lib.mw_gerstner_displace_steps_device,
+                     (C.c_void_p(pos.data_ptr()), nv, W.ctypes.data_as(C.c_void_p), 8, C.c_float(P["amplitude"]),
+                      C.c_float(P["frequency"]), C.c_float(P["steepness"]), tt.ctypes.data_as(C.c_void_p), nb,
+                      C.c_void_p(out_t.data_ptr()), C.c_void_p(stream.cuda_stream)))
+            _calls[(k, nb)] = (tt, c)
+        return _calls[(k, nb)][1]
 
     def run(nsteps, k0):
         k = k0
         while k < k0 + nsteps:
             nb = min(B, k0 + nsteps - k)
-            tt = np.array([(kk + 1) / 60.0 for kk in range(k, k + nb)], np.float32)
-            if nb == 1:     # the single-step entry point (one sincos per wave and vertex)
-                nat.check(nat.lib().mw_gerstner_displace_device(
-                    C.c_void_p(pos.data_ptr()), nv, W.ctypes.data_as(C.c_void_p), 8, C.c_float(P["amplitude"]),
-                    C.c_float(P["frequency"]), C.c_float(P["steepness"]), C.c_float(float(tt[0])), C.c_void_p(out_t.data_ptr()),
-                    C.c_void_p(stream.cuda_stream)))
-            else:
-                nat.check(nat.lib().mw_gerstner_displace_steps_device(
-                    C.c_void_p(pos.data_ptr()), nv, W.ctypes.data_as(C.c_void_p), 8, C.c_float(P["amplitude"]),
-                    C.c_float(P["frequency"]), C.c_float(P["steepness"]), tt.ctypes.data_as(C.c_void_p), nb,
-                    C.c_void_p(out_t.data_ptr()), C.c_void_p(stream.cuda_stream)))
+            fn, args = call(k, nb)
+            nat.check(fn(*args))
             k += nb
 
     # parity gate on a sample of the lattice, first and last step of one launch
@@ -844,21 +986,41 @@ def pond(a, mw, torch, dev, stream, barrier, dist, rank, world):
     barrier()
     preheat(lambda: run(B, 0), torch, a.preheat_ms)
     run(a.warmup, 0)
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(stream)
-    run(a.steps, a.warmup)
-    e1.record(stream)
+    run(a.steps, a.warmup)      # the timed plan's calls exist before the first region
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    barrier()
-    if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-    step_us = e0.elapsed_time(e1) * 1e3 / a.steps
-    real = (12.0 / B + 12.0) * nv / (step_us * 1e-6)
+
+    def wall_region():
+        barrier()
+        t0 = time.perf_counter()
+        run(a.steps, a.warmup)
+        while not stream.query():
+            pass
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        barrier()
+        return par.max_over_ranks(el, dist, e.red_dev)
+    pilot = wall_region()
+    R = scaled_repeats(pilot, a.repeats, a.min_timed_ms)
+    regions = [wall_region() for _ in range(R)]
+    el = float(np.median(regions))
+    # per-launch durations of the dominant kernel: HIP events between back-to-back launches on the launch stream
+    nl = 64
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nl + 1)]
+    fn, args = call(a.warmup, min(B, a.steps))
+    Bl = min(B, a.steps)
+    for _ in range(8):
+        nat.check(fn(*args))
+    evs[0].record(stream)
+    for i in range(nl):
+        nat.check(fn(*args))
+        evs[i + 1].record(stream)
+    torch.cuda.synchronize()
+    launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(nl)]
+    lp = pcts(launch_ms)
+    launch_mean_ms = float(np.mean(launch_ms))
+    bytes_launch = (12.0 + 12.0 * Bl) * nv
+    real = bytes_launch / (launch_mean_ms * 1e-3)
+    step_us = el / a.steps * 1e6
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # CPU_GERSTNER: the shader's own float32 arithmetic (oracle/gerstner_oracle.c), whole
@@ -866,15 +1028,15 @@ def pond(a, mw, torch, dev, stream, barrier, dist, rank, world):
         from concurrent.futures import ThreadPoolExecutor
         hp = np.ascontiguousarray(pos.cpu().numpy(), np.float32)
         ho = np.empty_like(hp)
-        args = (W, P["amplitude"], P["frequency"], P["steepness"])
+        args_c = (W, P["amplitude"], P["frequency"], P["steepness"])
 
         def step_cpu(nthreads, t):
             if nthreads == 1:
-                O.gerstner_f32_range(hp, 0, nv, *args, t, ho)
+                O.gerstner_f32_range(hp, 0, nv, *args_c, t, ho)
                 return
             cuts = np.linspace(0, nv, nthreads + 1).astype(np.int64)
             with ThreadPoolExecutor(nthreads) as ex:
-                list(ex.map(lambda i: O.gerstner_f32_range(hp, int(cuts[i]), int(cuts[i + 1]), *args, t, ho), range(nthreads)))
+                list(ex.map(lambda i: O.gerstner_f32_range(hp, int(cuts[i]), int(cuts[i + 1]), *args_c, t, ho), range(nthreads)))
 
         def time_cpu(nthreads, reps):
             step_cpu(nthreads, 0.0)
@@ -882,31 +1044,46 @@ def pond(a, mw, torch, dev, stream, barrier, dist, rank, world):
             for r in range(reps):
                 step_cpu(nthreads, (r + 1) / 60.0)
             return (time.perf_counter() - t1) / reps
-        el1 = time_cpu(1, 5)
+        reps = 3 if extra else 5
+        el1 = time_cpu(1, reps)
         cores = host_cores()
-        cands = sorted({c for c in (cores, cores // 2, cores // 4, 32, 16, 8) if 1 < c <= cores}) or [1]
-        eln, bestn = min((time_cpu(c, 5), c) for c in cands)
+        cands = sorted({c for c in ((cores // 2, 32) if extra else (cores, cores // 2, cores // 4, 32, 16, 8)) if 1 < c <= cores}) or [1]
+        eln, bestn = min((time_cpu(c, reps), c) for c in cands)
         cpu = {"value": nv / el1, "unit": "vertices/s", "cores": 1, "kind": "port",
-               "sample": f"5 whole steps of the same 1M-vertex, 8-wave lattice through the float32 restatement of Gerstner() "
+               "sample": f"{reps} whole steps of the same 1M-vertex, 8-wave lattice through the float32 restatement of Gerstner() "
                          f"(oracle/gerstner_oracle.c), {el1 * 1e3:.0f} ms per step; host has {os.cpu_count()} cores",
                "all_cores": {"value": nv / eln, "unit": "vertices/s", "cores": bestn,
                              "what": f"the same split over host threads; best of {cands} on the {cores}-core host"}}
+    out = None
     if rank == 0:
         build_id = nat.build_id()
-        traffic, traffic_note = pmc_traffic("pond", B, "k_gerstner", build_id)
-        print(json.dumps({
+        tr = pmc_traffic_ex("pond", Bl, "k_gerstner", build_id)
+        traffic, traffic_note = tr["traffic"], tr["note"]
+        rp = pcts(regions)
+        out = {
             "metric": "pond Gerstner vertices/sec (1M vertices, 8 waves)", "value": world * a.steps * nv / el, "build_id": build_id,
             "unit": "vertices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": R, "timed_ms_total": sum(regions) * 1e3,
+            "region_ms_stats": {k: (round(v * 1e3, 5) if k != "n" else v) for k, v in rp.items()},
             "config": {"workload": "pond: 1000x1000 vertex lattice, 8 Gerstner waves (SURVEY.md 8d config 5), t_k = k/60 s",
-                       "steps_per_launch": B},
-            "roofline": {"bound": "hbm", "kernel": "k_gerstner_steps<8>" if B > 1 else "k_gerstner",
+                       "steps_per_launch": Bl},
+            "roofline": {"bound": "hbm", "kernel": "k_gerstner_steps<8>" if Bl > 1 else "k_gerstner",
                          "achieved": real / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": real / HBM_PEAK, "traffic": traffic,
-                         "traffic_note": traffic_note, "physical_bytes_per_vertex_step": (traffic / (nv * B)) if traffic else None,
+                         "traffic_note": traffic_note, "traffic_scaled_from_b": tr["scaled_from_b"],
+                         "physical_bytes_per_vertex_step": (traffic / (nv * Bl)) if traffic else None,
+                         "real_frac": (traffic / (launch_mean_ms * 1e-3) / HBM_PEAK) if traffic else None,
+                         "bytes_per_launch": bytes_launch, "launch_us": launch_mean_ms * 1e3, "launches_timed": nl,
+                         "launch_us_stats": {k: (v * 1e3 if k != "n" else v) for k, v in lp.items()},
+                         "frac_at_median_launch": bytes_launch / (lp["median"] * 1e-3) / HBM_PEAK,
                          "us_per_step": step_us,
-                         "note": f"one launch of {B} time values moves 12 B/vertex of positions once and 12 B/vertex per step of "
-                                 f"results: (12/{B} + 12) B/vertex/step is what the kernel must and does move"},
-            "parity": parity, "cpu_baseline": cpu}))
+                         "note": f"one launch of {Bl} time values moves 12 B/vertex of positions once and 12 B/vertex per step of "
+                                 f"results: (12/{Bl} + 12) B/vertex/step is what the kernel must move; achieved = that per launch / the mean "
+                                 f"duration of {nl} back-to-back launches (HIP events on the launch stream)"},
+            "parity": parity, "cpu_baseline": cpu}
+    del out_t, pos
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

@@ -229,7 +229,10 @@ int32_t mw_tiles_local_count(const mw_tiles* t); /* tiles this process owns */
 mw_ocean* mw_tiles_ocean(mw_tiles* t, int32_t local_k); /* borrowed handle of a local tile (set_spectrum, set_choppiness, ...) */
 /* nsteps <= max_steps time-steps t[0..nsteps) on every local tile (mw_ocean_evaluate_device per tile, asynchronous) */
 mw_status mw_tiles_evaluate(mw_tiles* t, const float* times, int32_t nsteps, uint32_t flags);
-/* device pointers of local tile k's outputs: [max_steps][N*N*3], [max_steps][N*N*3], [max_steps][N*N*(1|4)] */
+/* device pointers of local tile k's outputs of the LATEST mw_tiles_evaluate: [max_steps][N*N*3], [max_steps][N*N*3],
+ * [max_steps][N*N*(1|4)].  A tile that is gathered owns two such sets used alternately (the gather sends straight from the set
+ * the latest evaluate wrote while the next evaluate fills the other one -- no snapshot copy): ask again after every evaluate
+ * once mw_tiles_gather is in use.  Without gathers the pointers never change.                                              */
 mw_status mw_tiles_outputs(mw_tiles* t, int32_t local_k, void** d_vertices, void** d_normals, void** d_white);
 /* OceanRenderer tiles: one GenerateTexture() (S/OceanRenderer.cs:216) on every local tile, asynchronous; the result textures
  * of local tile k stay in its handle: height [M*M], disp_xz [M*M*2], normal_xyz [M*M*3], white [M*M].                  */

@@ -20,6 +20,12 @@ extern "C" {
 mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, const char** names_out,
                                    int32_t* nkernels);
 
+/* the same measurement as a distribution: stats_out[6 k + 0..5] = mean, median, p10, p90, min, max of kernel k's `iters` launch
+ * durations in milliseconds (bench.py prints the median beside the mean so that roofline.frac can be recomputed from a
+ * rocprofv3 kernel trace of the same command, profiles/<round>_*_kernel_pcts.json)                                          */
+mw_status mw_ocean_profile_kernels_stats(mw_ocean* o, int32_t nsteps, int32_t iters, float* stats_out, const char** names_out,
+                                         int32_t* nkernels);
+
 /* time-steps of one pass-1 column job kept on one XCD when an enqueue carries nsteps time-steps (0 = plain grid) */
 int32_t mw_debug_pass1_time_group(mw_ocean* o, int32_t nsteps);
 

@@ -774,7 +774,11 @@ MW_HD void p2_vertices(const P2Args& A, int ab, int step, int tid, const ST& st)
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
     float* vblk = A.vertices + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;          // block-uniform
+#ifdef MW_ABLATE_SEG_STORES  // timing experiment (wrong results): a wave's store = 4 segments of 16 consecutive points, 64 points apart
+    const unsigned voff = (unsigned)((g * N + (T == 256 ? 64 * ((u >> 4) & 3) + (u & 15) + 16 * (u >> 6) : u)) * 3);
+#else
     const unsigned voff = (unsigned)((g * N + u) * 3);
+#endif
     const float rx = rest_coord(N, A.c.unit_width, a);
 #pragma unroll
     for (int q = 0; q < P; q++) {
@@ -915,7 +919,12 @@ MW_HD void p2_hs_finish_slopes(const P2Args& A, const Twiddles& tw, int ab, int 
     final_stage<N, P, +1>(x, u, tw.TF);
     float* nblk = A.normals + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;  // block-uniform
     float* wblk = A.white + ((size_t)step * N * N + (size_t)ab * R2 * N) * A.white_stride;
+#ifdef MW_ABLATE_SEG_STORES
+    const int us = (T == 256 ? 64 * ((u >> 4) & 3) + (u & 15) + 16 * (u >> 6) : u);
+    const unsigned noff = (unsigned)((g * N + us) * 3), woff = (unsigned)((g * N + us) * A.white_stride);
+#else
     const unsigned noff = (unsigned)((g * N + u) * 3), woff = (unsigned)((g * N + u) * A.white_stride);
+#endif
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int b = u + T * q;

@@ -131,10 +131,23 @@ MW_HD void gerstner_step_vertex(const GerstnerWaves& wv, const GerstnerPhases& p
 template <int NW>
 __global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts,
                                                         GerstnerWaves wv, GerstnerPhases ph, int nsteps, float amplitude,
-                                                        float frequency, float steepness, int steps_per_wg) {
-    const int step_lo = (int)blockIdx.y * steps_per_wg, step_hi = step_lo + steps_per_wg < nsteps ? step_lo + steps_per_wg : nsteps;
+                                                        float frequency, float steepness, int steps_per_wg, int xcd_blocks) {
+    // xcd_blocks > 0 (round 5): 1-D grid; the step groups of ONE vertex chunk sit in consecutive slots of ONE XCD (the dispatcher
+    // places workgroup b on XCD b % 8), so the first of them pulls the chunk's 12 KiB of positions into that XCD's L2 and the others
+    // hit there: the positions cross HBM once per launch instead of once per step group (13.5 -> 12.4 B per vertex-step) while the
+    // workgroups stay short-lived.  xcd_blocks = the number of vertex chunks per trip (what gridDim.x was in the 2-D form).
+    int vb = (int)blockIdx.x, sg = (int)blockIdx.y, nvb = (int)gridDim.x;
+    if (xcd_blocks > 0) {
+        const int ngroups = (nsteps + steps_per_wg - 1) / steps_per_wg;
+        const int xcd = (int)blockIdx.x % 8, slot = (int)blockIdx.x / 8;
+        sg = slot % ngroups;
+        vb = (slot / ngroups) * 8 + xcd;
+        nvb = xcd_blocks;
+        if (vb >= nvb) return;
+    }
+    const int step_lo = sg * steps_per_wg, step_hi = step_lo + steps_per_wg < nsteps ? step_lo + steps_per_wg : nsteps;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t v0 = ((int64_t)blockIdx.x * 4 + wave) * 256; v0 < nverts; v0 += (int64_t)gridDim.x * 1024) {  // wave-uniform chunk of 256 vertices
+    for (int64_t v0 = ((int64_t)vb * 4 + wave) * 256; v0 < nverts; v0 += (int64_t)nvb * 1024) {  // wave-uniform chunk of 256 vertices
         float v[12];
         float sa[4][NW], ca[4][NW];
         bool ok[4];
@@ -185,9 +198,16 @@ static inline hipError_t gerstner_launch_steps(const float* d_pos, int64_t nvert
     if (blocks > 256 * 16) blocks = 256 * 16;
     static const int spw_env = [] { const char* e = std::getenv("MW_POND_STEPS_PER_WG"); return e ? std::atoi(e) : 0; }();
     const int spw = spw_env > 0 ? (spw_env < nsteps ? spw_env : nsteps) : (MW_POND_STEPS_PER_WG < nsteps ? MW_POND_STEPS_PER_WG : nsteps);
-    const dim3 grid((unsigned)blocks, (unsigned)((nsteps + spw - 1) / spw));
-    if (nwaves == 4) k_gerstner_steps<4><<<grid, dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness, spw);
-    else k_gerstner_steps<8><<<grid, dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness, spw);
+#ifndef MW_POND_XCD
+#define MW_POND_XCD 1  // step groups of a vertex chunk on one XCD (environment MW_POND_XCD=0: the 2-D grid of round 4, A/B)
+#endif
+    static const int xcd_env = [] { const char* e = std::getenv("MW_POND_XCD"); return e ? std::atoi(e) : MW_POND_XCD; }();
+    const int ngroups = (nsteps + spw - 1) / spw;
+    const bool xcd = xcd_env != 0 && ngroups > 1;
+    const dim3 grid = xcd ? dim3((unsigned)(((blocks + 7) / 8) * 8 * ngroups)) : dim3((unsigned)blocks, (unsigned)ngroups);
+    const int xb = xcd ? (int)blocks : 0;
+    if (nwaves == 4) k_gerstner_steps<4><<<grid, dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness, spw, xb);
+    else k_gerstner_steps<8><<<grid, dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness, spw, xb);
     return hipGetLastError();
 }
 #endif

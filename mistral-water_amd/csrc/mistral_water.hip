@@ -4,8 +4,9 @@
 // /oracle and is never linked here.
 #include <hip/hip_runtime.h>
 
-#include <dlfcn.h>
+#include <dlfcn.h>  // tiles.inc binds RCCL at run time (dlopen / dlsym)
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -258,6 +259,9 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
 #pragma unroll
             MW_VT(h) stage_store<N, P, +1>(x[h], MW_U(h), MW_BUF(h), tw, s);
             if (s == 1) MW_STAMP(0, 6 + 8 * f);
+#ifdef MW_ABLATE_EXCH1
+            if (s == 1 && N >= MW_ABLATE_EXCH1) { __builtin_amdgcn_sched_barrier(0); continue; }
+#endif
             col_sync(s == p1_mid_passes<N, P>() - 1);
         }
         MW_STAMP(0, 7 + 8 * f);
@@ -531,6 +535,9 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
             if (!in_regs) __syncthreads();
 #pragma unroll
             MW_VT(h) p2_mid_store<N, P, R2>(tw, MW_VTID(h), s, x[h], set0);
+#ifdef MW_ABLATE_EXCH1
+            if (s == 1 && N >= MW_ABLATE_EXCH1) { __builtin_amdgcn_sched_barrier(0); continue; }
+#endif
             if (!in_regs) __syncthreads();
         }
         MW_STAMP(1, 6 + 8 * k);
@@ -594,6 +601,9 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
                 if (g0 == 0) load_slots<N, P>(xq, u, set0, s - 1);
                 if (!in_regs) __syncthreads();
                 if (g0 == 0) { if (in_regs) stage_regs<N, P, +1>(xq, u, tw, s); else stage_store<N, P, +1>(xq, u, set0, tw, s); }
+#ifdef MW_ABLATE_EXCH1
+                if (s == 1 && N >= MW_ABLATE_EXCH1) { __builtin_amdgcn_sched_barrier(0); continue; }
+#endif
                 if (!in_regs) __syncthreads();
             }
             if (g0 == 0) {
@@ -984,6 +994,7 @@ int32_t mw_abi_version(void) { return MW_ABI_VERSION; }
 #define MW_BUILD_TAG "default"
 #endif
 #ifndef MW_BUILD_HASH
+#warning "MW_BUILD_HASH is not defined: build through mistral_water/_native.py::build_native or tools/build_variant.sh (mw_build_id() will say unhashed-build)"
 #define MW_BUILD_HASH "unhashed-build"
 #endif
 const char* mw_build_id(void) { return MW_BUILD_HASH " " MW_BUILD_TAG; }
@@ -1459,8 +1470,30 @@ mw_status mw_ocean_displace_mesh(mw_ocean* o, float* vertices_xyz, float* normal
     return MW_OK;
 }
 
+// per-launch durations -> (mean, median, p10, p90, min, max), milliseconds
+static void launch_stats(std::vector<float>& v, float* out6) {
+    std::sort(v.begin(), v.end());
+    const size_t n = v.size();
+    double acc = 0.0;
+    for (float x : v) acc += x;
+    auto pct = [&](double q) { return v[(size_t)std::min<double>((double)n - 1.0, std::floor(q * (double)(n - 1) + 0.5))]; };
+    out6[0] = (float)(acc / (double)n); out6[1] = pct(0.5); out6[2] = pct(0.1); out6[3] = pct(0.9); out6[4] = v.front(); out6[5] = v.back();
+}
+static mw_status profile_kernels_impl(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, float* stats_out, const char** names_out,
+                                      int32_t* nkernels);
 mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, const char** names_out,
                                    int32_t* nkernels) {
+    if (!ms_out) return fail(MW_EINVAL, "mw_ocean_profile_kernels: bad argument");
+    return profile_kernels_impl(o, nsteps, iters, ms_out, nullptr, names_out, nkernels);
+}
+mw_status mw_ocean_profile_kernels_stats(mw_ocean* o, int32_t nsteps, int32_t iters, float* stats_out, const char** names_out,
+                                         int32_t* nkernels) {
+    if (!stats_out) return fail(MW_EINVAL, "mw_ocean_profile_kernels_stats: bad argument");
+    float ms[4] = {0.f, 0.f, 0.f, 0.f};
+    return profile_kernels_impl(o, nsteps, iters, ms, stats_out, names_out, nkernels);
+}
+static mw_status profile_kernels_impl(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, float* stats_out, const char** names_out,
+                                      int32_t* nkernels) {
     if (!o || !ms_out || !nkernels || iters < 1) return fail(MW_EINVAL, "mw_ocean_profile_kernels: bad argument");
     if (o->sem != MW_SEM_FFTMESH) return fail(MW_ESTATE, "mw_ocean_profile_kernels: FFTMesh semantics only");
     if (nsteps < 1 || nsteps > MW_MAX_BATCH) return fail(MW_EINVAL, "nsteps out of range");
@@ -1477,6 +1510,7 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
         for (int w = 0; w < 5 && he == hipSuccess; w++)
             he = direct_evaluate(o->direct, consts_of(o), o->h0, o->h0c, 1.0f, o->s_vert, o->s_norm, o->s_white, 1, o->stream);
         double acc[2] = {0.0, 0.0};
+        std::vector<float> per[2];
         for (int it = 0; it < iters && he == hipSuccess; it++) {
             he = direct_evaluate(o->direct, consts_of(o), o->h0, o->h0c, 1.0f + (float)it / 60.f, o->s_vert, o->s_norm, o->s_white, 1, o->stream, ev);
             hipEventRecord(ev[3], o->stream);
@@ -1487,10 +1521,16 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
             hipEventElapsedTime(&b, ev[2], ev[3]);
             acc[0] += g;
             acc[1] += a + b;
+            per[0].push_back(g);
+            per[1].push_back(a + b);
         }
         for (auto& e : ev) hipEventDestroy(e);
         if (he != hipSuccess) return fail(MW_EDEVICE, std::string("direct-sum profile: ") + hipGetErrorString(he));
-        for (int k = 0; k < 2; k++) { ms_out[k] = (float)(acc[k] / iters); if (names_out) names_out[k] = dnames[k]; }
+        for (int k = 0; k < 2; k++) {
+            ms_out[k] = (float)(acc[k] / iters);
+            if (names_out) names_out[k] = dnames[k];
+            if (stats_out) launch_stats(per[k], stats_out + 6 * k);
+        }
         *nkernels = 2;
         return MW_OK;
     }
@@ -1533,16 +1573,20 @@ mw_status mw_ocean_profile_kernels(mw_ocean* o, int32_t nsteps, int32_t iters, f
     }
     hipEventSynchronize(ev[2 * iters]);
     double acc[2] = {0.0, 0.0};
+    std::vector<float> per[2];
     for (int it = 0; it < iters && s == MW_OK; it++) {
         float m1 = 0.f, m2 = 0.f;
         hipEventElapsedTime(&m1, ev[2 * it], ev[2 * it + 1]);
         hipEventElapsedTime(&m2, ev[2 * it + 1], ev[2 * it + 2]);
         acc[0] += m1;
         acc[1] += m2;
+        per[0].push_back(m1);
+        per[1].push_back(m2);
     }
     for (int k = 0; k < 2; k++) {
         ms_out[k] = (float)(acc[k] / iters);
         if (names_out) names_out[k] = names[k];
+        if (stats_out && s == MW_OK) launch_stats(per[k], stats_out + 6 * k);
     }
     for (auto& e : ev) hipEventDestroy(e);
     if (nsteps != 1) { hipFree(dv); hipFree(dn); hipFree(dw); }

@@ -164,6 +164,7 @@ def lib():
         "mw_ocean_displace_mesh": (C.c_int, [vp, f32p, f32p, f32p]),
         "mw_ocean_displace_mesh_device": (C.c_int, [vp, vp, vp, vp]),
         "mw_ocean_profile_kernels": (C.c_int, [vp, C.c_int32, C.c_int32, f32p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
+        "mw_ocean_profile_kernels_stats": (C.c_int, [vp, C.c_int32, C.c_int32, f32p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32)]),
         "mw_gerstner_displace": (C.c_int, [f32p, C.c_int64, f32p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                            f32p, C.c_int32]),
         "mw_gerstner_displace_device": (C.c_int, [vp, C.c_int64, f32p, C.c_int32, C.c_float, C.c_float, C.c_float,
@@ -207,7 +208,7 @@ ABI_SYMBOLS = [
     "mw_gerstner_displace_device", "mw_gerstner_displace_steps_device", "mw_gerstner_max_steps", "mw_pond_displace", "mw_pond_displace_device",
 ]
 #: measurement and test hooks (include/mistral_water_hooks.h): exported, but not part of the drop-in boundary
-HOOK_SYMBOLS = ["mw_ocean_profile_kernels", "mw_debug_pass1_time_group", "mw_debug_omega_t", "mw_debug_evaluate_hds", "mw_debug_get_omega", "mw_debug_sincos",
+HOOK_SYMBOLS = ["mw_ocean_profile_kernels", "mw_ocean_profile_kernels_stats", "mw_debug_pass1_time_group", "mw_debug_omega_t", "mw_debug_evaluate_hds", "mw_debug_get_omega", "mw_debug_sincos",
                 "mw_debug_sincos_fast", "mw_debug_stream_read"]
 
 

@@ -185,6 +185,15 @@ class Ocean:
         nat.check(nat.lib().mw_ocean_profile_kernels(self._h, nsteps, iters, ms, names, C.byref(nk)))
         return [(names[k].decode(), float(ms[k])) for k in range(nk.value)]
 
+    def profile_kernels_stats(self, nsteps: int = 1, iters: int = 20):
+        """[(kernel name, {mean, median, p10, p90, min, max} in ms)] over `iters` launches (mw_ocean_profile_kernels_stats)."""
+        st = (C.c_float * 48)()
+        names = (C.c_char_p * 8)()
+        nk = C.c_int32(0)
+        nat.check(nat.lib().mw_ocean_profile_kernels_stats(self._h, nsteps, iters, st, names, C.byref(nk)))
+        keys = ("mean", "median", "p10", "p90", "min", "max")
+        return [(names[k].decode(), {kk: float(st[6 * k + i]) for i, kk in enumerate(keys)}) for k in range(nk.value)]
+
     def debug_evaluate_hds(self, t: float):
         """EvaluateWaves(t) plus hds [N*N, 2] exactly as the kernels hold it (test hook of the whitecap stage)."""
         NN = self.N * self.N

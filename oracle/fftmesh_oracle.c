@@ -87,6 +87,13 @@ float orc_dispersion(const orc_params* p, int n, int m) {
     return mf_floor(mf_sqrt(p->gravity * mf_sqrt(s)) / w) * w;
 }
 
+/* Dispersion(n,m) * t over the whole grid, out[n * N + m] -- the argument of :184-185 exactly as htilde() forms it (:183, one
+ * float32 product).  The GPU tests compare the device's omega*t with THIS over every grid point (index work: bit for bit).   */
+void orc_dispersion_grid(const orc_params* p, float t, float* out) {
+    for (int n = 0; n < p->N; n++)
+        for (int m = 0; m < p->N; m++) out[(size_t)n * p->N + m] = orc_dispersion(p, n, m) * t; /* :183 */
+}
+
 /* ---- S/FFTMesh.cs:149-166  Phillips(n,m) ---------------------------------------------- */
 float orc_phillips(const orc_params* p, int n, int m) {
     float kx = (float)(2 * n - p->N) / p->length * ORC_PI_F; /* :151 */

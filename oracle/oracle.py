@@ -87,6 +87,15 @@ def dispersion(p: Params, n: int, m: int) -> float:
     return lib().orc_dispersion(C.byref(p.c()), n, m)
 
 
+def dispersion_grid(p: Params, t: float):
+    """omega(n, m) * t over the whole grid [N, N] in the reference's strict float32 sequence (S/FFTMesh.cs:141-147, :183)."""
+    out = np.empty((p.N, p.N), np.float32)
+    lib().orc_dispersion_grid.restype = None
+    lib().orc_dispersion_grid.argtypes = [C.POINTER(_P), C.c_float, C.c_void_p]
+    lib().orc_dispersion_grid(C.byref(p.c()), C.c_float(t), _fp(out))
+    return out
+
+
 def phillips(p: Params, n: int, m: int) -> float:
     return lib().orc_phillips(C.byref(p.c()), n, m)
 

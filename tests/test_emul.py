@@ -40,6 +40,10 @@ def test_omega_t_bit_exact(emul, oracle):
         want = np.array([[np.float32(oracle.dispersion(p, i, j)) * np.float32(t) for j in range(N)] for i in range(N)],
                         np.float32)
         assert (got == want).all()
+        assert (oracle.dispersion_grid(p, t) == want).all()      # the grid entry point == the scalar one
+    # the whole grid at the bench's sizes and literal parameters (the kernels' omega_f32 on the host vs the oracle's restatement)
+    for p, t in [(workloads.fftmesh_config2(1024), 1.0), (workloads.fftmesh_params(2048), 3600.0), (workloads.fftmesh_config2(4096), 20.0 / 60.0)]:
+        assert (emul.omega_t(p, t) == oracle.dispersion_grid(p, t)).all(), p.N
 
 
 def test_rest_mesh_bit_exact(emul, oracle):

@@ -176,17 +176,23 @@ def test_fftmesh_large_grids(mw, oracle, N):
 
 
 def test_omega_t_bit_exact_on_device(mw, oracle, emul):
-    # the quantised dispersion floor() and the omega*t product are "index work": bit for bit over the WHOLE grid
-    # (S/FFTMesh.cs:146,183).  emul.omega_t is the same strict-f32 code on the host; spot rows pin it to the oracle.
-    for N, t in [(64, 1.0), (256, 16.65), (1024, 7.3), (4096, 2.5)]:
-        p = workloads.fftmesh_params(N)
+    # the quantised dispersion floor() and the omega*t product are "index work": bit for bit over the WHOLE grid against the ORACLE's
+    # restatement of S/FFTMesh.cs:141-147,183 (orc_dispersion_grid) -- not only against the host build of the kernels' own source
+    # (emul.omega_t), which a shared transcription error in omega_f32 would pass.  Also at the bench's literal
+    # config-2 / config-4 parameters (length = N) and with a gravity / length that is not a power of two.
+    cases = [(workloads.fftmesh_params(N), t) for N, t in [(64, 1.0), (128, 0.37), (256, 16.65), (512, 3600.0), (1024, 7.3), (2048, 1.0 / 60.0), (4096, 2.5)]]
+    cases += [(workloads.fftmesh_config2(1024), 1.0), (workloads.fftmesh_config2(4096), 20.0 / 60.0)]
+    cases += [(oracle.Params(N=256, unit_width=1.7, length=435.2, wind_x=3, wind_y=4, amplitude=0.01, gravity=3.711), 11.5)]
+    for p, t in cases:
+        N = p.N
         with make(mw, p) as o:
             got = o.debug_omega_t(t)
-        want = emul.omega_t(p, t)
-        assert (got == want).all(), f"N={N}: {(got != want).sum()} of {N * N} omega*t values differ"
-        for i in (0, 1, N // 2, N - 1):
-            row = np.array([oracle.dispersion(p, i, j) for j in range(N)], np.float32) * np.float32(t)
-            assert (want[i] == row).all()
+        want = oracle.dispersion_grid(p, t)
+        assert (got == want).all(), f"N={N}: {(got != want).sum()} of {N * N} omega*t values differ from the oracle"
+        assert (emul.omega_t(p, t) == want).all()      # the emulation's copy is pinned by the same table
+        for i in (0, N // 2, N - 1):                    # and the grid form by the scalar entry point the anchor tests use
+            row = np.array([oracle.dispersion(p, i, j) for j in (0, 1, N // 2, N - 1)], np.float32) * np.float32(t)
+            assert (want[i, [0, 1, N // 2, N - 1]] == row).all()
 
 
 def test_rest_mesh_bit_exact_on_device(mw, oracle):
@@ -314,6 +320,34 @@ def test_batched_device_steps_equal_single_steps(mw, oracle):
                 if k not in singles:
                     singles[k] = o.evaluate(tt[k])
                 assert (hv[k] == singles[k][0]).all() and (hw[k] == singles[k][2][:, 0]).all(), (ns, k)
+
+
+@pytest.mark.parametrize("N,K", [(1024, 20), (4096, 32)])
+def test_batched_enqueue_at_the_timed_shapes_vs_oracle(mw, oracle, N, K):
+    """The shapes bench.py times -- 1024^2 in ONE 20-step enqueue (pass-1 time group 5), 4096^2 in 32-step enqueues (group 8) -- on the
+    literal config-2 / config-4 sea: steps 0, mid and last of the batch against the f64 oracle (eval_fft_f64) at the stated tolerance,
+    and against the same step evaluated alone, bit for bit (only step 0 went through the bench's gate)."""
+    import torch
+    p = workloads.fftmesh_config2(N)
+    NN = N * N
+    times = [(k + 1) / 60.0 for k in range(K)]
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p, seed=1) as o:
+        h0, h0c = o.get_spectrum()
+        dv = torch.empty((K, NN, 3), dtype=torch.float32, device="cuda")
+        dn = torch.empty((K, NN, 3), dtype=torch.float32, device="cuda")
+        dw = torch.empty((K, NN), dtype=torch.float32, device="cuda")
+        o.evaluate_device(times, dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+        o.synchronize()
+        for k in (0, K // 2, K - 1):
+            v, n, w = dv[k].cpu().numpy(), dn[k].cpu().numpy(), dw[k].cpu().numpy()
+            vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, np.float32(times[k]), return_hds=True)
+            workloads.assert_parity(v, n, w[:, None], vf, nf, cf[:, :1], rest, np.abs(hds).max(), tag=f"N={N} step {k} of {K}", hds=hds)
+            del vf, nf, cf, hds
+            v1, n1, c1 = o.evaluate(times[k])
+            assert (v == v1).all() and (n == n1).all() and (w == c1[:, 0]).all(), (N, k)
+        del dv, dn, dw
+    torch.cuda.empty_cache()
 
 
 def test_update_lifecycle_matches_fftmesh_update(mw, oracle):

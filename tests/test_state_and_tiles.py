@@ -219,6 +219,48 @@ def test_tiles_evaluate_and_rccl_gather(mw, ntiles):
     assert e.value.status == mw.MW_EINVAL
 
 
+def test_gather_sends_from_alternating_output_sets_without_a_snapshot(mw):
+    """Round 5: a gathered FFTMesh tile owns two output sets.  The gather reads the set the latest evaluate wrote (no copy on the compute
+    stream), the next evaluate fills the other one, and an evaluate that comes back to a set waits for the sends that read it: six
+    batches with a gather each, never synchronised in between -- every gathered step must be its own batch's, bit for bit."""
+    p = workloads.fftmesh_params(256)
+    NN = 256 * 256
+    kw = dict(resolution=p.N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude,
+              choppiness=p.choppiness)
+    ntiles, B = 2, 4
+    with mw.Tiles(ntiles=ntiles, devices=[0] * ntiles, max_steps=B, seed=3, **kw) as t:
+        seen = []
+        for b in range(6):
+            times = [0.25 * (b * B + k + 1) for k in range(B)]
+            t.evaluate(times)
+            seen.append(t.outputs(0)[0])
+            t.gather(step=B - 1, root=0)
+            t.gather(step=B - 1, root=0)      # a second gather of the same batch reads the same set
+        assert seen[0] == seen[2] == seen[4] and seen[1] == seen[3] == seen[5] and seen[0] != seen[1]
+        t.synchronize()
+        ptr, fpt = t.gathered()
+        got = _d2h(ptr, ntiles * fpt).reshape(ntiles, fpt)
+        t_last = 0.25 * (5 * B + B)
+        for k in range(ntiles):
+            with mw.Ocean(seed=3 + k, **kw) as o:
+                v, n, c = o.evaluate(t_last)
+            assert (got[k, :NN * 3].reshape(NN, 3) == v).all() and (got[k, NN * 6:] == c[:, 0]).all(), k
+            dv, dn, dw = t.outputs(k)
+            assert (_d2h(dv, B * NN * 3).reshape(B, NN, 3)[B - 1] == v).all()
+        # a gather between two evaluates that is NOT synchronised must still deliver the FIRST batch: gather, overwrite-attempt, check
+        t.evaluate([1.0] * B)
+        t.gather(step=0, root=0)
+        t.evaluate([2.0] * B)                  # goes to the other set while the sends read the first one
+        t.evaluate([3.0] * B)                  # ... and this one to the same other set again (no gather in between)
+        t.synchronize()
+        got = _d2h(t.gathered()[0], ntiles * fpt).reshape(ntiles, fpt)
+        with mw.Ocean(seed=3, **kw) as o:
+            v1 = o.evaluate(1.0)[0]
+            v3 = o.evaluate(3.0)[0]
+        assert (got[0, :NN * 3].reshape(NN, 3) == v1).all()
+        assert (_d2h(t.outputs(0)[0], NN * 3).reshape(NN, 3) == v3).all()
+
+
 def test_baseline_config3_eight_1024_tiles_gathered_on_one_device(mw):
     """BASELINE.json configs[2] as far as ONE device allows: 8 independent 1024^2 tiles (config 2's literal
     parameters, seeds 1..8) created through mw_tiles_create -- all on device 0 here, one per GPU on the 8-GPU node -- a batch of
@@ -423,11 +465,13 @@ def test_oceanrenderer_tiles_and_rccl_gather(mw, ntiles):
         o.close()
 
 
-def test_tiles_on_two_devices_restore_the_callers_device(mw):
-    """Real multi-device gather (skipped on the 1-GPU box): one tile per device, root = the second device; every tile equals
-    Ocean(seed + k) bit for bit, and the entry points put the caller's current HIP device back."""
-    if mw.lib().mw_device_count() < 2:
-        pytest.skip("needs two devices")
+@pytest.mark.parametrize("ndev", [2, 4, 8])
+def test_tiles_on_two_devices_restore_the_callers_device(mw, ndev):
+    """Real multi-device gather (skipped where fewer devices are visible: the 1-GPU box skips all three): one tile per device on the
+    first `ndev` devices, root = the LAST device; every tile equals Ocean(seed + k) on its own device bit for bit, two batches with
+    a gather each (the alternating output sets across xGMI), and the entry points put the caller's current HIP device back."""
+    if mw.lib().mw_device_count() < ndev:
+        pytest.skip(f"needs {ndev} devices")
     hip = C.CDLL("libamdhip64.so")
     p = workloads.fftmesh_params(128)
     NN = 128 * 128
@@ -435,16 +479,19 @@ def test_tiles_on_two_devices_restore_the_callers_device(mw):
               choppiness=p.choppiness)
     dev = C.c_int(-1)
     assert hip.hipSetDevice(0) == 0
-    with mw.Tiles(ntiles=2, devices=[0, 1], max_steps=2, seed=11, **kw) as t:
-        t.evaluate([0.5, 1.5])
-        t.gather(step=1, root=1)
+    root = ndev - 1
+    with mw.Tiles(ntiles=ndev, devices=list(range(ndev)), max_steps=2, seed=11, **kw) as t:
+        t.evaluate([0.25, 0.75])
+        t.gather(step=0, root=root)
+        t.evaluate([0.5, 1.5])                 # the other output set of every tile, while the first gather travels
+        t.gather(step=1, root=root)
         t.synchronize()
         assert hip.hipGetDevice(C.byref(dev)) == 0 and dev.value == 0
         ptr, fpt = t.gathered()
-        assert hip.hipSetDevice(1) == 0
-        got = _d2h(ptr, 2 * fpt).reshape(2, fpt)
+        assert hip.hipSetDevice(root) == 0
+        got = _d2h(ptr, ndev * fpt).reshape(ndev, fpt)
         assert hip.hipSetDevice(0) == 0
-    for k in range(2):
+    for k in range(ndev):
         with mw.Ocean(seed=11 + k, device=k, **kw) as o:
             v, n, c = o.evaluate(1.5)
         assert (got[k, :NN * 3].reshape(NN, 3) == v).all() and (got[k, NN * 6:] == c[:, 0]).all(), k
@@ -478,8 +525,9 @@ def test_bench_two_rank_control_flow_on_one_device():
     """The N > 1 control flow of bench.py as the driver launches it (torch.distributed.run, 2 processes), on the 1-GPU box:
     gloo carries barriers / reductions, both ranks drive cuda:0 (an RCCL communicator cannot hold one device twice, so the
     tile API agrees on its fallback and says so).  Rank 0 alone prints; value is the whole-job aggregate over MAX-of-ranks time."""
-    d = _run_bench(["--steps", "64", "--warmup", "32", "--no-cpu-baseline", "--preheat-ms", "20"],
+    d = _run_bench(["--steps", "64", "--warmup", "32", "--no-cpu-baseline", "--preheat-ms", "20"],      # the default workload: N > 1 carries the headline only
                    {"MW_BENCH_BACKEND": "gloo", "MW_BENCH_SAME_DEVICE": "1"}, nproc=2)
+    assert d["configs"] is None
     NN = 1024 * 1024
     assert d["n_gpus"] == 2 and d["steps"] == 64 and d["scaling"] == "weak" and d["config"]["tiles"] == 2
     assert d["config"]["steps_per_enqueue"] == 32 and d["config"]["enqueues_per_region"] == 2 and d["config"]["enqueues_timed"] == 2 * d["repeats"] and d["config"]["pass1_time_group"] == 8
@@ -497,8 +545,11 @@ def test_bench_two_rank_control_flow_on_one_device():
 def test_bench_times_what_it_prints_and_gates_the_tile_path():
     """The driver's command line (--steps 20 --warmup 5): ONE 20-step enqueue, pass-1 time group 5, roofline from 20-step
     launches, literal config-2 parameters, frame-at-a-time figures present; and the tile-API path keeps the parity gate."""
-    d = _run_bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline"], {})
+    d = _run_bench(["--workload", "ocean1024", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], {})
     c = d["config"]
+    assert d["repeats"] >= 5 and d["timed_ms_total"] >= 50.0 and d["region_ms_stats"]["n"] == d["repeats"]     # >= --min-timed-ms of timed work whatever K
+    st = d["roofline"]["launch_us_stats"]
+    assert st["p10"] <= st["median"] <= st["p90"] and abs(st["mean"] - d["roofline"]["launch_us"]) < 1e-3 * st["mean"]
     assert c["steps_per_enqueue"] == 20 and c["enqueues_per_region"] == 1 and c["enqueues_timed"] >= 5 and c["enqueue_sizes_timed"] == [20] and c["pass1_time_group"] == 5
     assert d["roofline"]["steps_per_launch"] == 20 and d["roofline"]["bytes_per_launch"] == 52 * 1024 * 1024 * 20
     assert "amplitude 0.41" in c["workload"] and d["parity"].startswith("ok")
@@ -506,5 +557,20 @@ def test_bench_times_what_it_prints_and_gates_the_tile_path():
     f = d["frame_at_a_time"]
     assert f["device_us_per_step"] > 0 and 0 < f["host_ms_per_frame_registered"] <= f["host_ms_per_frame_pageable"] * 2.0   # PCIe-bound either way
     assert d["single_step_us"] == f["device_us_per_step"]
-    t = _run_bench(["--steps", "32", "--warmup", "32", "--no-cpu-baseline"], {"MW_BENCH_FORCE_TILES": "1"})
+    t = _run_bench(["--workload", "ocean1024", "--steps", "32", "--warmup", "32", "--no-cpu-baseline"], {"MW_BENCH_FORCE_TILES": "1"})
     assert t["config"]["api"].startswith("mw_tiles_") and "through mw_tiles_" in t["parity"]
+
+
+def test_default_bench_line_carries_every_single_gpu_baseline_config():
+    """the driver's command line prints ONE line whose headline is the 1024^2 config and whose `configs` object holds
+    BASELINE configs[3] (4096^2) and configs[4] (the pond), each with its own parity gate, roofline object and bounded CPU baseline."""
+    d = _run_bench(["--steps", "20", "--warmup", "5"], {}, timeout=900)
+    assert d["config"]["grid"] == 1024 and d["parity"].startswith("ok") and d["cpu_baseline"]["value"] > 0
+    o, p = d["configs"]["ocean4096"], d["configs"]["pond"]
+    assert "error" not in o and "error" not in p, (o.get("error"), p.get("error"))
+    assert o["config"]["grid"] == 4096 and o["steps"] == 64 and o["config"]["steps_per_enqueue"] == 32 and o["parity"].startswith("ok")
+    assert o["roofline"]["bytes_per_launch"] == 52 * 4096 * 4096 * 32 and 0.2 < o["roofline"]["frac"] < 1.0
+    assert o["cpu_baseline"]["kind"] == "port" and o["cpu_baseline"]["value"] > 0 and o["timed_ms_total"] >= 50.0
+    assert p["unit"] == "vertices/s" and p["parity"].startswith("ok") and 0.2 < p["roofline"]["frac"] < 1.0
+    assert p["cpu_baseline"]["value"] > 0 and p["timed_ms_total"] >= 50.0 and p["config"]["steps_per_launch"] == 32
+    assert d["configs_wall_s"] < 150.0

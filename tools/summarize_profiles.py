@@ -1,11 +1,40 @@
-"""Condenses a tools/profile_r1.sh output directory into the small files committed under profiles/.
-usage: python tools/summarize_profiles.py gpurun_out/prof_<tag> profiles/<name>"""
+"""Condenses a tools/prof_workload.sh output directory into the small files committed under profiles/.
+usage: python tools/summarize_profiles.py gpurun_out/prof_<tag> profiles/<name>
+  <name>_kernel_stats.csv   rocprofv3's own --stats table (means over EVERY launch, clock-ramp and 1-step launches included)
+  <name>_kernel_pcts.json   per kernel, from the kernel trace: the full-size launches in time order, the first quarter dropped as
+                            warm-up (bench.py's preheat + warm-up steps run at ramping clocks), then mean / median / p10 / p90 / min /
+                            max -- what bench.py's roofline.launch_us(_stats) of the same command should reproduce
+  <name>_pmc.json           counter means per full-size launch + the bench line of the traced run"""
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), dst + "_kernel_stats.csv")
+# ---- percentiles per kernel from the per-dispatch trace -------------------------------------------------------------------
+def _pcts(v):
+    v = sorted(v)
+    n = len(v)
+    q = lambda f: v[min(n - 1, int(round(f * (n - 1))))]
+    return {"n": n, "mean_us": sum(v) / n / 1e3, "median_us": q(0.5) / 1e3, "p10_us": q(0.1) / 1e3, "p90_us": q(0.9) / 1e3,
+            "min_us": v[0] / 1e3, "max_us": v[-1] / 1e3}
+trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
+per = defaultdict(list)
+for f in trace:
+    for row in csv.DictReader(open(f)):
+        per[row["Kernel_Name"].split("(")[0]].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+kp = {}
+for k, rows in per.items():
+    if len(rows) < 8:
+        continue
+    rows.sort()
+    durs = [d for _, d in rows]
+    big = [d for d in durs if d >= 0.5 * max(durs)]           # the full-batch launches (bench.py also issues 1-step launches)
+    steady = big[len(big) // 4:]                               # time order: the first quarter = preheat + warm-up at ramping clocks
+    kp[k] = {"all_full_size_launches": _pcts(big), "after_warmup": _pcts(steady),
+             "note": "after_warmup = the full-size launches in time order with the first 25 % dropped"}
+if kp:
+    json.dump({"source": src, "kernels": kp}, open(dst + "_kernel_pcts.json", "w"), indent=1)
 bench_line = [l for l in open(os.path.join(src, "bench_stdout.txt")) if l.startswith("{")]
 pmc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
