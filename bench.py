@@ -838,7 +838,40 @@ def direct(a, e):
                     "note": "achieved = 92 B x N^2 / the mean duration of one step's three launches (HIP events on the launch stream).  Small "
                             "grids are launch-latency-bound (N = 50: three launches of a few workgroups), and up to N ~ 1500 the whole working "
                             "set sits in the 256-MiB Infinity Cache: the fraction says how far one step is from streaming at HBM rate"}
-            path = f"chirp-z: two Stockham transforms of size {1 << max(6, (2 * N - 2).bit_length())} per line and axis (k_czt x 2)"
+            # What DOES bound k_czt: its transform work, priced against the VALU and the LDS.  Per line of one axis: two
+            # Stockham transforms of size M (5 M log2 M flop each), the kernel product and the two chirps (6 flop per complex product);
+            # every radix pass but the last-in-registers one crosses LDS once (8 B written + 8 B read per point) and reads (P - 1) / P
+            # twiddles per point from the LDS table.  Lines: 3 packed planes x (N + 1 along j, then N along i).
+            M = 64
+            while M < 2 * N:
+                M *= 2
+            Pz = 16 if M >= 256 else 8
+            S_full, m = 0, 1
+            while m * Pz <= M:
+                m *= Pz
+                S_full += 1
+            RLz = M // m
+            n_exch = S_full if RLz > 1 else S_full - 1            # exchanges per transform (the last radix-P pass of M = P^S stays in registers)
+            n_pass = S_full + (1 if RLz > 1 else 0)
+            lines = 3 * (2 * N + 1)
+            flop_line = 2 * 5.0 * M * np.log2(M) + 6.0 * M + 6.0 * (2 * N + 1)
+            lds_line = 2 * (n_exch * 16.0 * M + (n_pass - 1) * 8.0 * M * (Pz - 1) / Pz)
+            valu_peak, lds_peak = MFMA_F32_PEAK, 256 * 128 * 2.4e9   # f32 vector rate (FMA = 2 flop); 128 B/clk/CU x 256 CUs x 2.4 GHz
+            b_valu, b_lds, b_hbm = lines * flop_line / valu_peak, lines * lds_line / lds_peak, bpp * NN / HBM_PEAK
+            k_czt_s = kern[0][1] * 1e-3
+            binding = max((b_valu, "valu"), (b_lds, "lds"), (b_hbm, "hbm"))
+            roof["transform_bounds"] = {
+                "transform_size": M, "points_per_thread": Pz, "lds_exchanges_per_transform": n_exch, "lines_per_step": lines,
+                "flop_per_step": lines * flop_line, "lds_bytes_per_step": lines * lds_line,
+                "valu_bound_us": b_valu * 1e6, "lds_bound_us": b_lds * 1e6, "hbm_bound_us": b_hbm * 1e6,
+                "valu_peak_TFLOPs": valu_peak / 1e12, "lds_peak_TBps": lds_peak / 1e12,
+                "binding": binding[1], "k_czt_us": k_czt_s * 1e6,
+                "k_czt_frac_of_binding_bound": binding[0] / k_czt_s, "step_frac_of_binding_bound": binding[0] / (step_ms * 1e-3),
+                "achieved_TFLOPs": lines * flop_line / k_czt_s / 1e12, "achieved_lds_TBps": lines * lds_line / k_czt_s / 1e12,
+                "note": "lower bounds of one step from its transform work: flop at the f32 vector peak (every op priced as if fused), LDS bytes "
+                        "(exchanges + table twiddles) at the aggregate LDS rate, 92 B per point at the HBM peak.  The achieved fractions say how "
+                        "far the two k_czt launches are from the binding one; small grids are launch-bound (a few workgroups per launch)"}
+            path = f"chirp-z: two Stockham transforms of size {M} per line and axis (k_czt x 2)"
         else:
             roof = {"bound": "mfma", "kernel": "k_gemm_f32_mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
                     "unit": "TFLOP/s", "frac": flops / (gemm_ms * 1e-3) / MFMA_F32_PEAK, "traffic": None,

@@ -41,6 +41,10 @@ mw_status mw_debug_get_omega(mw_ocean* o, float* out_host);
 mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host);
 /* the pond kernels' hardware-sine variant (v_sin_f32 / v_cos_f32 after an exact revolution count) */
 mw_status mw_debug_sincos_fast(const float* x_host, int32_t n, float* s_host, float* c_host);
+/* one wave applies the in-wave exchange of the 1024-point transform (v_permlane16_swap / v_permlane32_swap: the wave's four 16-lane rows
+ * <-> the low two bits of the slot index) to inout_host [64 lanes][16 slots][2]: the instructions are checked against the index map the
+ * host emulation uses (index work: bit for bit)                                                                                      */
+mw_status mw_debug_wave_transpose4(float* inout_host);
 /* streams `bytes` of device memory through `width`-byte per-lane loads (4, 8 or 16): FETCH_SIZE calibration */
 mw_status mw_debug_stream_read(int64_t bytes, int32_t width, int32_t iters);
 

@@ -700,14 +700,15 @@ template <int N, int P, int R2>
 MW_HD void p2_mid_store(const Twiddles& tw, int tid, int s, cf (&x)[P], cf* lds) {
     int r1, u1;
     p2_mid_map<N, P, R2>(tid, &r1, &u1);
-    if (LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1) stage_regs<N, P, +1>(x, u1, tw, s);  // stays in registers: p2_last_load reads nothing
+    if (LastStays<N, P>::value && s == FftGeom<N, P>::S - 1) stage_last_regs<N, P, +1>(x, u1, tw, s);  // stays in registers (or moves inside the wave): p2_last_load reads nothing
     else stage_store<N, P, +1>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE, tw, s);
 }
 // input of the final pass in the row-major mapping: the last exchange, unless the last radix-P pass left it in registers (LastInRegs:
 // the middle passes of an exact layout run in the same row-major mapping, p2_mid_map)
 template <int N, int P>
 MW_HD void p2_last_load(cf (&x)[P], int u, const cf* buf) {
-    if (!LastInRegs<N, P>::value) load_last<N, P>(x, u, buf);
+    if (LastStays<N, P>::value) load_last_regs<N, P>(x);
+    else load_last<N, P>(x, u, buf);
 }
 
 // final pass in the row-major mapping (thread (g,u) owns row a0+g, columns b = u + T q)

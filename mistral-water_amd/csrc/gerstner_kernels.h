@@ -93,6 +93,9 @@ __global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos,
 // from the host in the kernel arguments), joined by the angle-addition formulas: 7 FMAs per vertex, wave and step instead
 // of a sincos.  The positions are read once per launch; per step only the 12-B result leaves.
 #define MW_GERSTNER_PHASES 256  // nsteps * nwaves per launch (2 KiB of kernel arguments)
+#ifndef MW_POND_PACKED
+#define MW_POND_PACKED 1  // two vertices of a lane per v_pk_* instruction in k_gerstner_steps (A/B: -DMW_POND_PACKED=0)
+#endif
 #ifndef MW_POND_STEPS_PER_WG
 #define MW_POND_STEPS_PER_WG 8  // time values per workgroup of k_gerstner_steps (environment MW_POND_STEPS_PER_WG overrides: A/B)
 #endif
@@ -104,20 +107,23 @@ MW_HD void gerstner_position_part(const GerstnerWaves& wv, float frequency, floa
 #pragma unroll
     for (int i = 0; i < NW; i++) mw_sincos_fast(frequency * (wv.dx[i] * px + wv.dy[i] * pz), &sa[i], &ca[i]);
 }
-template <int NW>
+// V = float (one vertex; the host emulation and the scalar tails) or a 2-float vector (two vertices of a lane at once: the device kernel
+// -- the same expression then compiles to v_pk_mul_f32 / v_pk_fma_f32 with the uniform cb, sb broadcast, half the VALU instructions;
+// round 5: the launch was VALU-co-limited, ~60 instructions per vertex-step against 12 B stored)
+template <int NW, class V>
 MW_HD void gerstner_step_vertex(const GerstnerWaves& wv, const GerstnerPhases& ph, int step, float amplitude, float steepness,
-                                const float (&sa)[NW], const float (&ca)[NW], float px, float py, float pz, float* o) {
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+                                const V (&sa)[NW], const V (&ca)[NW], V px, V py, V pz, V* o) {
+    V sx = px * 0.f, sy = sx, sz = sx;
     const float sam = steepness * amplitude;
 #pragma unroll
     for (int i = 0; i < NW; i++) {
         const float cb = ph.cb[step * NW + i], sb = ph.sb[step * NW + i];
-        const float c = ca[i] * cb - sa[i] * sb, s = sa[i] * cb + ca[i] * sb;  // cos/sin(theta_i)
+        const V c = ca[i] * cb - sa[i] * sb, s = sa[i] * cb + ca[i] * sb;  // cos/sin(theta_i)
         sx += c * (sam * wv.dx[i]);
         sz += c * (sam * wv.dy[i]);
         sy += s;
     }
-    o[0] = px + sx; o[1] = py + amplitude * sy; o[2] = pz + sz;
+    o[0] = px + sx; o[1] = py + sy * amplitude; o[2] = pz + sz;
 }
 
 #if defined(__HIPCC__)
@@ -159,17 +165,43 @@ __global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict_
             v[3 * k] = p[0]; v[3 * k + 1] = p[1]; v[3 * k + 2] = p[2];
             gerstner_position_part<NW>(wv, frequency, v[3 * k], v[3 * k + 2], sa[k], ca[k]);
         }
+#if MW_POND_PACKED
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f sa2[2][NW], ca2[2][NW];
+#pragma unroll
+        for (int kp = 0; kp < 2; kp++)
+#pragma unroll
+            for (int i = 0; i < NW; i++) {
+                sa2[kp][i] = v2f{sa[2 * kp][i], sa[2 * kp + 1][i]};
+                ca2[kp][i] = v2f{ca[2 * kp][i], ca[2 * kp + 1][i]};
+            }
+#endif
         for (int step = step_lo; step < step_hi; step++) {
             float* dst = out + (size_t)step * nverts * 3 + 3 * v0;
+#if MW_POND_PACKED
+#pragma unroll
+            for (int kp = 0; kp < 2; kp++) {  // vertices 2 kp, 2 kp + 1 of the lane side by side in the two halves of v_pk_* operands
+                v2f o[3];
+                gerstner_step_vertex<NW, v2f>(wv, ph, step, amplitude, steepness, sa2[kp], ca2[kp], v2f{v[6 * kp], v[6 * kp + 3]},
+                                              v2f{v[6 * kp + 1], v[6 * kp + 4]}, v2f{v[6 * kp + 2], v[6 * kp + 5]}, o);
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+                    if (ok[2 * kp + e]) {
+                        float* q = dst + 3 * ((2 * kp + e) * 64 + lane);
+                        mw_store_stream<true>(&q[0], o[0][e]); mw_store_stream<true>(&q[1], o[1][e]); mw_store_stream<true>(&q[2], o[2][e]);
+                    }
+            }
+#else
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 float o[3];
-                gerstner_step_vertex<NW>(wv, ph, step, amplitude, steepness, sa[k], ca[k], v[3 * k], v[3 * k + 1], v[3 * k + 2], o);
+                gerstner_step_vertex<NW, float>(wv, ph, step, amplitude, steepness, sa[k], ca[k], v[3 * k], v[3 * k + 1], v[3 * k + 2], o);
                 if (ok[k]) {
                     float* q = dst + 3 * (k * 64 + lane);
                     mw_store_stream<true>(&q[0], o[0]); mw_store_stream<true>(&q[1], o[1]); mw_store_stream<true>(&q[2], o[2]);
                 }
             }
+#endif
         }
     }
 }
@@ -199,7 +231,9 @@ static inline hipError_t gerstner_launch_steps(const float* d_pos, int64_t nvert
     static const int spw_env = [] { const char* e = std::getenv("MW_POND_STEPS_PER_WG"); return e ? std::atoi(e) : 0; }();
     const int spw = spw_env > 0 ? (spw_env < nsteps ? spw_env : nsteps) : (MW_POND_STEPS_PER_WG < nsteps ? MW_POND_STEPS_PER_WG : nsteps);
 #ifndef MW_POND_XCD
-#define MW_POND_XCD 1  // step groups of a vertex chunk on one XCD (environment MW_POND_XCD=0: the 2-D grid of round 4, A/B)
+#define MW_POND_XCD 0  // 1: step groups of a vertex chunk on one XCD (environment MW_POND_XCD overrides).  Measured round 5 (profiles/r05_ab_notes.md):
+                       // 4.25e11 against 4.48e11 vertices/s for the 2-D grid -- the positions' second to fourth read is 1.1 of 13.5 B per
+                       // vertex-step and not what the launch waits for: off
 #endif
     static const int xcd_env = [] { const char* e = std::getenv("MW_POND_XCD"); return e ? std::atoi(e) : MW_POND_XCD; }();
     const int ngroups = (nsteps + spw - 1) / spw;

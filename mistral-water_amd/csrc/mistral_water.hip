@@ -351,7 +351,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
-            constexpr bool LIR = LastInRegs<N, P>::value && G::NBUF == 1;
+            constexpr bool LIR = LastStays<N, P>::value && G::NBUF == 1;
             const bool in_regs = LIR && s == FftGeom<N, P>::S - 1;  // the last pass writes nothing to LDS: no barrier on either side of it
             if (active) p2_mid_load<N, P, R2>(tid, s, x, set0 + cur * G::SETSTRIDE);
             if (!in_regs) { if (G::NBUF == 1) __syncthreads(); else cur ^= 1; }
@@ -529,7 +529,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
-            const bool in_regs = LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1;  // the last pass writes nothing to LDS (LastInRegs)
+            const bool in_regs = LastStays<N, P>::value && s == FftGeom<N, P>::S - 1;  // the last pass writes nothing to LDS (LastInRegs / LastInWave)
 #pragma unroll
             MW_VT(h) p2_mid_load<N, P, R2>(MW_VTID(h), s, x[h], set0);
             if (!in_regs) __syncthreads();
@@ -597,10 +597,10 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
             __syncthreads();
 #pragma unroll
             for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                const bool in_regs = LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1;
+                const bool in_regs = LastStays<N, P>::value && s == FftGeom<N, P>::S - 1;
                 if (g0 == 0) load_slots<N, P>(xq, u, set0, s - 1);
                 if (!in_regs) __syncthreads();
-                if (g0 == 0) { if (in_regs) stage_regs<N, P, +1>(xq, u, tw, s); else stage_store<N, P, +1>(xq, u, set0, tw, s); }
+                if (g0 == 0) { if (in_regs) stage_last_regs<N, P, +1>(xq, u, tw, s); else stage_store<N, P, +1>(xq, u, set0, tw, s); }  // g0 is wave-uniform: whole waves
 #ifdef MW_ABLATE_EXCH1
                 if (s == 1 && N >= MW_ABLATE_EXCH1) { __builtin_amdgcn_sched_barrier(0); continue; }
 #endif
@@ -669,12 +669,12 @@ __global__ __launch_bounds__((P2FrameGeom<N, P, R2>::NTHREADS)) void k_pass2_fra
     mw_setprio(fg == 0 ? MW_FRAME_PRIO_H : (fg == 1 ? MW_FRAME_PRIO_D : (fg == 2 ? MW_FRAME_PRIO_S : MW_FRAME_PRIO_X)));
 #pragma unroll
     for (int s = 1; s < FftGeom<N, P>::S; s++) {
-        const bool in_regs = LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1;
+        const bool in_regs = LastStays<N, P>::value && s == FftGeom<N, P>::S - 1;
         if (row) p2_mid_load<N, P, R2>(tl, s, x, mine);
         else if (halo) load_slots<N, P>(x, tl, mine, s - 1);
         if (!in_regs) row_sync();
-        if (row) p2_mid_store<N, P, R2>(tw, tl, s, x, mine);
-        else if (halo) { if (in_regs) stage_regs<N, P, +1>(x, tl, tw, s); else stage_store<N, P, +1>(x, tl, mine, tw, s); }
+        if (row) p2_mid_store<N, P, R2>(tw, tl, s, x, mine);  // (fg is wave-uniform: the in-wave exchange of LastInWave runs in whole waves)
+        else if (halo) { if (in_regs) stage_last_regs<N, P, +1>(x, tl, tw, s); else stage_store<N, P, +1>(x, tl, mine, tw, s); }
         if (!in_regs) row_sync();
     }
     MW_STAMP(1, 2);
@@ -1656,12 +1656,33 @@ __global__ void k_dbg_sincos_fast(const float* x, int n, float* sn, float* cs) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) sincos_fast_f32(x[i], &sn[i], &cs[i]);
 }
+// test hook: ONE wave applies wave_transpose4 (v_permlane16_swap / v_permlane32_swap, mw_math.h) to 64 lanes x 16 complex slots
+__global__ __launch_bounds__(64) void k_dbg_wave_transpose4(cf* io) {
+    cf x[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = io[threadIdx.x * 16 + r];
+    wave_transpose4<16>(x);
+#pragma unroll
+    for (int r = 0; r < 16; r++) io[threadIdx.x * 16 + r] = x[r];
+}
 static mw_status debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host, bool fast);
 mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host) {
     return debug_sincos(x_host, n, s_host, c_host, false);
 }
 mw_status mw_debug_sincos_fast(const float* x_host, int32_t n, float* s_host, float* c_host) {
     return debug_sincos(x_host, n, s_host, c_host, true);
+}
+mw_status mw_debug_wave_transpose4(float* inout_host) {
+    if (!inout_host) return fail(MW_EINVAL, "NULL argument");
+    cf* d = nullptr;
+    mw_status s = dmalloc(&d, 64 * 16);
+    if (s != MW_OK) return s;
+    hipError_t e = hipMemcpy(d, inout_host, sizeof(cf) * 64 * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_dbg_wave_transpose4, dim3(1), dim3(64), 0, 0, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpy(inout_host, d, sizeof(cf) * 64 * 16, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail(MW_EDEVICE, std::string("mw_debug_wave_transpose4: ") + hipGetErrorString(e));
+    return MW_OK;
 }
 static mw_status debug_sincos(const float* x_host, int32_t n, float* s_host, float* c_host, bool fast) {
     if (!x_host || !s_host || !c_host || n < 1) return fail(MW_EINVAL, "mw_debug_sincos: bad argument");

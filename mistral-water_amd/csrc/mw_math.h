@@ -527,6 +527,74 @@ MW_HD void stage_regs(cf (&x)[P], int u, const Twiddles& tw, int s) {
 // does not change after the last pass skip that round trip (4096^2 with 16 points per thread, 512^2 with 8).
 template <int N, int P>
 struct LastInRegs { static constexpr bool value = MW_LAST_IN_REGS && FftGeom<N, P>::RL == 1 && FftGeom<N, P>::S >= 2 && XLay<N, P>::EXACT; };
+// ---- the last exchange inside the wave (round 5; BASELINE.json's "wavefront shuffle") --------------------------------------------
+// N = 1024 at 16 points per thread: T = 64, ONE WAVE carries a row, passes 16 x 16 x 4.  After the second radix-16 pass lane u = k + 16 c
+// (k = u mod 16, c = its 16-lane row of the wave) holds in slot r the element n = 256 c + 16 r + k of the last intermediate sequence, and the
+// final radix-4 pass of thread u' wants n = u' + 64 q, i.e. u' = k + 16 (r mod 4), q = 4 c + r / 4: the value moves from row c of the wave to
+// row r mod 4 and nowhere else -- a 4 x 4 TRANSPOSITION between the wave's four 16-lane rows and the low two bits of the slot index.  gfx950
+// has the instruction for exactly that: v_permlane16_swap_b32 (odd rows of one register <-> even rows of another) and v_permlane32_swap_b32
+// (upper half of one <-> lower half of another) swap one lane bit with one register bit each, two VALU moves per complex value and bit, no
+// LDS crossbar (ds_bpermute, the form that lost in round 2, goes through it), no barrier.  32 moves replace 16 ds_write_b64 + 16 ds_read_b64
+// and two barriers per transform; after them slot 4 (q mod 4) + q / 4 holds what load_last would have put in slot q -- a renaming.  The
+// arithmetic is untouched: the same passes, the same table twiddles, the same bits as the LDS exchange it replaces.
+#ifndef MW_LAST_IN_WAVE
+#define MW_LAST_IN_WAVE 1
+#endif
+template <int N, int P>
+struct LastInWave {
+    static constexpr bool value = MW_LAST_IN_WAVE && P == 16 && FftGeom<N, P>::T == 64 && FftGeom<N, P>::S == 2 && FftGeom<N, P>::RL == 4 && XLay<N, P>::EXACT;
+};
+// where lane l's slot rho ends up / comes from under the transposition (it is an involution): used by the host emulation and the device test
+MW_HD void wave_transpose4_source(int lane, int rho, int* src_lane, int* src_rho) {
+    *src_lane = (lane & 15) | ((rho & 3) << 4);
+    *src_rho = (rho & ~3) | (lane >> 4);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void mw_swap16(float& a, float& b) {  // odd 16-lane rows of a <-> even rows of b
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    a = __builtin_bit_cast(float, r[0]);
+    b = __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ void mw_swap32(float& a, float& b) {  // upper 32 lanes of a <-> lower 32 lanes of b
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    a = __builtin_bit_cast(float, r[0]);
+    b = __builtin_bit_cast(float, r[1]);
+}
+#endif
+// all 64 lanes of the wave must be active.  Host (tests/emul): a no-op -- the emulation moves the values between its thread states itself
+// (wave_transpose4_source), the phase functions on either side are the same code.
+template <int P>
+MW_HD void wave_transpose4(cf (&x)[P]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int r = 0; r < P; r++)
+        if ((r & 1) == 0) { mw_swap16(x[r].x, x[r | 1].x); mw_swap16(x[r].y, x[r | 1].y); }  // slot bit 0 <-> lane bit 4
+#pragma unroll
+    for (int r = 0; r < P; r++)
+        if ((r & 2) == 0) { mw_swap32(x[r].x, x[r | 2].x); mw_swap32(x[r].y, x[r | 2].y); }  // slot bit 1 <-> lane bit 5
+#else
+    (void)x;
+#endif
+}
+// the last radix-P pass of a transform whose results stay in registers: LastInRegs (N = P^S: nothing to move) or LastInWave (the exchange
+// behind it runs inside the wave); load_last_regs is the matching "input of the final pass"
+template <int N, int P>
+struct LastStays { static constexpr bool value = LastInRegs<N, P>::value || LastInWave<N, P>::value; };
+template <int N, int P, int SGN, bool ALLOW_POW = true>
+MW_HD void stage_last_regs(cf (&x)[P], int u, const Twiddles& tw, int s) {
+    stage_regs<N, P, SGN, ALLOW_POW>(x, u, tw, s);
+    if (LastInWave<N, P>::value) wave_transpose4<P>(x);
+}
+template <int N, int P>
+MW_HD void load_last_regs(cf (&x)[P]) {
+    if (LastInWave<N, P>::value) {  // slot q of the final pass = slot 4 (q mod 4) + q / 4 after the transposition
+        cf y[P];
+#pragma unroll
+        for (int q = 0; q < P; q++) y[q] = x[4 * (q & 3) + (q >> 2)];
+#pragma unroll
+        for (int q = 0; q < P; q++) x[q] = y[q];
+    }
+}
 template <int N, int P, int SGN, bool ALLOW_POW = true>
 MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
     stage_regs<N, P, SGN, ALLOW_POW>(x, u, tw, s);

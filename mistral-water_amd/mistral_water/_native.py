@@ -181,6 +181,7 @@ def lib():
         "mw_debug_sincos": (C.c_int, [f32p, C.c_int32, f32p, f32p]),
         "mw_debug_sincos_fast": (C.c_int, [f32p, C.c_int32, f32p, f32p]),
         "mw_debug_stream_read": (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
+        "mw_debug_wave_transpose4": (C.c_int, [f32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = ABI symbol missing: fail loudly
@@ -209,7 +210,7 @@ ABI_SYMBOLS = [
 ]
 #: measurement and test hooks (include/mistral_water_hooks.h): exported, but not part of the drop-in boundary
 HOOK_SYMBOLS = ["mw_ocean_profile_kernels", "mw_ocean_profile_kernels_stats", "mw_debug_pass1_time_group", "mw_debug_omega_t", "mw_debug_evaluate_hds", "mw_debug_get_omega", "mw_debug_sincos",
-                "mw_debug_sincos_fast", "mw_debug_stream_read"]
+                "mw_debug_sincos_fast", "mw_debug_stream_read", "mw_debug_wave_transpose4"]
 
 
 def build_id() -> str:

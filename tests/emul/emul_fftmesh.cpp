@@ -36,6 +36,25 @@ struct Tables {
     }
 };
 
+// The in-wave exchange of LastInWave (mw_math.h): on the device v_permlane16_swap / v_permlane32_swap move the values between the lanes of
+// a wave; wave_transpose4 is a no-op on the host, so the emulation moves them between its thread states -- threads first .. first + count
+// (whole waves of 64), x_of(tid) = that thread's slot array -- by the index map the device test checks the instructions against.
+template <int N, int P, class F>
+void emul_last_in_wave(int first, int count, F x_of) {
+    if (!LastInWave<N, P>::value) return;
+    std::vector<cf> old((size_t)64 * P);
+    for (int w0 = first; w0 < first + count; w0 += 64) {
+        for (int l = 0; l < 64; l++)
+            for (int r = 0; r < P; r++) old[(size_t)l * P + r] = x_of(w0 + l)[r];
+        for (int l = 0; l < 64; l++)
+            for (int r = 0; r < P; r++) {
+                int sl, sr;
+                wave_transpose4_source(l, r, &sl, &sr);
+                x_of(w0 + l)[r] = old[(size_t)sl * P + sr];
+            }
+    }
+}
+
 template <int N, int P>
 void run_pass1(const P1Args& A, const StepTimes& tm, int nsteps) {
     constexpr int T = FftGeom<N, P>::T, NT = P1Geom<N, P>::NTHREADS, BS = P1Geom<N, P>::BUFSTRIDE;
@@ -85,6 +104,7 @@ void run_pass2(const P2Args& A, int nsteps) {
                         if (p2_active<N, P, R2>(ab, tid, f)) p2_mid_load<N, P, R2>(tid, s, st[tid].x, lds.data());
                     for (int tid = 0; tid < NT; tid++)
                         if (p2_active<N, P, R2>(ab, tid, f)) p2_mid_store<N, P, R2>(tw, tid, s, st[tid].x, lds.data());
+                    if (s == FftGeom<N, P>::S - 1) emul_last_in_wave<N, P>(0, NT, [&](int tid) { return st[tid].x; });
                 }
                 for (int tid = 0; tid < NT; tid++)
                     if (p2_active<N, P, R2>(ab, tid, f))
@@ -115,6 +135,7 @@ void run_pass2_hs(const P2Args& A, int nsteps) {
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
                     for (int tid = 0; tid < NT; tid++) p2_mid_load<N, P, R2>(tid, s, st[tid].x, lds.data());
                     for (int tid = 0; tid < NT; tid++) p2_mid_store<N, P, R2>(tw, tid, s, st[tid].x, lds.data());
+                    if (s == FftGeom<N, P>::S - 1) emul_last_in_wave<N, P>(0, NT, [&](int tid) { return st[tid].x; });
                 }
                 if (f == 2) {
                     for (int tid = 0; tid < NT; tid++)
@@ -135,11 +156,12 @@ void run_pass2_hs(const P2Args& A, int nsteps) {
                     }
                     for (int s = 1; s < FftGeom<N, P>::S; s++) {
                         for (int u = 0; u < T; u++) load_slots<N, P>(st[u].x, u, lds.data(), s - 1);
-                        const bool in_regs = LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1;  // as k_pass2_hs's halo transform
+                        const bool in_regs = LastStays<N, P>::value && s == FftGeom<N, P>::S - 1;  // as k_pass2_hs's halo transform
                         for (int u = 0; u < T; u++) {
-                            if (in_regs) stage_regs<N, P, +1>(st[u].x, u, tw, s);
+                            if (in_regs) stage_last_regs<N, P, +1>(st[u].x, u, tw, s);
                             else stage_store<N, P, +1>(st[u].x, u, lds.data(), tw, s);
                         }
+                        if (in_regs) emul_last_in_wave<N, P>(0, T, [&](int tid) { return st[tid].x; });
                     }
                     for (int u = 0; u < T; u++) { p2_last_load<N, P>(st[u].x, u, lds.data()); final_stage<N, P, +1>(st[u].x, u, tw.TF); }
                     for (int u = 0; u < T; u++) p2_hs_halo_publish<N, P, R2>(ab, u, st[u].x, lds.data());
@@ -176,15 +198,16 @@ void run_pass2_frame(const P2Args& A, int nsteps) {
                 else { p2_hs_halo_fetch<N, P, R2>(A, ab, step, tl, t.x); stage0_store<N, P, +1>(t.x, tl, mine); }
             });
             for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                const bool in_regs = LastInRegs<N, P>::value && s == FftGeom<N, P>::S - 1;
+                const bool in_regs = LastStays<N, P>::value && s == FftGeom<N, P>::S - 1;
                 each([&](int fg, int tl, St& t, cf* mine) {
                     if (fg < 3) p2_mid_load<N, P, R2>(tl, s, t.x, mine); else load_slots<N, P>(t.x, tl, mine, s - 1);
                 });
                 each([&](int fg, int tl, St& t, cf* mine) {
                     if (fg < 3) p2_mid_store<N, P, R2>(tw, tl, s, t.x, mine);
-                    else if (in_regs) stage_regs<N, P, +1>(t.x, tl, tw, s);
+                    else if (in_regs) stage_last_regs<N, P, +1>(t.x, tl, tw, s);
                     else stage_store<N, P, +1>(t.x, tl, mine, tw, s);
                 });
+                if (in_regs) emul_last_in_wave<N, P>(0, has_halo ? NT : 3 * FT, [&](int tid) { return st[tid].x; });
             }
             each([&](int fg, int tl, St& t, cf* mine) {
                 p2_last_load<N, P>(t.x, tl % T, mine + (fg < 3 ? tl / T : 0) * BS);
@@ -476,6 +499,7 @@ void emul_spectrum(int N, float length, float wind_x, float wind_y, float amplit
                              reinterpret_cast<cf*>(h0c));
 }
 
+void emul_wave_transpose4_source(int lane, int rho, int* src_lane, int* src_rho) { wave_transpose4_source(lane, rho, src_lane, src_rho); }
 void emul_omega_t(int N, float length, float gravity, float t, float* out) {
     for (int i = 0; i < N; i++)
         for (int j = 0; j < N; j++) out[i * N + j] = omega_t_f32(N, length, gravity, i, j, t);

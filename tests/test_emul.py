@@ -119,6 +119,38 @@ def test_round4_shortcuts_change_no_bit(oracle):
         base.set_variant(force_hs=False)
 
 
+def test_last_exchange_inside_the_wave_changes_no_bit(oracle):
+    """Round 5, LastInWave (mw_math.h): at 1024 points and 16 per thread the exchange in front of the final radix-4 pass is a 4 x 4
+    transposition between the wave's four 16-lane rows and the low two bits of the slot index (v_permlane16_swap / v_permlane32_swap on
+    the device, the index map wave_transpose4_source here) + a slot renaming, instead of a round trip through LDS behind two barriers.
+    Against a build with it switched off, bit for bit, in the three pass-2 kernels that run it: sequential halo (the shipped batched
+    plan at 1024^2), the frame variant, and the halo-group form; the map itself is checked against the instructions on the GPU
+    (test_wave_transpose4_instructions_match_the_index_map)."""
+    import emul_build
+    base = emul_build.load()
+    alt = emul_build.Emul(defs=("MW_LAST_IN_WAVE=0",))
+    p = workloads.fftmesh_params(1024)
+    h0, h0c = oracle.generate_spectrum(p, 5)
+    try:
+        for kw in (dict(force_hs=True), dict(frame=True), dict()):
+            base.set_variant(**kw); alt.set_variant(**kw)
+            a = base.evaluate(p, h0, h0c, [1.75], pts=16, white_stride=1)
+            b = alt.evaluate(p, h0, h0c, [1.75], pts=16, white_stride=1)
+            assert all((u == v).all() for u, v in zip(a, b)), kw
+            assert np.abs(a[0]).max() > 0 and np.abs(a[2]).max() > 0
+    finally:
+        base.set_variant()
+    # the map is an involution that only touches lane bits 5:4 and slot bits 1:0
+    L = base.L
+    import ctypes as C
+    for lane in range(64):
+        for rho in range(16):
+            sl, sr = C.c_int(), C.c_int()
+            L.emul_wave_transpose4_source(lane, rho, C.byref(sl), C.byref(sr))
+            assert (sl.value & 15) == (lane & 15) and (sr.value >> 2) == (rho >> 2)
+            assert (sl.value >> 4) == (rho & 3) and (sr.value & 3) == (lane >> 4)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_slope_field_storage_modes(oracle, mode):
     """MW_SPLIT_SLOPES: the slope field crosses the exchange buffer whole (0), as the kx part G for j <= N/2 with

@@ -195,6 +195,24 @@ def test_omega_t_bit_exact_on_device(mw, oracle, emul):
             assert (want[i, [0, 1, N // 2, N - 1]] == row).all()
 
 
+def test_wave_transpose4_instructions_match_the_index_map(mw, emul):
+    """The in-wave exchange of the 1024-point transform (LastInWave): one wave runs v_permlane16_swap / v_permlane32_swap over 64 lanes
+    x 16 complex slots of distinct values; every value must land where the index map says (the map the host emulation applies, which
+    tests/test_emul.py proves equal to the LDS exchange bit for bit).  Index work: exact."""
+    import ctypes as C
+    a = np.arange(64 * 16 * 2, dtype=np.float32).reshape(64, 16, 2) + 0.5
+    got = a.copy()
+    mw.check(mw.lib().mw_debug_wave_transpose4(got.ctypes.data_as(C.c_void_p)))
+    want = np.empty_like(a)
+    for lane in range(64):
+        for rho in range(16):
+            sl, sr = C.c_int(), C.c_int()
+            emul.L.emul_wave_transpose4_source(lane, rho, C.byref(sl), C.byref(sr))
+            want[lane, rho] = a[sl.value, sr.value]
+    assert (got == want).all(), f"{(got != want).any(axis=2).sum()} of 1024 slots differ"
+    assert not (got == a).all()
+
+
 def test_rest_mesh_bit_exact_on_device(mw, oracle):
     for N, u, L in [(64, 1.0, 64.0), (12, 1.0, 12.39), (7, 0.37, 3.0)]:
         p = oracle.Params(N=N, unit_width=u, length=L, amplitude=0.01, wind_x=5, wind_y=3)
