@@ -831,7 +831,7 @@ def direct(a, e):
             # SURVEY 8d's general formula 16 + 16 F + out with F = 3 Hermitian-packed complex planes crossing between the two axis passes
             # (round 4; five unpacked fields before): 16 (h0, h0conj) + 48 (3 planes written + read once) + 28 (vertex, normal, whitecap) = 92 B.
             bpp = 16 + 16 * 3 + 28
-            roof = {"bound": "hbm", "kernel": "k_czt (2 launches) + spectrum / assembly kernels = one step", "achieved": bpp * NN / (step_ms * 1e-3) / 1e9,
+            roof = {"bound": "hbm", "kernel": "k_czt + assembly = one step (" + ("2 launches" if "rows_assemble" in kern[1][0] else "3 launches") + ")", "achieved": bpp * NN / (step_ms * 1e-3) / 1e9,
                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bpp * NN / (step_ms * 1e-3) / HBM_PEAK, "traffic": None,
                     "algorithmic_bytes_per_point": bpp, "bytes_per_launch_group": bpp * NN, "launch_group_us": step_ms * 1e3,
                     "kernels": [{"name": nm, "us_per_step": ms * 1e3} for nm, ms in kern],
@@ -858,7 +858,8 @@ def direct(a, e):
             lds_line = 2 * (n_exch * 16.0 * M + (n_pass - 1) * 8.0 * M * (Pz - 1) / Pz)
             valu_peak, lds_peak = MFMA_F32_PEAK, 256 * 128 * 2.4e9   # f32 vector rate (FMA = 2 flop); 128 B/clk/CU x 256 CUs x 2.4 GHz
             b_valu, b_lds, b_hbm = lines * flop_line / valu_peak, lines * lds_line / lds_peak, bpp * NN / HBM_PEAK
-            k_czt_s = kern[0][1] * 1e-3
+            fused_small = "rows_assemble" in kern[1][0]       # N <= 128: the second axis runs inside the assembly launch
+            k_czt_s = (kern[0][1] + (kern[1][1] if fused_small else 0.0)) * 1e-3
             binding = max((b_valu, "valu"), (b_lds, "lds"), (b_hbm, "hbm"))
             roof["transform_bounds"] = {
                 "transform_size": M, "points_per_thread": Pz, "lds_exchanges_per_transform": n_exch, "lines_per_step": lines,

@@ -169,25 +169,11 @@ __global__ void k_direct_white(int N, const cf* hds, const float* normals, float
 #ifndef MW_CZT_XCD_GROUP
 #define MW_CZT_XCD_GROUP 1
 #endif
-template <int M, int P, int RW>
-__global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cf* lds = reinterpret_cast<cf*>(smem);
-    constexpr int T = M / P, BUF = FftGeom<M, P>::LBUF + 4;
-    // Row blocks of one 128-B line of the TRANSPOSED output (16 consecutive rows = 16 / RW consecutive blocks, 8 B each per column) are
-    // issued on ONE XCD (the dispatcher places block b on XCD b % 8), so that their 8 RW-byte pieces of a line meet in that XCD's L2
-    // instead of leaving four L2s as partial lines.  Any bijection is correct; blocks past the last whole group of 8 x G keep their index.
-    constexpr int G = 16 / RW > 0 ? 16 / RW : 1;
-    int rb = (int)blockIdx.x;
-    if (MW_CZT_XCD_GROUP && G > 1 && rb < (int)gridDim.x / (8 * G) * (8 * G)) {
-        const int grp = rb / (8 * G), in = rb % (8 * G), xcd = in % 8, slot = in / 8;
-        rb = grp * (8 * G) + xcd * G + slot;
-    }
-    const int tid = threadIdx.x, w = tid / T, u = tid % T, row = rb * RW + w, f = blockIdx.y;
-    const bool live = row < A.rows;
+// one line of one axis: pre-chirp + zero padding, forward transform, kernel product, inverse transform; x = the inverse transform's output
+// (element n = u + T q in slot q), the post-chirp is the caller's.  Barriers inside: every thread of the workgroup must call it.
+template <int M, int P>
+__device__ __forceinline__ void czt_line(const CztArgs& A, int f, int row, bool live, int u, cf* buf, cf (&x)[P]) {
     const Twiddles twf = TwGeom<M, P>::view(A.TWf), twi = TwGeom<M, P>::view(A.TWi);
-    cf* buf = lds + (size_t)w * BUF;
-    cf x[P];
     czt_load<M, P>(A, f, live ? row : 0, u, live, x);
     stage0_store<M, P, -1>(x, u, buf);
     __syncthreads();
@@ -217,7 +203,83 @@ __global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
     }
     if (!LastInRegs<M, P>::value) load_last<M, P>(x, u, buf);
     final_stage<M, P, +1>(x, u, twi.TF);
+}
+template <int M, int P, int RW>
+__global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = M / P, BUF = FftGeom<M, P>::LBUF + 4;
+    // Row blocks of one 128-B line of the TRANSPOSED output (16 consecutive rows = 16 / RW consecutive blocks, 8 B each per column) are
+    // issued on ONE XCD (the dispatcher places block b on XCD b % 8), so that their 8 RW-byte pieces of a line meet in that XCD's L2
+    // instead of leaving four L2s as partial lines.  Any bijection is correct; blocks past the last whole group of 8 x G keep their index.
+    constexpr int G = 16 / RW > 0 ? 16 / RW : 1;
+    int rb = (int)blockIdx.x;
+    if (MW_CZT_XCD_GROUP && G > 1 && rb < (int)gridDim.x / (8 * G) * (8 * G)) {
+        const int grp = rb / (8 * G), in = rb % (8 * G), xcd = in % 8, slot = in / 8;
+        rb = grp * (8 * G) + xcd * G + slot;
+    }
+    const int tid = threadIdx.x, w = tid / T, u = tid % T, row = rb * RW + w, f = blockIdx.y;
+    const bool live = row < A.rows;
+    cf x[P];
+    czt_line<M, P>(A, f, row, live, u, lds + (size_t)w * BUF, x);
     if (live) czt_store<M, P>(A, f, row, u, x);
+}
+// Small grids (M <= 256, i.e. N <= 128: the reference's Inspector default N = 50 and its shipped scene N = 12): the SECOND axis and the
+// assembly in ONE launch (round 5; a step is launch latency there -- three launches of a few workgroups, 15.5 us at N = 50).  A workgroup
+// owns RW output rows b of ALL three packed planes plus the next row of the two planes that carry the displacement (the forward difference
+// of the Jacobian reads (a, b + 1), S/FFTMesh.cs:264-267): 3 RW + 2 lines transformed side by side, post-chirped into their own LDS
+// buffers, then vertices / normals / whitecap straight from there -- the plane O never exists in memory.  The arithmetic of a line and of
+// a vertex is the three-launch plan's: the same bits (tests/test_zz_frame_plan.py::test_small_grid_fused_czt_equals_three_launches).
+template <int M, int P, int RW>
+__global__ __launch_bounds__(((3 * RW + 2) * M / P)) void k_czt_rows_assemble(CztArgs A, cf* hds, float* vertices, float* normals, float* white,
+                                                                              int white_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = M / P, BUF = FftGeom<M, P>::LBUF + 4, NT = (3 * RW + 2) * T;
+    static_assert(BUF >= M, "a line's exchange buffer holds its post-chirped outputs afterwards");
+    const int tid = threadIdx.x, gi = tid / T, u = tid % T, b0 = (int)blockIdx.x * RW;
+    const int f = gi < 3 * RW ? gi / RW : (gi == 3 * RW ? 0 : 2);         // halo lines: planes 0 (Dx in its imaginary part) and 2 (Dz)
+    const int row = gi < 3 * RW ? b0 + gi % RW : b0 + RW;
+    const bool live = row < A.rows;
+    cf* buf = lds + (size_t)gi * BUF;
+    cf x[P];
+    czt_line<M, P>(A, f, row, live, u, buf, x);
+    __syncthreads();  // the final pass has read its last exchange: the buffer now takes the post-chirped outputs, plain index a
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int n = u + T * q;
+        if (n < A.nout) buf[n] = cmul(x[q], A.w2[n]);  // czt_store's expression
+    }
+    __syncthreads();
+    const OceanConsts& C = A.C;
+    const int N = C.N;
+    const cf* P0 = lds;                              // [w][a] = H + i Dx
+    const cf* P1 = lds + (size_t)RW * BUF;           //          Sx + i Sz
+    const cf* P2 = lds + (size_t)2 * RW * BUF;       //          Dz (real part)
+    const cf* H0 = lds + (size_t)3 * RW * BUF;       // row b0 + RW of plane 0
+    const cf* H2 = H0 + BUF;                         //                 plane 2
+    for (int e = tid; e < RW * N; e += NT) {         // consecutive lanes -> consecutive b: RW x 12-byte runs
+        const int a = e / RW, w = e % RW, b = b0 + w;
+        if (b >= N) continue;
+        const int idx = a * N + b;
+        const cf p0 = P0[(size_t)w * BUF + a], p1 = P1[(size_t)w * BUF + a];
+        const float h = p0.x, dx = p0.y, sx = p1.x, sz = p1.y, dz = P2[(size_t)w * BUF + a].x;
+        const float mag = sqrtf(sx * sx + 1.0f + sz * sz);  // up - n, S/FFTMesh.cs:218 (k_czt_assemble_white's expressions from here on)
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        if (mag > 1e-5f) { nx = sx / mag; ny = 1.0f / mag; nz = sz / mag; }
+        normals[3 * idx] = nx; normals[3 * idx + 1] = ny; normals[3 * idx + 2] = nz;
+        vertices[3 * idx + 0] = ssub(rest_coord(N, C.unit_width, a), smul(dx, C.choppiness));  // :245
+        vertices[3 * idx + 1] = h;                                                             // :243
+        vertices[3 * idx + 2] = ssub(rest_coord(N, C.unit_width, b), smul(dz, C.choppiness));  // :244
+        if (hds) hds[idx] = mk(dx, dz);                                                        // :247
+        const bool hi = a != N - 1, hj = b != N - 1;
+        const cf z = mk(0.f, 0.f);
+        const cf di = hi ? mk(P0[(size_t)w * BUF + a + 1].y, P2[(size_t)w * BUF + a + 1].x) : z;
+        const cf dj = hj ? (w + 1 < RW ? mk(P0[(size_t)(w + 1) * BUF + a].y, P2[(size_t)(w + 1) * BUF + a].x) : mk(H0[a].y, H2[a].x)) : z;
+        const float xx = whitecap(mk(dx, dz), di, dj, hi, hj, nx, nz);
+        if (white_stride == 1) white[idx] = xx;
+        else { white[4 * idx] = xx; white[4 * idx + 1] = xx; white[4 * idx + 2] = xx; white[4 * idx + 3] = xx; }
+    }
 }
 // vertices / normals / whitecap from the three packed output planes O[p][a][b] = (H + i Dx, Sx + i Sz, Dz) (czt_packed_value;
 // S/FFTMesh.cs:211-218), and the forward-difference Jacobian (:258-274) from the displacement of the two neighbours -- one launch;
@@ -269,6 +331,34 @@ static inline int czt_alloc(CztState& z, int N) {
     }
     return 0;
 }
+// chirps and the transform of the wrapped kernel (f64 on the host): uploaded when the handle is created and when its length changes
+// (mw_ocean_create / mw_ocean_reinit_spectrum) -- an enqueue never synchronises or copies
+static inline hipError_t czt_upload_tables(CztState& z, int N, float unit_width, float length, hipStream_t st) {
+    std::vector<cf> w1, w2, Hh;
+    czt_build_tables(N, N + 1, z.M, unit_width, length, w1, w2, Hh);
+    hipError_t e = hipStreamSynchronize(st);  // a step still in flight may be reading the old tables
+    if (e == hipSuccess) e = hipMemcpy(z.w1, w1.data(), sizeof(cf) * (N + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(z.w2, w2.data(), sizeof(cf) * N, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(z.Hh, Hh.data(), sizeof(cf) * z.M, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    z.table_length = length;
+    z.table_unit_width = unit_width;
+    return hipSuccess;
+}
+#ifndef MW_CZT_FUSED_MAX_M
+#define MW_CZT_FUSED_MAX_M 256  // grids whose second axis and assembly run in one launch (environment MW_CZT_FUSED=0: three launches, A/B)
+#endif
+constexpr int czt_fused_rows(int M) { return M <= 128 ? 8 : 4; }
+template <int M>
+static hipError_t czt_launch_rows_assemble(const CztArgs& A, cf* hds, float* dv, float* dn, float* dw, int white_stride, hipStream_t st) {
+    constexpr int P = czt_points(M), RW = czt_fused_rows(M), NG = 3 * RW + 2, LB = NG * (FftGeom<M, P>::LBUF + 4) * (int)sizeof(cf);
+    static_assert(NG * (M / P) <= 1024 && LB <= 160 * 1024, "fused small-grid launch: geometry");
+    static AttrOnce attr;
+    hipError_t e = attr.set(reinterpret_cast<const void*>(&k_czt_rows_assemble<M, P, RW>), LB);
+    if (e != hipSuccess) return e;
+    k_czt_rows_assemble<M, P, RW><<<dim3((A.rows + RW - 1) / RW), dim3(NG * M / P), LB, st>>>(A, hds, dv, dn, dw, white_stride);
+    return hipGetLastError();
+}
 template <int M>
 static hipError_t czt_launch(const CztArgs& A, hipStream_t st) {
     constexpr int P = czt_points(M), RW = czt_rows(M), LB = RW * (FftGeom<M, P>::LBUF + 4) * (int)sizeof(cf);
@@ -284,17 +374,12 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
     CztState& z = d.czt;
     const int N = C.N;
     const unsigned nb = (unsigned)(((size_t)N * N + 127) / 128);
-    if (z.table_length != C.length || z.table_unit_width != C.unit_width) {  // chirps and the kernel's transform: once per handle / length
-        std::vector<cf> w1, w2, Hh;
-        czt_build_tables(N, N + 1, z.M, C.unit_width, C.length, w1, w2, Hh);
-        hipError_t e = hipStreamSynchronize(st);  // a step still in flight may be reading the old tables
-        if (e == hipSuccess) e = hipMemcpy(z.w1, w1.data(), sizeof(cf) * (N + 1), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(z.w2, w2.data(), sizeof(cf) * N, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(z.Hh, Hh.data(), sizeof(cf) * z.M, hipMemcpyHostToDevice);
+    if (z.table_length != C.length || z.table_unit_width != C.unit_width) {  // safety net only: the tables are uploaded at creation and at a
+        hipError_t e = czt_upload_tables(z, N, C.unit_width, C.length, st);    // length change (direct_prepare_tables), never inside an enqueue
         if (e != hipSuccess) return e;
-        z.table_length = C.length;
-        z.table_unit_width = C.unit_width;
     }
+    const char* fe = std::getenv("MW_CZT_FUSED");  // read per call: the GPU test flips it inside one process
+    const bool fused = !(fe && std::atoi(fe) == 0) && z.M <= MW_CZT_FUSED_MAX_M;
     if (ev) { hipEventRecord(ev[0], st); hipEventRecord(ev[1], st); }
     CztArgs A;
     A.w1 = z.w1; A.w2 = z.w2; A.Hh = z.Hh; A.TWf = z.TWf; A.TWi = z.TWi;
@@ -308,6 +393,14 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
         A.rows = pass == 0 ? N + 1 : N;
         A.in_ld = N + 1; A.in_plane = (long long)N * (N + 1);
         A.out_ld = pass == 0 ? N + 1 : N; A.out_plane = pass == 0 ? (long long)N * (N + 1) : (long long)N * N;
+        if (pass == 1 && fused) {  // small grids: the second axis and the assembly in one launch, no plane O
+            if (ev) hipEventRecord(ev[2], st);
+            switch (z.M) {
+                case 64: return czt_launch_rows_assemble<64>(A, d.hds, dv, dn, dw, white_stride, st);
+                case 128: return czt_launch_rows_assemble<128>(A, d.hds, dv, dn, dw, white_stride, st);
+                default: return czt_launch_rows_assemble<256>(A, d.hds, dv, dn, dw, white_stride, st);
+            }
+        }
         switch (z.M) {
             case 64: e = czt_launch<64>(A, st); break;
             case 128: e = czt_launch<128>(A, st); break;
@@ -354,6 +447,11 @@ static inline int direct_alloc(DirectState& d, int N, hipStream_t st) {
     if (hipMalloc((void**)&d.hds, sizeof(cf) * (size_t)N * N) != hipSuccess) { direct_free(d); return 4; }
     d.N = N;
     return 0;
+}
+// tables that depend on (unit_width, length) but not on t: built when the handle is created and when its length changes
+static inline hipError_t direct_prepare_tables(DirectState& d, int N, float unit_width, float length, hipStream_t st) {
+    if (d.use_czt) return czt_upload_tables(d.czt, N, unit_width, length, st);
+    return hipSuccess;  // GEMM form: k_direct_tables runs on the stream, inside the first enqueue after a change (asynchronous)
 }
 // flop of one step as the GEMMs execute it (padded), and algorithmically (60 N^3)
 static inline double direct_flops_padded(const DirectState& d) { return 60.0 * (double)d.Np * d.Np * d.Np; }

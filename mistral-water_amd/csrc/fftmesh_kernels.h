@@ -700,7 +700,7 @@ template <int N, int P, int R2>
 MW_HD void p2_mid_store(const Twiddles& tw, int tid, int s, cf (&x)[P], cf* lds) {
     int r1, u1;
     p2_mid_map<N, P, R2>(tid, &r1, &u1);
-    if (LastStays<N, P>::value && s == FftGeom<N, P>::S - 1) stage_last_regs<N, P, +1>(x, u1, tw, s);  // stays in registers (or moves inside the wave): p2_last_load reads nothing
+    if (mw_pass_in_regs<N, P>(s)) stage_last_regs<N, P, +1>(x, u1, tw, s);  // stays in registers (or moves inside the wave): p2_last_load reads nothing
     else stage_store<N, P, +1>(x, u1, lds + r1 * P2Buf<N, P>::BUFSTRIDE, tw, s);
 }
 // input of the final pass in the row-major mapping: the last exchange, unless the last radix-P pass left it in registers (LastInRegs:

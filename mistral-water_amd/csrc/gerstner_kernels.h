@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos,
 // of a sincos.  The positions are read once per launch; per step only the 12-B result leaves.
 #define MW_GERSTNER_PHASES 256  // nsteps * nwaves per launch (2 KiB of kernel arguments)
 #ifndef MW_POND_PACKED
-#define MW_POND_PACKED 1  // two vertices of a lane per v_pk_* instruction in k_gerstner_steps (A/B: -DMW_POND_PACKED=0)
+#define MW_POND_PACKED 0  // 1: two vertices of a lane per v_pk_* instruction in k_gerstner_steps.  Measured round 5 (profiles/r05_ab_notes.md): the
+                          // packed form halves the VALU instructions of the step loop (224 -> 120) but takes 146 instead of 123 VGPRs (3 instead
+                          // of 4 waves per SIMD) and is no faster (76-79 against 71-77 us per 32-step launch): off
 #endif
 #ifndef MW_POND_STEPS_PER_WG
 #define MW_POND_STEPS_PER_WG 8  // time values per workgroup of k_gerstner_steps (environment MW_POND_STEPS_PER_WG overrides: A/B)

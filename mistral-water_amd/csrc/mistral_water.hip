@@ -529,7 +529,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
-            const bool in_regs = LastStays<N, P>::value && s == FftGeom<N, P>::S - 1;  // the last pass writes nothing to LDS (LastInRegs / LastInWave)
+            const bool in_regs = mw_pass_in_regs<N, P>(s);  // the last pass writes nothing to LDS (LastInRegs / LastInWave)
 #pragma unroll
             MW_VT(h) p2_mid_load<N, P, R2>(MW_VTID(h), s, x[h], set0);
             if (!in_regs) __syncthreads();
@@ -597,7 +597,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
             __syncthreads();
 #pragma unroll
             for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                const bool in_regs = LastStays<N, P>::value && s == FftGeom<N, P>::S - 1;
+                const bool in_regs = mw_pass_in_regs<N, P>(s);
                 if (g0 == 0) load_slots<N, P>(xq, u, set0, s - 1);
                 if (!in_regs) __syncthreads();
                 if (g0 == 0) { if (in_regs) stage_last_regs<N, P, +1>(xq, u, tw, s); else stage_store<N, P, +1>(xq, u, set0, tw, s); }  // g0 is wave-uniform: whole waves
@@ -669,7 +669,7 @@ __global__ __launch_bounds__((P2FrameGeom<N, P, R2>::NTHREADS)) void k_pass2_fra
     mw_setprio(fg == 0 ? MW_FRAME_PRIO_H : (fg == 1 ? MW_FRAME_PRIO_D : (fg == 2 ? MW_FRAME_PRIO_S : MW_FRAME_PRIO_X)));
 #pragma unroll
     for (int s = 1; s < FftGeom<N, P>::S; s++) {
-        const bool in_regs = LastStays<N, P>::value && s == FftGeom<N, P>::S - 1;
+        const bool in_regs = mw_pass_in_regs<N, P>(s);
         if (row) p2_mid_load<N, P, R2>(tl, s, x, mine);
         else if (halo) load_slots<N, P>(x, tl, mine, s - 1);
         if (!in_regs) row_sync();
@@ -1084,6 +1084,10 @@ static mw_status ocean_create_impl(const mw_params* params, int tiles, mw_ocean*
             }
         } else {
             if (direct_alloc(o->direct, N, o->stream) != 0) { mw_ocean_destroy(o); return fail(MW_ENOMEM, "direct path alloc failed"); }
+            if (direct_prepare_tables(o->direct, N, params->unit_width, params->length, o->stream) != hipSuccess) {
+                mw_ocean_destroy(o);
+                return fail(MW_EDEVICE, "direct path: chirp tables could not be uploaded");
+            }
         }
         hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((NN + 255) / 256)), dim3(256), 0, o->stream, N, params->length,
                            params->wind_x, params->wind_y, params->amplitude, params->gravity, params->seed, o->h0, o->h0c);
@@ -1245,6 +1249,8 @@ mw_status mw_ocean_reinit_spectrum(mw_ocean* o, float length, float wind_x, floa
         o->h0 = n0; o->h0c = n0c;
         if (e == hipSuccess) s = run_prep(o);
         if (s == MW_OK && e == hipSuccess) e = hipStreamSynchronize(o->stream);
+        if (s == MW_OK && e == hipSuccess && !o->use_fft && length != old_length)  // chirp tables of the new length, here and not inside the next enqueue
+            e = direct_prepare_tables(o->direct, N, o->p.unit_width, length, o->stream);
         if (s != MW_OK || e != hipSuccess) {
             o->h0 = old0; o->h0c = old0c;
             o->p.length = old_length;
@@ -1503,7 +1509,10 @@ static mw_status profile_kernels_impl(mw_ocean* o, int32_t nsteps, int32_t iters
         if (nsteps != 1) return fail(MW_EINVAL, "mw_ocean_profile_kernels: the direct-sum path evaluates one step per enqueue");
         static const char* gnames[2] = {"k_gemm_f32_mfma (4 launches: z sum, x sum)", "k_direct_spec + k_direct_assemble + k_direct_white"};
         static const char* znames[2] = {"k_czt (2 launches: spectrum + chirp-z along j, chirp-z along i)", "k_czt_assemble_white"};
-        const char* const* dnames = o->direct.use_czt ? znames : gnames;
+        static const char* fnames[2] = {"k_czt (spectrum + chirp-z along j)", "k_czt_rows_assemble (chirp-z along i + vertices, normals, whitecap: one launch)"};
+        const char* fe = std::getenv("MW_CZT_FUSED");
+        const bool fused = o->direct.use_czt && !(fe && std::atoi(fe) == 0) && o->direct.czt.M <= MW_CZT_FUSED_MAX_M;
+        const char* const* dnames = o->direct.use_czt ? (fused ? fnames : znames) : gnames;
         hipEvent_t ev[4];
         for (auto& e : ev) hipEventCreate(&e);
         hipError_t he = hipSuccess;

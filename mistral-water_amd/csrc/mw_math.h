@@ -550,15 +550,19 @@ MW_HD void wave_transpose4_source(int lane, int rho, int* src_lane, int* src_rho
     *src_rho = (rho & ~3) | (lane >> 4);
 }
 #if defined(__HIP_DEVICE_COMPILE__)
+// (the two results go through named scalars: __builtin_bit_cast applied DIRECTLY to a vector element, bit_cast(float, r[1]), reads element 0
+// in this clang -- both outputs became the first one; tests/test_gpu_parity.py::test_wave_transpose4_instructions_match_the_index_map)
 __device__ __forceinline__ void mw_swap16(float& a, float& b) {  // odd 16-lane rows of a <-> even rows of b
     const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-    a = __builtin_bit_cast(float, r[0]);
-    b = __builtin_bit_cast(float, r[1]);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
 }
 __device__ __forceinline__ void mw_swap32(float& a, float& b) {  // upper 32 lanes of a <-> lower 32 lanes of b
     const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
-    a = __builtin_bit_cast(float, r[0]);
-    b = __builtin_bit_cast(float, r[1]);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
 }
 #endif
 // all 64 lanes of the wave must be active.  Host (tests/emul): a no-op -- the emulation moves the values between its thread states itself
@@ -580,6 +584,12 @@ MW_HD void wave_transpose4(cf (&x)[P]) {
 // behind it runs inside the wave); load_last_regs is the matching "input of the final pass"
 template <int N, int P>
 struct LastStays { static constexpr bool value = LastInRegs<N, P>::value || LastInWave<N, P>::value; };
+// THE predicate "radix-P pass s leaves its results in registers": the phase functions (p2_mid_store / p2_last_load, p1_finish, the halo and
+// chirp-z transforms) and the kernels' barrier elision all ask this one function, so a caller cannot skip the LDS write and still read
+// the exchange afterwards.  A kernel that keeps its barriers anyway (ping-pong buffers, MW_DBUF) stays correct: the phase
+// functions alone decide where the data is.
+template <int N, int P>
+MW_HD constexpr bool mw_pass_in_regs(int s) { return LastStays<N, P>::value && s == FftGeom<N, P>::S - 1; }
 template <int N, int P, int SGN, bool ALLOW_POW = true>
 MW_HD void stage_last_regs(cf (&x)[P], int u, const Twiddles& tw, int s) {
     stage_regs<N, P, SGN, ALLOW_POW>(x, u, tw, s);

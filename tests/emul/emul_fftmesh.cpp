@@ -156,7 +156,7 @@ void run_pass2_hs(const P2Args& A, int nsteps) {
                     }
                     for (int s = 1; s < FftGeom<N, P>::S; s++) {
                         for (int u = 0; u < T; u++) load_slots<N, P>(st[u].x, u, lds.data(), s - 1);
-                        const bool in_regs = LastStays<N, P>::value && s == FftGeom<N, P>::S - 1;  // as k_pass2_hs's halo transform
+                        const bool in_regs = mw_pass_in_regs<N, P>(s);  // as k_pass2_hs's halo transform
                         for (int u = 0; u < T; u++) {
                             if (in_regs) stage_last_regs<N, P, +1>(st[u].x, u, tw, s);
                             else stage_store<N, P, +1>(st[u].x, u, lds.data(), tw, s);
@@ -198,7 +198,7 @@ void run_pass2_frame(const P2Args& A, int nsteps) {
                 else { p2_hs_halo_fetch<N, P, R2>(A, ab, step, tl, t.x); stage0_store<N, P, +1>(t.x, tl, mine); }
             });
             for (int s = 1; s < FftGeom<N, P>::S; s++) {
-                const bool in_regs = LastStays<N, P>::value && s == FftGeom<N, P>::S - 1;
+                const bool in_regs = mw_pass_in_regs<N, P>(s);
                 each([&](int fg, int tl, St& t, cf* mine) {
                     if (fg < 3) p2_mid_load<N, P, R2>(tl, s, t.x, mine); else load_slots<N, P>(t.x, tl, mine, s - 1);
                 });
