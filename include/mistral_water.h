@@ -124,7 +124,10 @@ mw_status mw_ocean_get_spectrum(mw_ocean* o, float* h0_xy, float* h0conj_xy);
  *    SetParams (:163) and never again.
  *  FFTMesh semantics = the spectrum fill of GenerateMesh (S/FFTMesh.cs:114-116) with a new seed (the `generate` tick
  *    draws fresh UnityEngine.Random values, :62-68); the timer is not touched (mw_ocean_reset_timer does that).  The grid
- *    must stay on the same evaluation path: MW_ESTATE if the new length flips unit_width == length / N.              */
+ *    must stay on the same evaluation path: MW_ESTATE if the new length flips unit_width == length / N.
+ *  The call is synchronous and transactional: the new spectrum is generated into buffers of its own (the handle transiently holds
+ *  two spectra: 2 x N^2 x 8 B more, 268 MB at 4096^2), the derived tables -- and for non-FFT grids the chirp tables of the new
+ *  length -- are rebuilt, the stream is drained, and only then are the old buffers freed (hipFree: a device-wide synchronisation).  */
 mw_status mw_ocean_reinit_spectrum(mw_ocean* o, float length, float wind_x, float wind_y, float amplitude, uint64_t seed);
 
 /* Save / restore the animation state.  OceanRenderer: the current phase texture (F/Dispersion.shader:32-41), M*M floats,

@@ -1,4 +1,4 @@
-"""Prints one line per bench JSON file: value, us/step, roofline achieved / frac, parity (tools/bench_direct.sh, bench_all.sh)."""
+"""Prints one line per bench JSON file: value, us/step, roofline achieved / frac, parity (tools/bench_direct.sh, tools/profile_round.sh)."""
 import json
 import sys
 

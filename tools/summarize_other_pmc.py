@@ -1,4 +1,4 @@
-"""Condenses the renderer/pond PMC passes of tools/profile_r1.sh: mean 2*FETCH_SIZE and WRITE_SIZE (KiB) per launch and kernel.
+"""Condenses the renderer/pond PMC passes of tools/prof_workload.sh: mean 2*FETCH_SIZE and WRITE_SIZE (KiB) per launch and kernel.
 usage: python tools/summarize_other_pmc.py gpurun_out/prof_<tag> profiles/r01_other_pmc.json"""
 import csv, glob, json, os, sys
 from collections import defaultdict
