@@ -93,11 +93,6 @@ __global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos,
 // from the host in the kernel arguments), joined by the angle-addition formulas: 7 FMAs per vertex, wave and step instead
 // of a sincos.  The positions are read once per launch; per step only the 12-B result leaves.
 #define MW_GERSTNER_PHASES 256  // nsteps * nwaves per launch (2 KiB of kernel arguments)
-#ifndef MW_POND_PACKED
-#define MW_POND_PACKED 0  // 1: two vertices of a lane per v_pk_* instruction in k_gerstner_steps.  Measured round 5 (profiles/r05_ab_notes.md): the
-                          // packed form halves the VALU instructions of the step loop (224 -> 120) but takes 146 instead of 123 VGPRs (3 instead
-                          // of 4 waves per SIMD) and is no faster (76-79 against 71-77 us per 32-step launch): off
-#endif
 #ifndef MW_POND_STEPS_PER_WG
 #define MW_POND_STEPS_PER_WG 8  // time values per workgroup of k_gerstner_steps (environment MW_POND_STEPS_PER_WG overrides: A/B)
 #endif
@@ -109,9 +104,7 @@ MW_HD void gerstner_position_part(const GerstnerWaves& wv, float frequency, floa
 #pragma unroll
     for (int i = 0; i < NW; i++) mw_sincos_fast(frequency * (wv.dx[i] * px + wv.dy[i] * pz), &sa[i], &ca[i]);
 }
-// V = float (one vertex; the host emulation and the scalar tails) or a 2-float vector (two vertices of a lane at once: the device kernel
-// -- the same expression then compiles to v_pk_mul_f32 / v_pk_fma_f32 with the uniform cb, sb broadcast, half the VALU instructions;
-// round 5: the launch was VALU-co-limited, ~60 instructions per vertex-step against 12 B stored)
+// V = float, or a 2-float vector (two vertices of a lane per v_pk_* instruction: the round-5 experiment, no faster -- see the note below)
 template <int NW, class V>
 MW_HD void gerstner_step_vertex(const GerstnerWaves& wv, const GerstnerPhases& ph, int step, float amplitude, float steepness,
                                 const V (&sa)[NW], const V (&ca)[NW], V px, V py, V pz, V* o) {
@@ -167,33 +160,8 @@ __global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict_
             v[3 * k] = p[0]; v[3 * k + 1] = p[1]; v[3 * k + 2] = p[2];
             gerstner_position_part<NW>(wv, frequency, v[3 * k], v[3 * k + 2], sa[k], ca[k]);
         }
-#if MW_POND_PACKED
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        v2f sa2[2][NW], ca2[2][NW];
-#pragma unroll
-        for (int kp = 0; kp < 2; kp++)
-#pragma unroll
-            for (int i = 0; i < NW; i++) {
-                sa2[kp][i] = v2f{sa[2 * kp][i], sa[2 * kp + 1][i]};
-                ca2[kp][i] = v2f{ca[2 * kp][i], ca[2 * kp + 1][i]};
-            }
-#endif
         for (int step = step_lo; step < step_hi; step++) {
             float* dst = out + (size_t)step * nverts * 3 + 3 * v0;
-#if MW_POND_PACKED
-#pragma unroll
-            for (int kp = 0; kp < 2; kp++) {  // vertices 2 kp, 2 kp + 1 of the lane side by side in the two halves of v_pk_* operands
-                v2f o[3];
-                gerstner_step_vertex<NW, v2f>(wv, ph, step, amplitude, steepness, sa2[kp], ca2[kp], v2f{v[6 * kp], v[6 * kp + 3]},
-                                              v2f{v[6 * kp + 1], v[6 * kp + 4]}, v2f{v[6 * kp + 2], v[6 * kp + 5]}, o);
-#pragma unroll
-                for (int e = 0; e < 2; e++)
-                    if (ok[2 * kp + e]) {
-                        float* q = dst + 3 * ((2 * kp + e) * 64 + lane);
-                        mw_store_stream<true>(&q[0], o[0][e]); mw_store_stream<true>(&q[1], o[1][e]); mw_store_stream<true>(&q[2], o[2][e]);
-                    }
-            }
-#else
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 float o[3];
@@ -203,85 +171,17 @@ __global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict_
                     mw_store_stream<true>(&q[0], o[0]); mw_store_stream<true>(&q[1], o[1]); mw_store_stream<true>(&q[2], o[2]);
                 }
             }
-#endif
         }
     }
 }
 #endif
 
-#if defined(__HIPCC__)
-// ---- the step loop on the matrix cores (round 5) ------------------------------------------------------------------------------------
-// k_gerstner_steps is VALU-bound, not store-bound: 56 VALU instructions per vertex and step (rocprofv3: SQ_ACTIVE_INST_VALU x 4 = 84 % of
-// the SIMD cycles of a launch) against 12 B stored.  But the angle addition makes the offsets BILINEAR in the per-vertex vector
-// V = (cos a_i, sin a_i)_i (a_i = frequency dir_i . x, 2 NW values) and per-step coefficients that are the same for every vertex:
-//     sx(step)   = sum_i cos a_i (A_i cos b_i) + sin a_i (-A_i sin b_i),   A_i = steepness amplitude dir_i.x     (W/MistralWaterLib.cginc:86)
-//     sz(step)   =       the same with dir_i.y                                                                    (:87)
-//     amp sy(step) = sum_i cos a_i (amplitude sin b_i) + sin a_i (amplitude cos b_i),  b_i = t_step speed_i        (:88)
-// i.e. Out[(step, component)][vertex] = M[(step, component)][2 NW] . V[2 NW][vertex]: a matrix product with K = 2 NW = 16 whose left
-// factor has 4 rows per time value (x, y, z, one zero row).  Eight time values are exactly the 32 rows of v_mfma_f32_32x32x2_f32; a wave
-// takes 32 vertices per tile: lanes l and l + 32 both own vertex l % 32 and form the sines of HALF of its waves each (the B operand wants
-// K index 2 t + l / 32 from lane l), NW MFMAs per tile, and the accumulator layout hands lane l the complete (x, y, z) of its vertex for the
-// four time values 2 q + l / 32 -- one dwordx3 store each, 32 lanes = 384 contiguous bytes.  The VALU is left with the 8 hardware sines per
-// vertex and tile group and three adds per vertex and step; float32 MFMA is an fma chain in k order, i.e. the same arithmetic as the VALU
-// form up to the order of the sum (inside the stated 8e-6, tests/test_gpu_parity.py::test_gerstner_time_batched).  The pond is not the
-// FFT path BASELINE's "no MFMA" speaks of: this IS a GEMM-shaped inner loop.
-typedef float mw_f16v __attribute__((ext_vector_type(16)));
-template <int NW>
-__global__ __launch_bounds__(256) void k_gerstner_steps_mfma(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts,
-                                                             GerstnerWaves wv, GerstnerPhases ph, int nsteps, float amplitude,
-                                                             float frequency, float steepness) {
-    constexpr int HW = NW / 2;  // waves whose sines one half of the lanes forms
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, j = lane & 31;
-    const int step_lo = (int)blockIdx.y * 8;
-    // A operand: row j of M = (time value step_lo + j / 4, component j % 4), K = 2 t + h  <->  wave i = HW h + t / 2, cos (t even) / sin (t odd)
-    float a[NW];
-    {
-        const int comp = j & 3, step = step_lo + (j >> 2);
-        const bool live = comp < 3 && step < nsteps;
-        const float sam = steepness * amplitude;
-#pragma unroll
-        for (int m = 0; m < HW; m++) {
-            const int i = HW * h + m;
-            const float cb = live ? ph.cb[step * NW + i] : 0.f, sb = live ? ph.sb[step * NW + i] : 0.f;
-            const float dxi = h ? wv.dx[HW + m] : wv.dx[m], dyi = h ? wv.dy[HW + m] : wv.dy[m];
-            const float Ai = sam * (comp == 0 ? dxi : dyi);
-            a[2 * m] = comp == 1 ? amplitude * sb : Ai * cb;       // coefficient of cos a_i
-            a[2 * m + 1] = comp == 1 ? amplitude * cb : -(Ai * sb);  // coefficient of sin a_i
-        }
-    }
-    for (int64_t v0 = ((int64_t)blockIdx.x * 4 + wave) * 256; v0 < nverts; v0 += (int64_t)gridDim.x * 1024) {  // wave-uniform chunk of 256 vertices
-#pragma unroll 2
-        for (int tile = 0; tile < 8; tile++) {
-            const int64_t vid = v0 + tile * 32 + j;
-            if (v0 + tile * 32 >= nverts) break;  // wave-uniform
-            const bool ok = vid < nverts;
-            const float* p = pos + 3 * (ok ? vid : v0);
-            const float px = p[0], py = p[1], pz = p[2];
-            float b[NW];
-#pragma unroll
-            for (int m = 0; m < HW; m++) {
-                const float dxi = h ? wv.dx[HW + m] : wv.dx[m], dyi = h ? wv.dy[HW + m] : wv.dy[m];
-                mw_sincos_fast(frequency * (dxi * px + dyi * pz), &b[2 * m + 1], &b[2 * m]);
-            }
-            mw_f16v acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < NW; t++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
-            // accumulator slot r of lane l: row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32  ->  time value step_lo + 2 (r / 4) + h, component r % 4
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int step = step_lo + 2 * q + h;
-                if (ok && step < nsteps) {
-                    float* o = out + ((size_t)step * nverts + vid) * 3;
-                    mw_store_stream<true>(&o[0], px + acc[4 * q]);
-                    mw_store_stream<true>(&o[1], py + acc[4 * q + 1]);
-                    mw_store_stream<true>(&o[2], pz + acc[4 * q + 2]);
-                }
-            }
-        }
-    }
-}
-#endif
-
+// Round 5 measured what bounds this kernel (profiles/r05_ab_notes.md).  The VALU is busy 84 % of a launch (SQ_ACTIVE_INST_VALU), and yet
+// neither halving the step loop's instructions (two vertices per v_pk_* instruction: MW_POND_PACKED) nor taking the step loop off the
+// VALU altogether -- the offsets are bilinear in (cos a_i, sin a_i) and per-step coefficients, i.e. a K = 2 NW matrix product, built on
+// v_mfma_f32_32x32x2_f32 with 8 time values = the 32 rows of a tile, parity green, commit 08cea07 -- changed the launch time (82 against
+// 77 us): the launch waits for its 384 MB of result stores (4.9-5.5 TB/s of pure writes into 32 slabs; the box's best single write stream is
+// 6.8), the arithmetic hides under them.  Neither is in the tree.
 #if defined(__HIPCC__)
 // nsteps time values in one launch; nwaves must be 4 or 8 and nsteps * nwaves <= MW_GERSTNER_PHASES (the caller checks)
 static inline hipError_t gerstner_launch_steps(const float* d_pos, int64_t nverts, const float* waves, int nwaves, float amplitude,
@@ -303,18 +203,6 @@ static inline hipError_t gerstner_launch_steps(const float* d_pos, int64_t nvert
     int64_t blocks = (nverts + 1023) / 1024;  // 1024 vertices per 256-thread workgroup and trip
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;
-#ifndef MW_POND_MFMA
-#define MW_POND_MFMA 1  // the step loop as a K = 2 NW matrix product on the matrix cores (environment MW_POND_MFMA=0: the VALU form, A/B)
-#endif
-    {
-        const char* me = std::getenv("MW_POND_MFMA");
-        if (me ? std::atoi(me) != 0 : MW_POND_MFMA != 0) {
-            const dim3 grid((unsigned)blocks, (unsigned)((nsteps + 7) / 8));  // 8 time values = the 32 rows of one MFMA tile per workgroup
-            if (nwaves == 4) k_gerstner_steps_mfma<4><<<grid, dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness);
-            else k_gerstner_steps_mfma<8><<<grid, dim3(256), 0, st>>>(d_pos, d_out, nverts, wv, ph, nsteps, amplitude, frequency, steepness);
-            return hipGetLastError();
-        }
-    }
     static const int spw_env = [] { const char* e = std::getenv("MW_POND_STEPS_PER_WG"); return e ? std::atoi(e) : 0; }();
     const int spw = spw_env > 0 ? (spw_env < nsteps ? spw_env : nsteps) : (MW_POND_STEPS_PER_WG < nsteps ? MW_POND_STEPS_PER_WG : nsteps);
 #ifndef MW_POND_XCD
