@@ -19,20 +19,25 @@ def _pcts(v):
     return {"n": n, "mean_us": sum(v) / n / 1e3, "median_us": q(0.5) / 1e3, "p10_us": q(0.1) / 1e3, "p90_us": q(0.9) / 1e3,
             "min_us": v[0] / 1e3, "max_us": v[-1] / 1e3}
 trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
-per = defaultdict(list)
+per = defaultdict(lambda: defaultdict(list))   # kernel -> launch geometry -> [(start, duration)]
 for f in trace:
     for row in csv.DictReader(open(f)):
-        per[row["Kernel_Name"].split("(")[0]].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+        geom = (row.get("Grid_Size_X"), row.get("Grid_Size_Y"), row.get("Grid_Size_Z"))
+        per[row["Kernel_Name"].split("(")[0]][geom].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
 kp = {}
-for k, rows in per.items():
+for k, by_geom in per.items():
+    # bench.py launches a kernel at several sizes (the timed batch size, 1-step launches of the parity gate and the latency figure, 32-step
+    # context launches): the launches of the TIMED size are the geometry with the most launches -- one grid size, one batch size
+    geom, rows = max(by_geom.items(), key=lambda kv: len(kv[1]))
     if len(rows) < 8:
         continue
     rows.sort()
     durs = [d for _, d in rows]
-    big = [d for d in durs if d >= 0.5 * max(durs)]           # the full-batch launches (bench.py also issues 1-step launches)
-    steady = big[len(big) // 4:]                               # time order: the first quarter = preheat + warm-up at ramping clocks
-    kp[k] = {"all_full_size_launches": _pcts(big), "after_warmup": _pcts(steady),
-             "note": "after_warmup = the full-size launches in time order with the first 25 % dropped"}
+    steady = durs[len(durs) // 4:]                             # time order: the first quarter = preheat + warm-up at ramping clocks
+    kp[k] = {"grid_size": geom, "all_launches_of_this_size": _pcts(durs), "after_warmup": _pcts(steady),
+             "other_sizes": {"x".join(str(g) for g in gg): len(v) for gg, v in by_geom.items() if gg != geom},
+             "note": "the launch geometry with the most launches (= the timed batch size); after_warmup = those launches in time order with "
+                     "the first 25 % dropped"}
 if kp:
     json.dump({"source": src, "kernels": kp}, open(dst + "_kernel_pcts.json", "w"), indent=1)
 bench_line = [l for l in open(os.path.join(src, "bench_stdout.txt")) if l.startswith("{")]
