@@ -180,10 +180,24 @@ def _d2h(ptr, nfloats):
     return out
 
 
+@pytest.fixture(params=["1", "0"], ids=["rccl_self_send", "device_local_copy"])
+def gather_path(request):
+    """Tiles that live on the root's device are copied, not sent (round 5); MW_TILES_FORCE_RCCL=1 sends them through the one-rank
+    communicator as round 4 did, so that ncclSend / ncclRecv stay exercised on the 1-GPU box.  Both must deliver the same bytes."""
+    import os
+    old = os.environ.get("MW_TILES_FORCE_RCCL")
+    os.environ["MW_TILES_FORCE_RCCL"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("MW_TILES_FORCE_RCCL", None)
+    else:
+        os.environ["MW_TILES_FORCE_RCCL"] = old
+
+
 @pytest.mark.parametrize("ntiles", [1, 3])
-def test_tiles_evaluate_and_rccl_gather(mw, ntiles):
+def test_tiles_evaluate_and_rccl_gather(mw, ntiles, gather_path):
     """Tiles on device 0 (a 1-GPU box): the gather runs over a one-rank RCCL communicator (self send/receive) on the side
-    stream; the root buffer must equal every tile's own outputs bit for bit, and tile k must be the ocean of seed + k."""
+    stream, or as a device-local copy; the root buffer must equal every tile's own outputs bit for bit, and tile k must be the ocean of seed + k."""
     p = workloads.fftmesh_params(128)
     NN = 128 * 128
     times = [0.5, 1.0, 2.5]
@@ -219,7 +233,7 @@ def test_tiles_evaluate_and_rccl_gather(mw, ntiles):
     assert e.value.status == mw.MW_EINVAL
 
 
-def test_gather_sends_from_alternating_output_sets_without_a_snapshot(mw):
+def test_gather_sends_from_alternating_output_sets_without_a_snapshot(mw, gather_path):
     """Round 5: a gathered FFTMesh tile owns two output sets.  The gather reads the set the latest evaluate wrote (no copy on the compute
     stream), the next evaluate fills the other one, and an evaluate that comes back to a set waits for the sends that read it: six
     batches with a gather each, never synchronised in between -- every gathered step must be its own batch's, bit for bit."""
@@ -289,7 +303,7 @@ def test_baseline_config3_eight_1024_tiles_gathered_on_one_device(mw):
             assert not (got[k, :NN * 3] == got[0, :NN * 3]).all()    # the tiles ARE different oceans
 
 
-def test_tiles_per_process_form_with_one_rank(mw):
+def test_tiles_per_process_form_with_one_rank(mw, gather_path):
     """mw_tiles_create_rank (the torch.distributed.run launch): unique id -> ncclCommInitRank; world of one rank here."""
     p = workloads.fftmesh_params(64)
     NN = 64 * 64
@@ -427,7 +441,7 @@ def test_reinit_spectrum_fftmesh_regenerates_in_place(mw, oracle):
 
 
 @pytest.mark.parametrize("ntiles", [1, 2])
-def test_oceanrenderer_tiles_and_rccl_gather(mw, ntiles):
+def test_oceanrenderer_tiles_and_rccl_gather(mw, ntiles, gather_path):
     """OceanRenderer semantics behind mw_tiles_* (tile axis only: the phase recurrence F/FFTCommon.cginc:101-104 serialises
     time): tile k is, bit for bit, the single handle of seed + k, frame after frame, and the gathered buffer carries the four
     result textures of every tile."""
