@@ -14,7 +14,7 @@ process instead of trusting every array expression:
 MW_HOST_MEM_CAP_GB (default 48) sets the cap, MW_MEMGUARD=off disables the guard.
 
 The cap is per PROCESS.  Under a launcher with several local ranks (torch.distributed.run sets LOCAL_WORLD_SIZE) the default cap is
-divided by the number of local ranks (not below 8 GiB), so that the ranks TOGETHER stay near the allowance of one process; an explicit
+divided by the number of local ranks (not below 12 GiB), so that the ranks TOGETHER stay near the allowance of one process; an explicit
 MW_HOST_MEM_CAP_GB is taken as given.  When the watchdog ends a rank it does so with os._exit: no HIP / RCCL teardown runs, and peer
 ranks blocked in a collective stay blocked until their own timeout (bench.py bounds the communicator bootstrap with
 MW_BENCH_TILES_TIMEOUT; the driver bounds the run) -- a dead box would have been worse.
@@ -43,7 +43,7 @@ def install(cap_gb: float | None = None) -> str:
             local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
         except ValueError:
             local = 1
-        cap_gb = max(8.0, 48.0 / local)      # (a rank with torch + the ROCm runtime + the parity gate's f64 arrays sits at 3-5 GiB)
+        cap_gb = max(12.0, 48.0 / local)      # (a rank with torch + the ROCm runtime + the parity gate's f64 arrays sits at 3-5 GiB)
     cap = int(float(cap_gb if cap_gb is not None else os.environ["MW_HOST_MEM_CAP_GB"]) * 2**30)
     if mode in ("data", "as"):
         import resource
