@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Prints the DESIGN.md section-7 table from the committed round files (profiles/<round>_bench_*.json, <round>_*_pmc.json)."""
 import json, os, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 def J(name):
     return json.load(open(os.path.join(P, f"{R}_{name}.json")))
