@@ -59,3 +59,33 @@ def test_metric_and_bytes_are_baselines():
     base = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "BASELINE.json")))
     assert bench.BASELINE_METRIC == base["metric"]
     assert bench.BYTES_PER_POINT == 92 and bench.BYTES_PASS1 + bench.BYTES_PASS2 == 92      # SURVEY.md 8d canonical figure
+
+
+def test_pass1_counters_are_only_scaled_across_equal_time_groups(tmp_path, monkeypatch):
+    """a counter pass of another batch size is quoted PER STEP only for kernels whose workgroups are independent per time-step
+    (pass 2).  Pass 1 reads the spectrum once per time GROUP (5 at 20 steps per launch, 8 at 32): its counters are quoted from another batch
+    size only when the group size is the same, and the line says which pass was scaled (`scaled_from_b`)."""
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    rec = {"bench_line": {"build_id": "b", "config": {"pass1_time_group": 8}},
+           "pmc_mean_per_launch": {"void k_pass2_hs<1024, 16, 4, 2, false, 0>": {"FETCH_SIZE": 1000.0, "WRITE_SIZE": 3000.0},
+                                   "void k_pass1<1024, 16, 1, false>": {"FETCH_SIZE": 10.0, "WRITE_SIZE": 30.0}}}
+    (tmp_path / "profiles" / f"{bench.PROFILE_ROUND}_ocean1024_b32_pmc.json").write_text(json.dumps(rec))
+    r2 = bench.pmc_traffic_ex("ocean1024", 20, "k_pass2", "b")
+    assert r2["scaled_from_b"] == 32 and r2["traffic"] == (2 * 1000.0 + 3000.0) * 1024.0 * 20 / 32
+    r1 = bench.pmc_traffic_ex("ocean1024", 20, "k_pass1", "b", tgroup=5)          # 20 steps group by 5, the pass was taken at 8
+    assert r1["traffic"] is None and "time group" in r1["note"]
+    r1 = bench.pmc_traffic_ex("ocean1024", 16, "k_pass1", "b", tgroup=8)          # 16 steps group by 8 like the pass: scaled
+    assert r1["scaled_from_b"] == 32 and r1["traffic"] == (2 * 10.0 + 30.0) * 1024.0 * 16 / 32
+    r1 = bench.pmc_traffic_ex("ocean1024", 32, "k_pass1", "b", tgroup=8)          # a pass at exactly this batch size: as measured
+    assert r1["scaled_from_b"] is None and r1["traffic"] == (2 * 10.0 + 30.0) * 1024.0
+
+
+def test_repeats_scale_to_a_minimum_of_timed_work():
+    """five 0.27-ms regions were 1.4 ms of evidence.  R = max(--repeats, ceil(min_timed_ms / region))."""
+    assert bench.scaled_repeats(0.27e-3, 5, 50.0) == 186
+    assert bench.scaled_repeats(8.2e-3, 5, 50.0) == 7
+    assert bench.scaled_repeats(0.5, 5, 50.0) == 5                  # long regions: --repeats decides
+    assert bench.scaled_repeats(1e-9, 5, 50.0) == 2000              # capped
+    st = bench.pcts([5.0, 1.0, 3.0, 2.0, 4.0])
+    assert (st["median"], st["min"], st["max"], st["n"]) == (3.0, 1.0, 5.0, 5) and st["p10"] <= st["median"] <= st["p90"]
