@@ -117,6 +117,7 @@ public static class MistralWaterNative
     [DllImport(Lib)] public static extern int mw_tiles_local_count(IntPtr tiles);
     [DllImport(Lib)] public static extern IntPtr mw_tiles_ocean(IntPtr tiles, int localK);
     [DllImport(Lib)] public static extern Status mw_tiles_evaluate(IntPtr tiles, float[] times, int nsteps, uint flags);
+    // the outputs of the LATEST mw_tiles_evaluate: a tile that is gathered owns two output sets used alternately -- ask again after every evaluate once mw_tiles_gather is in use
     [DllImport(Lib)] public static extern Status mw_tiles_outputs(IntPtr tiles, int localK, out IntPtr dVertices, out IntPtr dNormals, out IntPtr dWhite);
     [DllImport(Lib)] public static extern Status mw_tiles_generate_texture(IntPtr tiles, float deltaTime);
     [DllImport(Lib)] public static extern Status mw_tiles_textures(IntPtr tiles, int localK, out IntPtr dHeight, out IntPtr dDispXZ, out IntPtr dNormal, out IntPtr dWhite);
