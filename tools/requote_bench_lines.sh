@@ -2,7 +2,7 @@
 # After `cp gpurun_out/profiles_<tag>/* profiles/`: take the bench lines that quote roofline.traffic once more, now that the counter
 # files of THIS build are in place (inside profile_round.sh they were taken before the files existed: traffic null).
 #   gpurun --timeout 1200 -- 'bash tools/requote_bench_lines.sh r04'   then copy gpurun_out/profiles_<tag>/*bench* back again
-tag=${1:-r04}
+tag=${1:-r05}
 P=gpurun_out/profiles_${tag}; mkdir -p $P
 timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $P/${tag}_bench_ocean1024_driver_k20.json
 timeout 300 python bench.py --steps 640 --warmup 64 --no-cpu-baseline 2>/dev/null | tail -1 > $P/${tag}_bench_ocean1024_b32_steps640.json
