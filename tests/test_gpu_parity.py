@@ -162,6 +162,50 @@ def test_fftmesh_parity_after_an_hour(mw, oracle):
             workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"t={t}")
 
 
+@pytest.mark.parametrize("case", ["calm", "negative_time", "no_chop", "inverted_chop", "moon_gravity", "tiny_patch", "huge_patch"])
+def test_fftmesh_edge_parameters(mw, oracle, case):
+    """The corners of FFTMesh's Inspector space on the FFT path (256^2 and the headline's 1024^2), device spectrum generation included:
+    a calm sea (wind (0, 0): Phillips' l = w^2 / g = 0, exp(-1 / 0) = 0 -- S/FFTMesh.cs:149-166 -- the spectrum and every output are exactly
+    flat), negative time (EvaluateWaves accepts any float, :224), choppiness 0 and negative (:244-245), another gravity (the quantised
+    dispersion changes its floor, :141-147), a patch of 4 m and of 40 km (k spans 1e-4 .. 1e3 rad/m; length = N * unit_width stays commensurate)."""
+    for N in (256, 1024):
+        kw = dict(N=N, unit_width=1.0, length=float(N), wind_x=12.0, wind_y=-7.0, amplitude=2e-4, choppiness=0.8, gravity=9.81)
+        t = 2.75
+        if case == "calm":
+            kw.update(wind_x=0.0, wind_y=0.0)
+        elif case == "negative_time":
+            t = -123.456
+        elif case == "no_chop":
+            kw.update(choppiness=0.0)
+        elif case == "inverted_chop":
+            kw.update(choppiness=-1.3)
+        elif case == "moon_gravity":
+            kw.update(gravity=1.62)
+        elif case == "tiny_patch":
+            kw.update(unit_width=4.0 / N, length=4.0, amplitude=2e-9)
+        elif case == "huge_patch":
+            kw.update(unit_width=40000.0 / N, length=40000.0, amplitude=2e-2, wind_x=30.0, wind_y=5.0)
+        p = oracle.Params(**kw)
+        assert p.commensurate
+        h0, h0c = oracle.generate_spectrum(p, 17)
+        rest = oracle.rest_mesh(p)[0]
+        with make(mw, p, seed=17) as o:
+            assert o.max_batch > 1, "FFT path expected"
+            g0, g0c = o.get_spectrum()
+            sc = max(float(np.abs(h0).max()), 1e-30)
+            assert np.isfinite(g0).all() and np.isfinite(g0c).all()
+            assert np.abs(g0 - h0).max() <= 4e-6 * sc and np.abs(g0c - h0c).max() <= 4e-6 * sc, (case, N)
+            o.set_spectrum(h0, h0c)
+            v, n, c = o.evaluate(t)
+        assert np.isfinite(v).all() and np.isfinite(n).all() and np.isfinite(c).all(), (case, N)
+        if case == "calm":
+            assert (h0 == 0).all() and (v == rest).all() and (n == np.array([0, 1, 0], np.float32)).all() and (c == 0).all()
+            continue
+        vf, nf, cf, hds = oracle.eval_fft_f64(p, h0, h0c, np.float32(t), return_hds=True)
+        workloads.assert_parity(v, n, c, vf, nf, cf, rest, np.abs(hds).max(), tag=f"{case} N={N}", hds=hds, min_decided=0.5)
+        assert np.abs(v - rest).max() > 0, "a non-trivial sea"
+
+
 @pytest.mark.parametrize("N", [2048, 4096])
 def test_fftmesh_large_grids(mw, oracle, N):
     """BASELINE config 4 (4096^2): parity at full size against the numpy-FFT f64 oracle."""
@@ -586,6 +630,43 @@ def test_gerstner_time_batched(mw, oracle):
     with pytest.raises(mw.MistralWaterError) as e:     # 33 steps of 8 waves exceed the phase table
         mw.gerstner_displace_steps_device(dp.data_ptr(), 3, W, 0.1, 2.58, 0.99, [0.0] * 33, do.data_ptr())
     assert e.value.status == mw.MW_EINVAL
+
+
+def test_gerstner_edge_parameters(mw, oracle):
+    """Corners of the pond's Gerstner() (W/MistralWaterLib.cginc:71-99): amplitude 0 (the lattice comes back bit for bit: every offset is a
+    product with steepness * amplitude = 0), steepness 0 (only the vertical term moves), negative time and an hour of it (the phase
+    t * speed reaches 1e4 rad: the hardware sine after an exact reduction must hold), one wave, and the two entry points agreeing with each
+    other to the angle-addition rounding."""
+    import torch
+    rng = np.random.default_rng(3)
+    W, P = workloads.pond_waves8(), workloads.POND
+    pos = rng.uniform(-50, 50, (4099, 3)).astype(np.float32)
+    out = mw.gerstner_displace(pos, W, 0.0, P["frequency"], P["steepness"], 1.25)
+    assert (out == pos).all()
+    out = mw.gerstner_displace(pos, W, P["amplitude"], P["frequency"], 0.0, 1.25)
+    assert (out[:, 0] == pos[:, 0]).all() and (out[:, 2] == pos[:, 2]).all() and np.abs(out[:, 1] - pos[:, 1]).max() > 0
+    def bound(wv, t):
+        # the shader's phase theta = frequency * dot(dir, x) + t * speed is FLOAT32 (W/MistralWaterLib.cginc:80-84, `half` = f32 on desktop),
+        # the oracle's f64: each of theta's roundings (the product t * speed, the sum) moves it by up to half an ulp of |theta|, and an
+        # offset moves by at most its amplitude times that, per wave
+        wv = np.asarray(wv, np.float64).reshape(-1, 3)
+        th = np.abs(P["frequency"] * (wv[:, 0] * 50.0 * 1.0 + np.abs(wv[:, 1]) * 50.0)) + abs(t) * np.abs(wv[:, 2])
+        ulp = float(np.spacing(np.float32(th.max())))
+        return 2e-5 + 8e-6 + len(wv) * max(P["amplitude"], P["amplitude"] * P["steepness"]) * 1.5 * ulp
+    for t in (-7.5, 3600.0, -3600.0):
+        for wv in (W, W[:1]):
+            got = mw.gerstner_displace(pos, wv, P["amplitude"], P["frequency"], P["steepness"], t)
+            want = oracle.gerstner_f64(pos, wv, P["amplitude"], P["frequency"], P["steepness"], np.float32(t))
+            assert np.abs(got - want).max() < bound(wv, t), (t, len(wv), np.abs(got - want).max(), bound(wv, t))
+    dp = torch.from_numpy(pos).cuda()
+    times = [-7.5, 0.0, 3600.0]
+    do = torch.empty((len(times), pos.shape[0], 3), dtype=torch.float32, device="cuda")
+    mw.gerstner_displace_steps_device(dp.data_ptr(), pos.shape[0], W, P["amplitude"], P["frequency"], P["steepness"], times, do.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for k, t in enumerate(times):
+        want = oracle.gerstner_f64(pos, W, P["amplitude"], P["frequency"], P["steepness"], np.float32(t))
+        assert np.abs(do[k].cpu().numpy() - want).max() < bound(W, t), t      # (the batched form's time part is formed in f64 on the host: tighter in practice)
 
 
 def test_pond_unaligned_device_views(mw, oracle):

@@ -214,6 +214,37 @@ def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
 
 
 @pytest.mark.gpu
+def test_gpu_generate_texture_edge_time_steps(mw, oracle):
+    """deltaTime corners of GenerateTexture() (S/OceanRenderer.cs:216-223; F/FFTCommon.cginc:101-104, the stateful fmod phase): a frame with
+    deltaTime = 0 (a paused game: the phase must not move, the textures repeat), a negative step (time scale < 0: fmod of a negative
+    argument keeps its sign in HLSL and in C), a step of ten minutes (omega dt ~ 1e4 rad before the fmod), and mult = 0 (the Inspector's
+    time multiplier, :223) -- the phase texture bit for bit against the oracle's strict-float32 recurrence, the textures at the usual bounds."""
+    for mult in (1.5, 0.0):
+        import dataclasses
+        rp = dataclasses.replace(shipped(32), mult=mult)
+        M = rp.M
+        o = mw.Ocean(resolution=32, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude, choppiness=rp.choppiness,
+                     gravity=rp.gravity, mult=rp.mult, seed=5, semantics=mw.MW_SEM_OCEANRENDERER)
+        init4 = oracle.renderer_initial_spectrum(rp, 5)
+        o.set_spectrum(init4[..., :2], init4[..., 2:])
+        ph = np.zeros((M, M), np.float32)
+        prev = None
+        for dt in (0.02, 0.0, -0.25, 600.0, 0.0):
+            before = ph.copy()
+            h, d, n, w = o.generate_texture(dt)
+            H, D, Nn, W, G = oracle.renderer_step_f64(rp, init4, ph, dt, literal_passes=False)      # advances ph in place
+            assert (o.get_phase() == ph).all(), (mult, dt)                                         # the recurrence: index-like work, exact
+            if dt == 0.0 or mult == 0.0:
+                assert (ph == before).all()
+                if prev is not None:
+                    assert all((a == b).all() for a, b in zip(prev, (h, d, n, w))), "a frame without time must repeat the previous one"
+            tol_check(h, H, 3e-6, "height"); tol_check(d, D, 3e-6, "disp")
+            or_bounds.assert_normal_white(n, w, Nn, W, rp.length, D[..., 0], G, D[..., 1], H, tag=f"mult={mult} dt={dt}")
+            prev = (h, d, n, w)
+        o.close()
+
+
+@pytest.mark.gpu
 def test_gpu_oceanrenderer_lifecycle(mw):
     r = mw.OceanRenderer()
     r.resolution, r.length, r.amplitude, r.choppiness, r.mult = 16, 60.0, 0.41, 0.46, 1.5
