@@ -467,6 +467,26 @@ def test_direct_path_other_grids(mw, oracle, N):
     workloads.assert_parity(v, n, c, vd, nd, cd, rest, rel=4e-5, tag=f"direct N={N}")
 
 
+@pytest.mark.parametrize("N,u,L", [(2, 1.0, 2.0), (3, 1.0, 3.0), (5, 0.7, 4.0), (63, 1.0, 63.0), (64, 1.0, 70.0), (127, 1.0, 127.0),
+                                   (128, 1.1, 128.0), (129, 1.0, 129.0)])
+def test_direct_path_tiny_and_threshold_grids(mw, oracle, N, u, L):
+    """Non-FFT grids at the edges of the chirp-z plans: the smallest meshes a scene can carry (2, 3, 5 vertices per side: transform size 64,
+    most of it zero padding), power-of-two sizes that are NOT commensurate (64 with length 70, 128 with unit width 1.1: the FFT path must
+    refuse them and the separable sum serve them), and the sizes either side of the two-launch / three-launch switch (127, 128 -> M = 256;
+    129 -> M = 512).  Against the f64 oracle's separable sum."""
+    p = oracle.Params(N=N, unit_width=u, length=L, wind_x=4.0, wind_y=-2.5, amplitude=1e-3, choppiness=0.6)
+    h0, h0c = oracle.generate_spectrum(p, 4)
+    rest = oracle.rest_mesh(p)[0]
+    with make(mw, p) as o:
+        assert o.max_batch == 1, "the direct path (one step per enqueue) was expected"
+        o.set_spectrum(h0, h0c)
+        v, n, c = o.evaluate(0.75)
+        kinds = [k for k, _ in o.profile_kernels(nsteps=1, iters=2)]
+    assert ("rows_assemble" in kinds[1]) == (N <= 128), kinds      # two launches up to M = 256, three beyond
+    vd, nd, cd, hds = oracle.eval_matmul_f64(p, h0, h0c, 0.75, return_hds=True)
+    workloads.assert_parity(v, n, c, vd, nd, cd, rest, rel=2e-5, tag=f"direct N={N}", hds=hds, min_decided=0.0)
+
+
 def test_direct_path_inspector_defaults(mw, oracle):
     """S/FFTMesh.cs:13-19: a fresh FFTMesh component has resolution 50, length 1, unitWidth 1, wind (1, 1), amplitude 1 -- not
     commensurate (50 * 1 != 1): the MFMA direct-sum path.  mw_params_default carries exactly these values."""
