@@ -375,6 +375,7 @@ def test_batched_device_steps_equal_single_steps(mw, oracle):
         for ns in (24, 12, 6, 7):
             tt = [0.25 + 0.37 * k for k in range(ns)]
             dv.zero_(); dn.zero_(); dw.zero_()
+            torch.cuda.synchronize()      # the fills run on torch's stream, the handle enqueues on its own non-blocking stream
             o.evaluate_device(tt, dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
             o.synchronize()
             hv, hw = dv.cpu().numpy(), dw.cpu().numpy()
@@ -382,6 +383,35 @@ def test_batched_device_steps_equal_single_steps(mw, oracle):
                 if k not in singles:
                     singles[k] = o.evaluate(tt[k])
                 assert (hv[k] == singles[k][0]).all() and (hw[k] == singles[k][2][:, 0]).all(), (ns, k)
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_every_kind_of_batch_size_equals_single_steps(mw, oracle, N):
+    """Enqueues of 2, 3, 5, 16, 31 and 32 steps (prime sizes take the plain 2-D grid of pass 1, the others time groups of 2 .. 8) at the
+    headline's grid -- where a single step runs the frame plan's kernels and a batch the sequential-halo kernel with the in-wave exchange --
+    and at 2048^2: first and last step of every batch == the same time evaluated alone, bit for bit."""
+    import torch
+    p = workloads.fftmesh_params(N)
+    NN = N * N
+    with make(mw, p, seed=6) as o:
+        dv = torch.empty((32, NN, 3), dtype=torch.float32, device="cuda")
+        dn = torch.empty((32, NN, 3), dtype=torch.float32, device="cuda")
+        dw = torch.empty((32, NN), dtype=torch.float32, device="cuda")
+        singles = {}
+        for ns in (2, 3, 5, 16, 31, 32):
+            tt = [0.125 + 0.61 * k for k in range(ns)]
+            dv.zero_(); dn.zero_(); dw.zero_()
+            torch.cuda.synchronize()      # the fills run on torch's stream, the handle enqueues on its own non-blocking stream
+            o.evaluate_device(tt, dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+            o.synchronize()
+            for k in (0, ns - 1):
+                if k not in singles:
+                    singles[k] = o.evaluate(tt[k])
+                v, n, c = singles[k]
+                assert (dv[k].cpu().numpy() == v).all() and (dn[k].cpu().numpy() == n).all() and (dw[k].cpu().numpy() == c[:, 0]).all(), (ns, k)
+        assert np.abs(singles[0][2]).max() > 0
+    del dv, dn, dw
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("N,K", [(1024, 20), (4096, 32)])
