@@ -111,6 +111,30 @@ def test_reinit_spectrum_fftmesh(mw, oracle):
         assert e.value.status == mw.MW_ESTATE
 
 
+@pytest.mark.parametrize("N", [50, 200])
+def test_reinit_spectrum_on_a_non_fft_grid_rebuilds_the_chirp_tables(mw, oracle, N):
+    """Round 5: the chirp-z tables of a non-FFT grid depend on (unit_width, length) and are uploaded by mw_ocean_create and by
+    mw_ocean_reinit_spectrum -- never lazily inside an enqueue.  After a reinit with a NEW length (two launches at N = 50, three at N = 200) the
+    handle must be the handle a fresh create with those parameters gives, bit for bit, and match the oracle."""
+    old = oracle.Params(N=N, unit_width=1.0, length=float(N) * 0.9, wind_x=4.0, wind_y=2.0, amplitude=5e-4, choppiness=0.7)
+    new = dataclasses.replace(old, length=float(N) * 1.37, wind_x=-3.0, wind_y=6.0, amplitude=8e-4)
+    kw = lambda q, seed: dict(resolution=q.N, unit_width=q.unit_width, length=q.length, wind=(q.wind_x, q.wind_y), amplitude=q.amplitude,
+                              choppiness=q.choppiness, seed=seed)
+    with mw.Ocean(**kw(old, 3)) as o:
+        assert o.max_batch == 1
+        o.evaluate(0.5)                                            # tables of the old length in use
+        o.reinit_spectrum(length=new.length, wind=(new.wind_x, new.wind_y), amplitude=new.amplitude, seed=9)
+        a = o.evaluate(1.25)
+        h0, h0c = o.get_spectrum()
+    with mw.Ocean(**kw(new, 9)) as f:
+        b = f.evaluate(1.25)
+        g0, g0c = f.get_spectrum()
+    assert (h0 == g0).all() and (h0c == g0c).all()
+    assert all((x == y).all() for x, y in zip(a, b)), "reinit + evaluate must equal create + evaluate"
+    vd, nd, cd, hds = oracle.eval_matmul_f64(new, h0, h0c, 1.25, return_hds=True)
+    workloads.assert_parity(a[0], a[1], a[2], vd, nd, cd, oracle.rest_mesh(new)[0], rel=2e-5, tag=f"non-FFT reinit N={N}", hds=hds, min_decided=0.0)
+
+
 def test_mirrors_regenerate_and_render_initial(mw):
     m = mw.FFTMesh(seed=4)
     m.resolution, m.unitWidth, m.length, m.amplitude = 64, 1.0, 64.0, 2e-6
