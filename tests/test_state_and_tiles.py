@@ -135,6 +135,48 @@ def test_reinit_spectrum_on_a_non_fft_grid_rebuilds_the_chirp_tables(mw, oracle,
     workloads.assert_parity(a[0], a[1], a[2], vd, nd, cd, oracle.rest_mesh(new)[0], rel=2e-5, tag=f"non-FFT reinit N={N}", hds=hds, min_decided=0.0)
 
 
+def test_handles_give_their_device_memory_back(mw):
+    """Create / use / destroy, twenty times over every kind of handle (FFT path with a batched and a single-step enqueue, the chirp-z path,
+    OceanRenderer with RGBA targets, tiles with a gather = both output sets + the root buffer): the free device memory after the last destroy
+    is the free memory before the first create (hipMemGetInfo; torch's caching allocator is not involved -- the library allocates with hipMalloc)."""
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+    p = workloads.fftmesh_params(256)
+    kw = dict(resolution=p.N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude, choppiness=p.choppiness)
+    NN = 256 * 256
+    dv = torch.empty((4, NN, 3), dtype=torch.float32, device="cuda"); dn = torch.empty_like(dv); dw = torch.empty((4, NN), dtype=torch.float32, device="cuda")
+
+    def cycle():
+        with mw.Ocean(seed=1, **kw) as o:
+            o.evaluate_device([0.1, 0.2, 0.3, 0.4], dv.data_ptr(), dn.data_ptr(), dw.data_ptr())
+            o.evaluate(0.5)
+            o.reinit_spectrum(seed=2)
+        with mw.Ocean(resolution=50, unit_width=1.0, length=1.0, wind=(1.0, 1.0), amplitude=1.0, choppiness=1.0, seed=1) as o:
+            o.evaluate(0.5)
+        with mw.Ocean(resolution=16, length=54.0, wind=(14.45, 12.0), amplitude=0.41, choppiness=0.46, mult=1.5, seed=1,
+                      semantics=mw.MW_SEM_OCEANRENDERER) as o:
+            o.generate_texture(0.02)
+            o.generate_texture_rgba(0.02)
+        with mw.Tiles(ntiles=2, devices=[0, 0], max_steps=2, seed=3, **kw) as t:
+            t.evaluate([0.5, 1.0])
+            t.gather(step=1, root=0)
+            t.evaluate([1.5, 2.0])
+            t.gather(step=0, root=1)
+            t.synchronize()
+    cycle()                                  # first use: one-time allocations of the runtime / RCCL itself
+    before = free_bytes()
+    for _ in range(20):
+        cycle()
+    after = free_bytes()
+    assert before - after < (8 << 20), f"{(before - after) / 2**20:.1f} MiB did not come back after 20 create / destroy cycles"
+
+
 def test_mirrors_regenerate_and_render_initial(mw):
     m = mw.FFTMesh(seed=4)
     m.resolution, m.unitWidth, m.length, m.amplitude = 64, 1.0, 64.0, 2e-6
