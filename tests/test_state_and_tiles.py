@@ -177,6 +177,45 @@ def test_handles_give_their_device_memory_back(mw):
     assert before - after < (8 << 20), f"{(before - after) / 2**20:.1f} MiB did not come back after 20 create / destroy cycles"
 
 
+def test_two_host_threads_drive_two_handles_at_once(mw, oracle):
+    """The library keeps no unguarded global state: two host threads (ctypes releases the GIL inside every call), each with its own handle on
+    its own stream -- one alternating single steps and 5-step batches on a 512^2 FFT grid, the other stepping a non-FFT grid and the pond's
+    host entry point -- produce exactly what each produces alone."""
+    import threading
+    p = workloads.fftmesh_params(512)
+    kwa = dict(resolution=p.N, unit_width=p.unit_width, length=p.length, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude, choppiness=p.choppiness, seed=4)
+    kwb = dict(resolution=65, unit_width=0.5, length=40.0, wind=(3.0, 2.0), amplitude=1e-3, choppiness=0.8, seed=5)
+    W, P = workloads.pond_waves8(), workloads.POND
+    pos = workloads.pond_lattice(200, seed=1)
+
+    def work_a(out):
+        with mw.Ocean(**kwa) as o:
+            for k in range(12):
+                out.append(o.evaluate(0.1 * (k + 1)))
+
+    def work_b(out):
+        with mw.Ocean(**kwb) as o:
+            for k in range(12):
+                out.append(o.evaluate(0.07 * (k + 1)))
+                out.append((mw.gerstner_displace(pos, W, P["amplitude"], P["frequency"], P["steepness"], 0.3 * k),))
+    ref_a, ref_b, got_a, got_b = [], [], [], []
+    work_a(ref_a); work_b(ref_b)
+    errs = []
+
+    def guarded(fn, out):
+        try:
+            fn(out)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    ta, tb = threading.Thread(target=guarded, args=(work_a, got_a)), threading.Thread(target=guarded, args=(work_b, got_b))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errs, errs
+    for ref, got in ((ref_a, got_a), (ref_b, got_b)):
+        assert len(ref) == len(got)
+        for r, g in zip(ref, got):
+            assert all((x == y).all() for x, y in zip(r, g))
+
+
 def test_mirrors_regenerate_and_render_initial(mw):
     m = mw.FFTMesh(seed=4)
     m.resolution, m.unitWidth, m.length, m.amplitude = 64, 1.0, 64.0, 2e-6
