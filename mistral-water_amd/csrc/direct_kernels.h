@@ -169,40 +169,120 @@ __global__ void k_direct_white(int N, const cf* hds, const float* normals, float
 #ifndef MW_CZT_XCD_GROUP
 #define MW_CZT_XCD_GROUP 1
 #endif
-// one line of one axis: pre-chirp + zero padding, forward transform, kernel product, inverse transform; x = the inverse transform's output
-// (element n = u + T q in slot q), the post-chirp is the caller's.  Barriers inside: every thread of the workgroup must call it.
+// Small transforms (round 5, second pass): a step on these grids is a chain of dependent latencies, not bandwidth -- and up to here every
+// table value was asked for where it is used: the twiddle rows of all passes of both transforms from global memory (an L2 round trip in
+// front of each pass), the kernel's transform after the forward transform's last barrier, the post-chirp after the inverse one.  Now the
+// twiddle tables of both directions are staged in LDS at the top of the kernel (CztTw; published by the first barrier of czt_line) and the
+// kernel's transform / the post-chirp are requested before the first input load, so that ONE memory latency covers them all (M <= 512 only: at
+// M = 2048 the 64 extra registers of the early loads cost a wave per SIMD, N = 1000 98 -> 122 us).  Same table
+// values, same expressions: the same bits (tests/test_zz_frame_plan.py, every direct-path parity test).
+#ifndef MW_CZT_PRELOAD
+#define MW_CZT_PRELOAD 1
+#endif
+#ifndef MW_CZT_STAGE_MAX_M
+#define MW_CZT_STAGE_MAX_M 512  // larger transforms keep their tables in global memory (their LDS decides how many workgroups share a CU)
+#endif
 template <int M, int P>
-__device__ __forceinline__ void czt_line(const CztArgs& A, int f, int row, bool live, int u, cf* buf, cf (&x)[P]) {
-    const Twiddles twf = TwGeom<M, P>::view(A.TWf), twi = TwGeom<M, P>::view(A.TWi);
-    czt_load<M, P>(A, f, live ? row : 0, u, live, x);
+struct CztTw {
+    static constexpr bool STAGE = MW_CZT_PRELOAD && M <= MW_CZT_STAGE_MAX_M && TwGeom<M, P>::IN_LDS;
+    static constexpr int HALF = STAGE ? ((TwGeom<M, P>::LDS_ALL + 1) & ~1) : 0;  // cf entries per direction, 16-B aligned
+    static constexpr int CF = 2 * HALF;                                          // in front of the line buffers
+};
+// the workgroup's share of both tables: requested at the top of the kernel (load), written to LDS behind the requests of the first input
+// row and in front of the first barrier of czt_line_core (store; TwStage's two halves, mw_math.h).  NT_MIN <= the workgroup's thread count.
+template <int M, int P, int NT_MIN>
+struct CztTwRegs {
+    static constexpr int IT = CztTw<M, P>::STAGE ? (TwGeom<M, P>::LDS_CF + NT_MIN - 1) / NT_MIN : 0;
+    cf f[IT > 0 ? IT : 1], b[IT > 0 ? IT : 1];
+    int tid = 0, nthreads = NT_MIN;
+    cf* twl = nullptr;
+    __device__ __forceinline__ void load(const CztArgs& A, cf* twl_, int tid_, int nthreads_) {
+        tid = tid_; nthreads = nthreads_; twl = twl_;
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = tid + k * nthreads;
+            const bool in = i < TwGeom<M, P>::LDS_CF;
+            f[k] = in ? A.TWf[i] : mk(0.f, 0.f);
+            b[k] = in ? A.TWi[i] : mk(0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void operator()() const {
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = tid + k * nthreads;
+            if (i < TwGeom<M, P>::LDS_CF) { twl[i] = f[k]; twl[CztTw<M, P>::HALF + i] = b[k]; }
+        }
+    }
+};
+struct CztNoHook { __device__ __forceinline__ void operator()() const {} };
+// the transforms of a line whose pre-chirped, zero-padded input is in x (x = the inverse transform's output afterwards); hh = the kernel's
+// transform at this thread's slots where STAGE.  Barriers inside: every thread of the workgroup must call it.
+// before_first_barrier: called once in front of the first barrier (the LDS writes of the staged tables)
+template <int M, int P, class Hook>
+__device__ __forceinline__ void czt_line_core(const CztArgs& A, int u, cf* buf, cf (&x)[P], const cf* twl, const cf (&hh)[P], const Hook& before_first_barrier) {
+    constexpr bool ST = CztTw<M, P>::STAGE;
+    constexpr int T = M / P;
+    const Twiddles twf = ST ? TwGeom<M, P>::view(A.TWf, twl) : TwGeom<M, P>::view(A.TWf);
+    const Twiddles twi = ST ? TwGeom<M, P>::view(A.TWi, twl + CztTw<M, P>::HALF) : TwGeom<M, P>::view(A.TWi);
+    // A line's buffer is written and read by the line's own T threads only: where those sit in ONE wave (T <= 64: M <= 512) its exchanges
+    // need that wave's LDS operations in order and no workgroup barrier (the lines drift apart: a dozen barriers less on the dependent
+    // chain of a small-grid step).  The first barrier stays a workgroup barrier: it publishes the staged tables.
+#ifndef MW_CZT_WAVE_SYNC
+#define MW_CZT_WAVE_SYNC 1
+#endif
+    constexpr bool WS = MW_CZT_WAVE_SYNC && T <= 64 && 64 % T == 0;
+    auto line_sync = [&]() {
+        if (WS) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
     stage0_store<M, P, -1>(x, u, buf);
+    before_first_barrier();
     __syncthreads();
 #pragma unroll
     for (int s = 1; s < FftGeom<M, P>::S; s++) {
         const bool in_regs = LastInRegs<M, P>::value && s == FftGeom<M, P>::S - 1;  // M = P^S (4096): no identity round trip through LDS
         load_slots<M, P>(x, u, buf, s - 1);
         if (in_regs) { stage_regs<M, P, -1, false>(x, u, twf, s); continue; }
-        __syncthreads();
+        line_sync();
         stage_store<M, P, -1, false>(x, u, buf, twf, s);
-        __syncthreads();
+        line_sync();
     }
     if (!LastInRegs<M, P>::value) load_last<M, P>(x, u, buf);
     final_stage<M, P, -1>(x, u, twf.TF);
-    czt_mul_kernel<M, P>(A, u, x);
-    __syncthreads();  // every read of the forward transform's last exchange is done
+    if (ST) {
+#pragma unroll
+        for (int q = 0; q < P; q++) x[q] = cmul(x[q], hh[q]);  // czt_mul_kernel's expression
+    } else {
+        czt_mul_kernel<M, P>(A, u, x);
+    }
+    line_sync();  // every read of the forward transform's last exchange is done
     stage0_store<M, P, +1>(x, u, buf);
-    __syncthreads();
+    line_sync();
 #pragma unroll
     for (int s = 1; s < FftGeom<M, P>::S; s++) {
         const bool in_regs = LastInRegs<M, P>::value && s == FftGeom<M, P>::S - 1;
         load_slots<M, P>(x, u, buf, s - 1);
         if (in_regs) { stage_regs<M, P, +1, false>(x, u, twi, s); continue; }
-        __syncthreads();
+        line_sync();
         stage_store<M, P, +1, false>(x, u, buf, twi, s);
-        __syncthreads();
+        line_sync();
     }
     if (!LastInRegs<M, P>::value) load_last<M, P>(x, u, buf);
     final_stage<M, P, +1>(x, u, twi.TF);
+}
+// one line of one axis: pre-chirp + zero padding, forward transform, kernel product, inverse transform; x = the inverse transform's output
+// (element n = u + T q in slot q), the post-chirp is the caller's.  Barriers inside: every thread of the workgroup must call it.
+// twl: where the staged tables will be (CztTwRegs: written by before_first_barrier) where CztTw<M, P>::STAGE
+template <int M, int P, class Hook>
+__device__ __forceinline__ void czt_line(const CztArgs& A, int f, int row, bool live, int u, cf* buf, cf (&x)[P], const cf* twl, const Hook& before_first_barrier) {
+    constexpr int T = M / P;
+    cf hh[P];
+    if (CztTw<M, P>::STAGE) {
+#pragma unroll
+        for (int q = 0; q < P; q++) hh[q] = A.Hh[u + T * q];
+    }
+    czt_load<M, P>(A, f, live ? row : 0, u, live, x);
+    czt_line_core<M, P>(A, u, buf, x, twl, hh, before_first_barrier);
 }
 template <int M, int P, int RW>
 __global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
@@ -220,9 +300,26 @@ __global__ __launch_bounds__((RW * M / P)) void k_czt(CztArgs A) {
     }
     const int tid = threadIdx.x, w = tid / T, u = tid % T, row = rb * RW + w, f = blockIdx.y;
     const bool live = row < A.rows;
+    CztTwRegs<M, P, RW * T> twr;
+    twr.load(A, lds, tid, RW * T);
+    cf w2r[P];
+    if (CztTw<M, P>::STAGE) {
+#pragma unroll
+        for (int q = 0; q < P; q++) w2r[q] = (u + T * q < A.nout) ? A.w2[u + T * q] : mk(0.f, 0.f);
+    }
     cf x[P];
-    czt_line<M, P>(A, f, row, live, u, lds + (size_t)w * BUF, x);
-    if (live) czt_store<M, P>(A, f, row, u, x);
+    czt_line<M, P>(A, f, row, live, u, lds + CztTw<M, P>::CF + (size_t)w * BUF, x, lds, twr);
+    if (!live) return;
+    if (CztTw<M, P>::STAGE) {  // czt_store with the post-chirp already here
+        cf* __restrict__ o = A.out + (size_t)f * A.out_plane + row;
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const int n = u + T * q;
+            if (n < A.nout) o[(size_t)n * A.out_ld] = cmul(x[q], w2r[q]);
+        }
+    } else {
+        czt_store<M, P>(A, f, row, u, x);
+    }
 }
 // Small grids (M <= 256, i.e. N <= 128: the reference's Inspector default N = 50 and its shipped scene N = 12): the SECOND axis and the
 // assembly in ONE launch (round 5; a step is launch latency there -- three launches of a few workgroups, 15.5 us at N = 50).  A workgroup
@@ -241,22 +338,30 @@ __global__ __launch_bounds__(((3 * RW + 2) * M / P)) void k_czt_rows_assemble(Cz
     const int f = gi < 3 * RW ? gi / RW : (gi == 3 * RW ? 0 : 2);         // halo lines: planes 0 (Dx in its imaginary part) and 2 (Dz)
     const int row = gi < 3 * RW ? b0 + gi % RW : b0 + RW;
     const bool live = row < A.rows;
-    cf* buf = lds + (size_t)gi * BUF;
+    CztTwRegs<M, P, NT> twr;
+    twr.load(A, lds, tid, NT);
+    cf* const rows = lds + CztTw<M, P>::CF;
+    cf* buf = rows + (size_t)gi * BUF;
+    cf w2r[P];
+    if (CztTw<M, P>::STAGE) {
+#pragma unroll
+        for (int q = 0; q < P; q++) w2r[q] = (u + T * q < A.nout) ? A.w2[u + T * q] : mk(0.f, 0.f);
+    }
     cf x[P];
-    czt_line<M, P>(A, f, row, live, u, buf, x);
+    czt_line<M, P>(A, f, row, live, u, buf, x, lds, twr);
     __syncthreads();  // the final pass has read its last exchange: the buffer now takes the post-chirped outputs, plain index a
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int n = u + T * q;
-        if (n < A.nout) buf[n] = cmul(x[q], A.w2[n]);  // czt_store's expression
+        if (n < A.nout) buf[n] = cmul(x[q], CztTw<M, P>::STAGE ? w2r[q] : A.w2[n]);  // czt_store's expression
     }
     __syncthreads();
     const OceanConsts& C = A.C;
     const int N = C.N;
-    const cf* P0 = lds;                              // [w][a] = H + i Dx
-    const cf* P1 = lds + (size_t)RW * BUF;           //          Sx + i Sz
-    const cf* P2 = lds + (size_t)2 * RW * BUF;       //          Dz (real part)
-    const cf* H0 = lds + (size_t)3 * RW * BUF;       // row b0 + RW of plane 0
+    const cf* P0 = rows;                              // [w][a] = H + i Dx
+    const cf* P1 = rows + (size_t)RW * BUF;           //          Sx + i Sz
+    const cf* P2 = rows + (size_t)2 * RW * BUF;       //          Dz (real part)
+    const cf* H0 = rows + (size_t)3 * RW * BUF;       // row b0 + RW of plane 0
     const cf* H2 = H0 + BUF;                         //                 plane 2
     for (int e = tid; e < RW * N; e += NT) {         // consecutive lanes -> consecutive b: RW x 12-byte runs
         const int a = e / RW, w = e % RW, b = b0 + w;
@@ -276,6 +381,94 @@ __global__ __launch_bounds__(((3 * RW + 2) * M / P)) void k_czt_rows_assemble(Cz
         const cf z = mk(0.f, 0.f);
         const cf di = hi ? mk(P0[(size_t)w * BUF + a + 1].y, P2[(size_t)w * BUF + a + 1].x) : z;
         const cf dj = hj ? (w + 1 < RW ? mk(P0[(size_t)(w + 1) * BUF + a].y, P2[(size_t)(w + 1) * BUF + a].x) : mk(H0[a].y, H2[a].x)) : z;
+        const float xx = whitecap(mk(dx, dz), di, dj, hi, hj, nx, nz);
+        if (white_stride == 1) white[idx] = xx;
+        else { white[4 * idx] = xx; white[4 * idx + 1] = xx; white[4 * idx + 2] = xx; white[4 * idx + 3] = xx; }
+    }
+}
+// Tiny grids (N <= 20, transform size 64; the reference's shipped scene is N = 12, D/FFT Mesh.unity:147-150): BOTH axes and the assembly in
+// ONE workgroup and ONE launch (round 5) -- the whole step of such a grid is 3 (N + 1) + 3 N lines of 8 threads, and a second dependent launch
+// costs more than one CU loses by doing all of them.  The plane between the axes (TT[p][b][i]) and the output planes live in LDS; every line
+// and every vertex is formed by the expressions of the two-launch plan: the same bits (test_small_grid_fused_czt_equals_three_launches).
+// Measured (us per step back to back, one launch / two): N = 4 6.5 / 8.8, 12 8.2 / 9.4, 16 9.5 / 10.1, 20 10.1 / 10.7, 24 13.5 / 11.8, 32 17.8 / 13.4
+// (the geometry allows any N <= 32).
+#ifndef MW_CZT_ONE_MAX_N
+#define MW_CZT_ONE_MAX_N 20
+#endif
+template <int M, int P>
+__global__ __launch_bounds__(1024) void k_czt_one(CztArgs A, cf* hds, float* vertices, float* normals, float* white, int white_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = M / P, BUF = FftGeom<M, P>::LBUF + 4;
+    static_assert(BUF >= M, "a line's exchange buffer holds its post-chirped outputs afterwards");
+    const OceanConsts& C = A.C;
+    const int N = C.N, N1 = N + 1;
+    const int tid = threadIdx.x, nthreads = blockDim.x, gi = tid / T, u = tid % T;
+    cf* const TT = lds + CztTw<M, P>::CF;                       // [p][b][i], N + 1 entries per row
+    cf* const rows = TT + (((size_t)MW_CZT_PLANES * N * N1 + 1) & ~(size_t)1);
+    cf* const buf = rows + (size_t)gi * BUF;                    // blockDim.x / T line buffers
+    CztTwRegs<M, P, 128> twr;  // (at least 128 threads: czt_launch_one rounds 3 (N + 1) lines of 8 up to whole waves, N >= 2)
+    twr.load(A, lds, tid, nthreads);
+    cf hh[P], w2r[P], w1r[P];
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        hh[q] = A.Hh[u + T * q];
+        w2r[q] = (u + T * q < N) ? A.w2[u + T * q] : mk(0.f, 0.f);
+        w1r[q] = (u + T * q < N1) ? A.w1[u + T * q] : mk(0.f, 0.f);
+    }
+    cf x[P];
+    {   // along j: line (p, i) formed from the spectrum, i = 0 .. N  ->  TT[p][b][i]
+        const int f = gi / N1, row = gi % N1;
+        const bool live = gi < MW_CZT_PLANES * N1;
+        czt_load<M, P>(A, f, live ? row : 0, u, live, x);
+        czt_line_core<M, P>(A, u, buf, x, lds, hh, twr);
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < P; q++) {
+                const int n = u + T * q;
+                if (n < N) TT[((size_t)f * N + n) * N1 + row] = cmul(x[q], w2r[q]);  // czt_store's expression
+            }
+        }
+    }
+    __syncthreads();
+    const int f = gi / N, b = gi % N;
+    const bool live = gi < MW_CZT_PLANES * N;
+    {   // along i: line (p, b) read from TT  ->  post-chirped outputs O[p][a][b] in the line's own buffer, index a
+        const cf* r = TT + ((size_t)(live ? f : 0) * N + (live ? b : 0)) * N1;
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const int n = u + T * q;
+            x[q] = (live && n < N1) ? cmul(r[n], w1r[q]) : mk(0.f, 0.f);  // czt_load's expression
+        }
+        czt_line_core<M, P>(A, u, buf, x, lds, hh, CztNoHook());
+        __syncthreads();  // the final pass has read its last exchange
+#pragma unroll
+        for (int q = 0; q < P; q++) {
+            const int n = u + T * q;
+            if (n < N) buf[n] = cmul(x[q], w2r[q]);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < N * N; e += nthreads) {  // k_czt_rows_assemble's expressions on the planes in LDS
+        const int a = e / N, bb = e % N;
+        const int idx = a * N + bb;
+        const cf* P0 = rows + (size_t)bb * BUF;             // plane 0, row b: H + i Dx
+        const cf* P1 = rows + (size_t)(N + bb) * BUF;       //          Sx + i Sz
+        const cf* P2 = rows + (size_t)(2 * N + bb) * BUF;   //          Dz (real part)
+        const cf p0 = P0[a], p1 = P1[a];
+        const float h = p0.x, dx = p0.y, sx = p1.x, sz = p1.y, dz = P2[a].x;
+        const float mag = sqrtf(sx * sx + 1.0f + sz * sz);  // up - n, S/FFTMesh.cs:218
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        if (mag > 1e-5f) { nx = sx / mag; ny = 1.0f / mag; nz = sz / mag; }
+        normals[3 * idx] = nx; normals[3 * idx + 1] = ny; normals[3 * idx + 2] = nz;
+        vertices[3 * idx + 0] = ssub(rest_coord(N, C.unit_width, a), smul(dx, C.choppiness));   // :245
+        vertices[3 * idx + 1] = h;                                                              // :243
+        vertices[3 * idx + 2] = ssub(rest_coord(N, C.unit_width, bb), smul(dz, C.choppiness));  // :244
+        if (hds) hds[idx] = mk(dx, dz);                                                         // :247
+        const bool hi = a != N - 1, hj = bb != N - 1;
+        const cf z = mk(0.f, 0.f);
+        const cf di = hi ? mk(P0[a + 1].y, P2[a + 1].x) : z;
+        const cf dj = hj ? mk(P0[BUF + a].y, P2[BUF + a].x) : z;
         const float xx = whitecap(mk(dx, dz), di, dj, hi, hj, nx, nz);
         if (white_stride == 1) white[idx] = xx;
         else { white[4 * idx] = xx; white[4 * idx + 1] = xx; white[4 * idx + 2] = xx; white[4 * idx + 3] = xx; }
@@ -351,7 +544,7 @@ static inline hipError_t czt_upload_tables(CztState& z, int N, float unit_width,
 constexpr int czt_fused_rows(int M) { return M <= 128 ? 8 : 4; }
 template <int M>
 static hipError_t czt_launch_rows_assemble(const CztArgs& A, cf* hds, float* dv, float* dn, float* dw, int white_stride, hipStream_t st) {
-    constexpr int P = czt_points(M), RW = czt_fused_rows(M), NG = 3 * RW + 2, LB = NG * (FftGeom<M, P>::LBUF + 4) * (int)sizeof(cf);
+    constexpr int P = czt_points(M), RW = czt_fused_rows(M), NG = 3 * RW + 2, LB = (CztTw<M, P>::CF + NG * (FftGeom<M, P>::LBUF + 4)) * (int)sizeof(cf);
     static_assert(NG * (M / P) <= 1024 && LB <= 160 * 1024, "fused small-grid launch: geometry");
     static AttrOnce attr;
     hipError_t e = attr.set(reinterpret_cast<const void*>(&k_czt_rows_assemble<M, P, RW>), LB);
@@ -359,9 +552,27 @@ static hipError_t czt_launch_rows_assemble(const CztArgs& A, cf* hds, float* dv,
     k_czt_rows_assemble<M, P, RW><<<dim3((A.rows + RW - 1) / RW), dim3(NG * M / P), LB, st>>>(A, hds, dv, dn, dw, white_stride);
     return hipGetLastError();
 }
+// N <= MW_CZT_ONE_MAX_N (transform size 64): one launch (MW_CZT_ONE=0, read per call: the two-launch plan, for A/B and the bit-identity test)
+static inline bool czt_one_launch(const CztState& z, int N) {
+    const char* oe = std::getenv("MW_CZT_ONE");
+    const char* fe = std::getenv("MW_CZT_FUSED");
+    return z.M == 64 && N <= MW_CZT_ONE_MAX_N && !(oe && std::atoi(oe) == 0) && !(fe && std::atoi(fe) == 0);
+}
+static hipError_t czt_launch_one(const CztArgs& A, cf* hds, float* dv, float* dn, float* dw, int white_stride, hipStream_t st) {
+    constexpr int M = 64, P = czt_points(M), T = M / P, BUF = FftGeom<M, P>::LBUF + 4;
+    const int N = A.C.N, lines = MW_CZT_PLANES * (N + 1), nthreads = ((lines * T + 63) / 64) * 64;
+    const size_t cf_count = (size_t)CztTw<M, P>::CF + (((size_t)MW_CZT_PLANES * N * (N + 1) + 1) & ~(size_t)1) + (size_t)(nthreads / T) * BUF;
+    const int LB = (int)(cf_count * sizeof(cf));
+    if (nthreads > 1024 || LB > 160 * 1024) return hipErrorInvalidValue;
+    static AttrOnce attr;
+    hipError_t e = attr.set(reinterpret_cast<const void*>(&k_czt_one<M, P>), 160 * 1024);
+    if (e != hipSuccess) return e;
+    k_czt_one<M, P><<<dim3(1), dim3(nthreads), LB, st>>>(A, hds, dv, dn, dw, white_stride);
+    return hipGetLastError();
+}
 template <int M>
 static hipError_t czt_launch(const CztArgs& A, hipStream_t st) {
-    constexpr int P = czt_points(M), RW = czt_rows(M), LB = RW * (FftGeom<M, P>::LBUF + 4) * (int)sizeof(cf);
+    constexpr int P = czt_points(M), RW = czt_rows(M), LB = (CztTw<M, P>::CF + RW * (FftGeom<M, P>::LBUF + 4)) * (int)sizeof(cf);
     static AttrOnce attr;
     hipError_t e = attr.set(reinterpret_cast<const void*>(&k_czt<M, P, RW>), LB);
     if (e != hipSuccess) return e;
@@ -384,6 +595,11 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
     CztArgs A;
     A.w1 = z.w1; A.w2 = z.w2; A.Hh = z.Hh; A.TWf = z.TWf; A.TWi = z.TWi;
     A.nin = N + 1; A.nout = N;  // the packed planes live on the index set [0, N]^2 (czt_packed_value)
+    if (czt_one_launch(z, N)) {  // tiny grids: both axes and the assembly in one workgroup (k_czt_one)
+        A.h0 = h0; A.h0c = h0c; A.t = t; A.C = C;
+        if (ev) hipEventRecord(ev[2], st);
+        return czt_launch_one(A, d.hds, dv, dn, dw, white_stride, st);
+    }
     hipError_t e = hipSuccess;
     for (int pass = 0; pass < 2 && e == hipSuccess; pass++) {
         // along j: rows i = 0 .. N formed from the spectrum -> TT[p][b][i] (N rows of N + 1); along i: rows b -> O[p][a][b]

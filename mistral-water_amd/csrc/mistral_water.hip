@@ -131,14 +131,6 @@ __device__ long long g_stamps[2][64][16][32];  // [kernel][block slot][wave][sta
 // LDS layout of both pass kernels: [twiddle tables, if small] [NBUF sets of exchange buffers].  With
 // NBUF == 2 the sets are used ping-pong (every store goes to the set the previous load did NOT read), so
 // one barrier per exchange suffices; with NBUF == 1 a second (WAR) barrier follows every load.
-template <int N, int P, int NT>
-__device__ __forceinline__ void stage_twiddles(cf* dst, const cf* __restrict__ src, int tid) {
-    using TG = TwGeom<N, P>;
-    for (int i = tid; i < TG::LDS_CF; i += NT) dst[i] = src[i];
-    if (TG::PW_CF)  // base twiddles of the powers pass: entry 1 of every (P+1)-entry row
-        for (int i = tid; i < TG::PW_CF; i += NT) dst[TG::LDS_CF + i] = src[TG::off_ts(TG::POW_STAGE) + i * (P + 1) + 1];
-}
-
 // VT = virtual threads per lane (see k_pass2_hs): the phase functions are written for 4*T virtual threads (4 spectrum
 // columns x T); a workgroup of 4*T/VT lanes runs virtual threads tid, tid + NT, ... of every phase back to back.
 // issue priority (s_setprio, 0..3) of the row groups by field once the loads are out: the slope groups -- the longest fetch, then the
@@ -210,7 +202,8 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
     };
     (void)col_sync;
     const float t = times.t[step];
-    if (TwGeom<N, P>::LDS_ALL) stage_twiddles<N, P, NT>(lds, A.TW, tid);  // visible after the first barrier
+    TwStage<N, P, NT> tws;
+    if (TwGeom<N, P>::LDS_ALL) tws.load(lds, A.TW, tid);  // in LDS behind the spectrum requests, visible after the first barrier
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     int cur = 0;  // set the next store goes to
@@ -224,6 +217,7 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
     if constexpr (FS) MW_STAMP_HWID(0);
 #pragma unroll
     MW_VT(h) p1_animate<N, P>(A, jb, tid + h * NT, t, st[h]);
+    if (TwGeom<N, P>::LDS_ALL) tws.store(lds, tid);
     MW_STAMP(0, 1);
 #pragma unroll
     for (int f = 0; f < 3; f++) {
@@ -301,7 +295,8 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
     // the same XCD's L2 instead of a second 128-B line fill across the fabric.
     const int ab = p2_row_block<N / R2>((int)blockIdx.x);
     const int g = tid / T;
-    if (TwGeom<N, P>::LDS_ALL) stage_twiddles<N, P, G::NTHREADS>(lds, A.TW, tid);
+    TwStage<N, P, G::NTHREADS> tws;
+    if (TwGeom<N, P>::LDS_ALL) tws.load(lds, A.TW, tid);
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     float* noise_lds = reinterpret_cast<float*>(lds + G::NOISE_OFF);
@@ -330,6 +325,7 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
 #else
         if (active) p2_load<N, P, R2>(A, ab, step, tid, f, x, set0 + cur * G::SETSTRIDE);
 #endif
+        if (k == 0 && TwGeom<N, P>::LDS_ALL) tws.store(lds, tid);  // published by the barrier below
         MW_STAMP(1, 2 + 8 * k);
 #ifdef MW_ABLATE_FFT
         if (active) {  // no exchanges: treat the loaded values as the transformed row (memory-pattern floor)
@@ -417,7 +413,8 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
     const int ab = p2_row_block<N / R2>((int)blockIdx.x);  // neighbouring row blocks (halo rows, shared 128-B lines) on one XCD
 #endif
     const int g0 = wave_uniform<true>(tid0 / T);  // row group of virtual thread 0; virtual thread h is in group g0 + h * NT / T
-    if (TwGeom<N, P>::LDS_ALL) stage_twiddles<N, P, NT>(lds, A.TW, tid0);
+    TwStage<N, P, NT> tws;
+    if (TwGeom<N, P>::LDS_ALL) tws.load(lds, A.TW, tid0);
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     P2StateHS<P> st[VT];
@@ -467,7 +464,8 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int f = p2_hs_field(k);
-        __syncthreads();  // k = 0: twiddle tables staged; later: the previous phase's LDS reads are done
+        if (k != 0 || MW_TW_STAGE != 2) __syncthreads();  // the previous phase's LDS reads are done (k = 0: nothing to wait for -- the twiddle tables
+                                                          // go to LDS behind the first requests below and are published by the barrier after stage 0)
         MW_STAMP(1, 1 + 8 * k);
         if (PF >= 1 && k == 1) {  // compile-time: k is unrolled
             if constexpr (PF != 0) {
@@ -511,6 +509,7 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
         if constexpr (HALO_EARLY)
             if (k == (PF >= 1 ? 0 : 1) && g0 == 0 && ab * R2 + R2 < N)
                 p2_hs_halo_fetch<N, P, R2>(A, ab, step, mw_fresh(tid0) % T, xh, PF >= 1 ? &xh_nyq : nullptr);
+        if (k == 0 && TwGeom<N, P>::LDS_ALL) tws.store(lds, tid0);
         if (f == 2 && SPARTS) {
 #pragma unroll
             MW_VT(h) {
@@ -649,9 +648,11 @@ __global__ __launch_bounds__((P2FrameGeom<N, P, R2>::NTHREADS)) void k_pass2_fra
     cf x[P];
     MW_STAMP(1, 0);
     MW_STAMP_RT(1, 30);
+    TwStage<N, P, G::NTHREADS> tws;
+    if (TwGeom<N, P>::LDS_ALL) tws.load(lds, A.TW, tid);  // requested first (vmcnt is in order), written to LDS behind the row requests
     if (row) p2_fetch<N, P, R2>(A, ab, step, tl, fg, x);
     else if (halo) p2_hs_halo_fetch<N, P, R2>(A, ab, step, tl, x);
-    if (TwGeom<N, P>::LDS_ALL) stage_twiddles<N, P, G::NTHREADS>(lds, A.TW, tid);
+    if (TwGeom<N, P>::LDS_ALL) tws.store(lds, tid);
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     if (row) p2_stage0<N, P, R2>(tl, x, mine);
     else if (halo) stage0_store<N, P, +1>(x, tl, mine);
@@ -1512,7 +1513,8 @@ static mw_status profile_kernels_impl(mw_ocean* o, int32_t nsteps, int32_t iters
         static const char* fnames[2] = {"k_czt (spectrum + chirp-z along j)", "k_czt_rows_assemble (chirp-z along i + vertices, normals, whitecap: one launch)"};
         const char* fe = std::getenv("MW_CZT_FUSED");
         const bool fused = o->direct.use_czt && !(fe && std::atoi(fe) == 0) && o->direct.czt.M <= MW_CZT_FUSED_MAX_M;
-        const char* const* dnames = o->direct.use_czt ? (fused ? fnames : znames) : gnames;
+        static const char* onames[2] = {"(no separate launch)", "k_czt_one (both axes + vertices, normals, whitecap: one workgroup, one launch)"};
+        const char* const* dnames = o->direct.use_czt ? (czt_one_launch(o->direct.czt, o->N) ? onames : (fused ? fnames : znames)) : gnames;
         hipEvent_t ev[4];
         for (auto& e : ev) hipEventCreate(&e);
         hipError_t he = hipSuccess;

@@ -418,6 +418,52 @@ struct TwGeom {
     }
 };
 
+// Staging of the twiddle tables (TwGeom::LDS_CF leading entries + the PW_CF base twiddles of a powers pass) by NT threads, in two halves
+// (round 5): load() puts EVERY global load of the workgroup's share in flight at once, store() writes them to LDS -- placed by the kernels
+// behind the requests of their first input rows and in front of their first barrier, so that the tables ride under the same memory latency
+// as the data.  Up to here it was a copy loop `for (i = tid; i < LDS_CF; i += NT) lds[i] = tw[i]`, which compiles to load -> s_waitcnt
+// vmcnt(0) -> ds_write per iteration: three to five L2 round trips ONE AFTER THE OTHER at the head of every workgroup, in front of a barrier
+// in front of its first data request (k_pass2_hs<1024>: five of them, 128 lanes for 528 entries).  MW_TW_STAGE=0 keeps that loop (A/B).
+#ifndef MW_TW_STAGE
+#define MW_TW_STAGE 2  // 2: loads at the top, LDS writes behind the first data requests; 1: loads then writes at the top; 0: the copy loop
+#endif
+#if defined(__HIPCC__)
+// WITH_PW = false: a kernel that keeps the table in every pass (stage_regs<.., ALLOW_POW = false>: the OceanRenderer passes) and whose LDS
+// layout has no room for the base twiddles of a powers pass
+template <int N, int P, int NT, bool WITH_PW = true>
+struct TwStage {
+    using TG = TwGeom<N, P>;
+    static constexpr int PW = WITH_PW ? TG::PW_CF : 0;
+    static constexpr int IT = MW_TW_STAGE ? (TG::LDS_CF + NT - 1) / NT : 0, ITP = MW_TW_STAGE ? (PW + NT - 1) / NT : 0;
+    cf r[IT > 0 ? IT : 1], rp[ITP > 0 ? ITP : 1];
+    __device__ __forceinline__ void store_now(cf* dst, int tid) const {
+#pragma unroll
+        for (int k = 0; k < IT; k++) { const int i = tid + k * NT; if (IT * NT == TG::LDS_CF || i < TG::LDS_CF) dst[i] = r[k]; }
+#pragma unroll
+        for (int k = 0; k < ITP; k++) { const int i = tid + k * NT; if (ITP * NT == PW || i < PW) dst[TG::LDS_CF + i] = rp[k]; }
+    }
+    // at the top of the kernel
+    __device__ __forceinline__ void load(cf* dst, const cf* __restrict__ src, int tid) {
+        if (MW_TW_STAGE == 0) {
+            for (int i = tid; i < TG::LDS_CF; i += NT) dst[i] = src[i];
+            if (PW)  // base twiddles of the powers pass: entry 1 of every (P+1)-entry row
+                for (int i = tid; i < PW; i += NT) dst[TG::LDS_CF + i] = src[TG::off_ts(TG::POW_STAGE) + i * (P + 1) + 1];
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < IT; k++) { const int i = tid + k * NT; r[k] = (IT * NT == TG::LDS_CF || i < TG::LDS_CF) ? src[i] : mk(0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < ITP; k++) {
+            const int i = tid + k * NT;
+            rp[k] = (ITP * NT == PW || i < PW) ? src[TG::off_ts(TG::POW_STAGE) + i * (P + 1) + 1] : mk(0.f, 0.f);
+        }
+        if (MW_TW_STAGE == 1) store_now(dst, tid);
+    }
+    // behind the kernel's first data requests, in front of its first barrier
+    __device__ __forceinline__ void store(cf* dst, int tid) const { if (MW_TW_STAGE == 2) store_now(dst, tid); }
+};
+#endif
+
 // LDS indices are written as (per-thread base) + (compile-time constant) so that every ds_read / ds_write
 // carries its offset in the instruction's immediate field and costs no address VALU.
 template <int N, int P, int SGN>

@@ -102,11 +102,13 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Arg
         A.initT += toff; A.phase_in += toff; A.phase_out += toff; A.E += 3 * toff;
     }
     const int w = tid / T, u = tid % T;
-    for (int i = tid; i < TwGeom<N, P>::LDS_CF; i += G::NTHREADS) lds[i] = A.TW[i];
+    TwStage<N, P, G::NTHREADS, false> tws;
+    tws.load(lds, A.TW, tid);
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     cf h[P], x[P];
     or_p1_animate<N, P>(A, jb, tid, f0 == 0, h);
+    tws.store(lds, tid);  // behind the spectrum / phase requests; published by the first barrier
     for (int f = f0; f < f1; f++) {
         or_p1_build<N, P>(A, jb, tid, f, h, x);
         if (f != f0) __syncthreads();  // the previous field's final-pass reads of the buffers are done
@@ -136,7 +138,8 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
         if (A.height_g) A.height_g += toff;
         if (A.disp_a) A.disp_a += toff;
     }
-    for (int i = tid; i < TwGeom<N, P>::LDS_CF; i += G::NTHREADS) lds[i] = A.TW[i];
+    TwStage<N, P, G::NTHREADS, false> tws;
+    tws.load(lds, A.TW, tid);
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     cf x[P];
@@ -147,6 +150,7 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
         const int f = or_p2_field(k);
         if (k != k0) __syncthreads();
         or_p2_load<N, P>(A, ab, tid, f, x, set0);
+        if (k == k0) tws.store(lds, tid);  // behind the first row requests; published by the barrier below
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {

@@ -503,7 +503,7 @@ def test_direct_path_tiny_and_threshold_grids(mw, oracle, N, u, L):
     """Non-FFT grids at the edges of the chirp-z plans: the smallest meshes a scene can carry (2, 3, 5 vertices per side: transform size 64,
     most of it zero padding), power-of-two sizes that are NOT commensurate (64 with length 70, 128 with unit width 1.1: the FFT path must
     refuse them and the separable sum serve them), and the sizes either side of the two-launch / three-launch switch (127, 128 -> M = 256;
-    129 -> M = 512).  Against the f64 oracle's separable sum."""
+    129 -> M = 512); 2, 3, 5 run the one-launch plan (k_czt_one).  Against the f64 oracle's separable sum."""
     p = oracle.Params(N=N, unit_width=u, length=L, wind_x=4.0, wind_y=-2.5, amplitude=1e-3, choppiness=0.6)
     h0, h0c = oracle.generate_spectrum(p, 4)
     rest = oracle.rest_mesh(p)[0]
@@ -512,7 +512,8 @@ def test_direct_path_tiny_and_threshold_grids(mw, oracle, N, u, L):
         o.set_spectrum(h0, h0c)
         v, n, c = o.evaluate(0.75)
         kinds = [k for k, _ in o.profile_kernels(nsteps=1, iters=2)]
-    assert ("rows_assemble" in kinds[1]) == (N <= 128), kinds      # two launches up to M = 256, three beyond
+    # one launch up to N = 20 (k_czt_one), two up to M = 256, three beyond
+    assert ("k_czt_one" in kinds[1]) == (N <= 20) and ("rows_assemble" in kinds[1]) == (20 < N <= 128), kinds
     vd, nd, cd, hds = oracle.eval_matmul_f64(p, h0, h0c, 0.75, return_hds=True)
     workloads.assert_parity(v, n, c, vd, nd, cd, rest, rel=2e-5, tag=f"direct N={N}", hds=hds, min_decided=0.0)
 

@@ -142,26 +142,36 @@ def test_both_forms_of_the_direct_sum(form):
     assert r.returncode == 0 and "CZT_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("N,u,L", [(12, 1.0, 12.39), (50, 1.0, 1.0), (64, 1.3, 64.0), (65, 1.0, 65.0), (100, 1.0, 100.0), (128, 0.9, 128.0)])
+@pytest.mark.parametrize("N,u,L", [(2, 1.0, 2.0), (3, 1.0, 3.0), (7, 0.8, 9.1), (12, 1.0, 12.39), (20, 1.0, 25.0), (21, 1.0, 21.0), (32, 1.0, 32.0), (33, 1.0, 33.0),
+                                   (50, 1.0, 1.0), (64, 1.3, 64.0), (65, 1.0, 65.0), (100, 1.0, 100.0), (128, 0.9, 128.0)])
 def test_small_grid_fused_czt_equals_three_launches(mw, oracle, N, u, L):
     """Round 5: grids with a chirp-z transform size M <= 256 (N <= 128: the shipped 12-vertex scene, the Inspector default N = 50) run the
     second axis and the assembly in ONE launch (k_czt_rows_assemble: 3 RW + 2 lines side by side, vertices / normals / whitecap straight
-    from LDS).  MW_CZT_FUSED=0 selects the three-launch plan at run time: the same bits, hds included; and the f64 oracle at 2e-5."""
+    from LDS), and grids with N <= 20 (transform size 64) the WHOLE step in one workgroup and one launch (k_czt_one: the plane between the
+    axes never leaves LDS).  MW_CZT_FUSED=0 selects the three-launch plan at run time, MW_CZT_ONE=0 the two-launch one: the same bits,
+    hds included; and the f64 oracle at 2e-5."""
     p = oracle.Params(N=N, unit_width=u, length=L, wind_x=3.0, wind_y=2.0, amplitude=2e-4 if N > 12 else 2e-3, choppiness=0.7)
     kw = dict(resolution=N, unit_width=u, length=L, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude, choppiness=p.choppiness, seed=5)
     res = {}
+    plans = {"default": {}, "two": {"MW_CZT_ONE": "0"}, "three": {"MW_CZT_FUSED": "0"}}
     try:
-        for fused in ("1", "0"):
-            os.environ["MW_CZT_FUSED"] = fused
+        for name, env in plans.items():
+            for k in ("MW_CZT_ONE", "MW_CZT_FUSED"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
             with mw.Ocean(**kw) as o:
                 assert o.max_batch == 1
                 h0, h0c = o.get_spectrum()
-                res[fused] = (o.evaluate(0.75), o.debug_evaluate_hds(0.75), o.profile_kernels(nsteps=1, iters=3))
+                res[name] = (o.evaluate(0.75), o.debug_evaluate_hds(0.75), o.profile_kernels(nsteps=1, iters=3))
     finally:
-        os.environ.pop("MW_CZT_FUSED", None)
-    assert "rows_assemble" in res["1"][2][1][0] and "rows_assemble" not in res["0"][2][1][0]      # the plans really differ
-    for a, b in zip(res["1"][0] + res["1"][1], res["0"][0] + res["0"][1]):
-        assert (a == b).all()
-    v, n, c = res["1"][0]
+        for k in ("MW_CZT_ONE", "MW_CZT_FUSED"):
+            os.environ.pop(k, None)
+    names = {k: r[2][1][0] for k, r in res.items()}
+    assert ("k_czt_one" in names["default"]) == (N <= 20), names                                  # the plans really differ
+    assert "rows_assemble" in names["two"] and "rows_assemble" not in names["three"] and "k_czt_one" not in names["three"], names
+    for other in ("two", "three"):
+        for a, b in zip(res["default"][0] + res["default"][1], res[other][0] + res[other][1]):
+            assert (a == b).all(), other
+    v, n, c = res["default"][0]
     vd, nd, cd, hds = oracle.eval_matmul_f64(p, h0, h0c, 0.75, return_hds=True)
     workloads.assert_parity(v, n, c, vd, nd, cd, oracle.rest_mesh(p)[0], rel=2e-5, tag=f"fused czt N={N}", hds=hds)
