@@ -18,7 +18,7 @@ run ocean4096 ocean4096 32 128
 run pond pond 32 3200
 run renderer1024 renderer1024 1 2000
 run renderer1024 renderer1024 4 500 --tiles 4
-for n in 50 100 1000 2000; do
+for n in 12 50 100 1000 2000; do
   timeout 300 python bench.py --workload direct --direct-n $n --steps 200 --warmup 20 2> gpurun_out/${tag}_direct_$n.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_direct_$n.json
 done
 MW_BENCH_FORCE_TILES=1 timeout 300 python bench.py --steps 640 --warmup 64 --gather --no-cpu-baseline --no-latency 2> gpurun_out/${tag}_tiles.err | tail -1 > gpurun_out/profiles_${tag}/${tag}_bench_ocean1024_tiles_gather.json
@@ -33,6 +33,6 @@ timeout 300 python tools/frame_probe.py 2> /dev/null | tail -1 > gpurun_out/prof
 rm -rf /tmp/fp_${tag}; TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/fp_${tag} -o fp --output-format csv -- python tools/frame_probe.py > /dev/null 2>&1
 f=$(find /tmp/fp_${tag} -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" > gpurun_out/profiles_${tag}/${tag}_frame_kernel_stats.csv
 bash tools/frame_stamps.sh > /dev/null 2>&1; cp gpurun_out/frame_ab/stamps.txt gpurun_out/profiles_${tag}/${tag}_frame_stamps.txt 2> /dev/null
-P=gpurun_out/profiles_${tag}; python tools/bench_summary.py $P/${tag}_bench_direct_50.json $P/${tag}_bench_direct_100.json $P/${tag}_bench_direct_1000.json $P/${tag}_bench_direct_2000.json $P/${tag}_bench_ocean1024_b32_steps640.json $P/${tag}_bench_ocean2048.json $P/${tag}_bench_ocean4096.json $P/${tag}_bench_pond.json $P/${tag}_bench_renderer1024.json $P/${tag}_bench_renderer1024_tiles4.json $P/${tag}_bench_ocean1024_driver_k20.json
+P=gpurun_out/profiles_${tag}; python tools/bench_summary.py $P/${tag}_bench_direct_12.json $P/${tag}_bench_direct_50.json $P/${tag}_bench_direct_100.json $P/${tag}_bench_direct_1000.json $P/${tag}_bench_direct_2000.json $P/${tag}_bench_ocean1024_b32_steps640.json $P/${tag}_bench_ocean2048.json $P/${tag}_bench_ocean4096.json $P/${tag}_bench_pond.json $P/${tag}_bench_renderer1024.json $P/${tag}_bench_renderer1024_tiles4.json $P/${tag}_bench_ocean1024_driver_k20.json
 ls gpurun_out/profiles_${tag}
 # back in the container: cp gpurun_out/profiles_${tag}/* profiles/   (only gpurun_out/ travels back from the GPU box)
