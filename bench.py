@@ -37,6 +37,9 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 import memguard  # noqa: E402  host-memory cap (tests/memguard.py): a harness bug must end this process, not the GPU box
 memguard.install()
+# the host driver of these boxes supports dmabuf IPC only: without this RCCL's communicator bootstrap between processes fails with
+# `hipIpcGetMemHandle: invalid argument`.  Exported by the image already; set here as well so that a launcher with a scrubbed environment works.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
