@@ -745,8 +745,19 @@ inline std::vector<cf> build_twiddle_table_host(int N, int P, int sgn) {
 }
 // ---- spectrum algebra (DESIGN.md "Hermitian packing") ---------------------------------------
 // h(k,t) = P e^{i th} + Q e^{-i th}
+// The four products of each component as ONE product and three FMAs written out (round 5): with hipcc's -ffp-contract=fast the optimiser
+// decides per inlined copy which of `a*b + c*d + ...` it fuses, and two launch forms of one kernel that reach this function through
+// differently shaped loops (or_p1_animate: point by point in the lone frame, eight points at a time in the batched forms) produced spectra
+// that differed in the last bit -- a batched OceanRenderer handle was no longer bit-identical to its single handles.  Same policy as cmul /
+// MW_FFT_STRICT: the rounding is fixed in the source.
+#ifndef MW_ANIMATE_EXPLICIT
+#define MW_ANIMATE_EXPLICIT 1  // 0: the plain expression of rounds 1-4 (A/B of the speed only: its bits depend on the inlining context)
+#endif
 MW_HD cf animate(float px, float py, float qx, float qy, float c, float s) {
-    return mk(px * c - py * s + qx * c + qy * s, px * s + py * c - qx * s + qy * c);
+    if (!MW_ANIMATE_EXPLICIT) return mk(px * c - py * s + qx * c + qy * s, px * s + py * c - qx * s + qy * c);
+    const float re = __builtin_fmaf(px, c, __builtin_fmaf(-py, s, __builtin_fmaf(qx, c, smul(qy, s))));
+    const float im = __builtin_fmaf(px, s, __builtin_fmaf(py, c, __builtin_fmaf(-qx, s, smul(qy, c))));
+    return mk(re, im);
 }
 
 }  // namespace mw

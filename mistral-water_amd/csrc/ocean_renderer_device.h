@@ -107,7 +107,8 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Arg
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     cf h[P], x[P];
-    or_p1_animate<N, P>(A, jb, tid, f0 == 0, h);
+    if (gridDim.y == 1) or_p1_animate<N, P, MW_OR_P1_CHUNK>(A, jb, tid, f0 == 0, h);  // one workgroup per column job: bandwidth-bound forms
+    else or_p1_animate<N, P, 1>(A, jb, tid, f0 == 0, h);                                // one field per workgroup: the lone frame
     tws.store(lds, tid);  // behind the spectrum / phase requests; published by the first barrier
     for (int f = f0; f < f1; f++) {
         or_p1_build<N, P>(A, jb, tid, f, h, x);

@@ -108,7 +108,11 @@ struct OrP1Geom {
 };
 // Dispersion + h~ for the 4 texel columns px = 4 jb .. 4 jb + 3 (transform index = py = u + T q)
 // Every field's block recomputes the advanced phase from phase_in; only the field-0 block stores it (write_phase).
-template <int N, int P>
+#ifndef MW_OR_P1_CHUNK
+#define MW_OR_P1_CHUNK 8  // points whose loads the bandwidth-bound launch forms request together (1: point by point, A/B)
+#endif
+// CH: points whose loads are requested together
+template <int N, int P, int CH_>
 MW_HD void or_p1_animate(const OrP1Args& A, int jb, int tid, bool write_phase, cf (&h)[P]) {
     constexpr int T = FftGeom<N, P>::T;
     const int w = wave_uniform<(T % 64) == 0>(tid / T), u = tid % T, px = 4 * jb + w;
@@ -119,14 +123,32 @@ MW_HD void or_p1_animate(const OrP1Args& A, int jb, int tid, bool write_phase, c
     float* const c_po = A.phase_out + col;
     const f4* const c_in = A.initT + col;
     const unsigned uo = (unsigned)u;
+    // CH = 8: every request of eight points first, then the arithmetic and the phase stores (round 5).  Written point by point (CH = 1) -- load
+    // omega, phase and spectrum, advance, STORE the phase, next point -- the store to phase_out, which may alias the next point's loads as far
+    // as the compiler knows, keeps every load behind the previous point's store: `L L L s_waitcnt S` x 8 in the ISA.  Measured
+    // (profiles/r05_ab_notes.md): together they are faster where the launch is bandwidth-bound (4 tiles per frame 102.6 -> 98.5 us, 2048^2
+    // textures 129 -> 126) and SLOWER in a lone 1024^2 frame (35.9 -> 38.0 us: its 771 workgroups start at the same instant, and the three
+    // field workgroups of a column job then miss L2 together where point by point they drift apart and two of them hit): the kernel picks
+    // by the launch form (gridDim.y).
+    constexpr int CH = P < CH_ ? P : CH_;
 #pragma unroll
-    for (int q = 0; q < P; q++) {
-        const float ph = or_phase_step((c_om + T * q)[uo], (c_pi + T * q)[uo], A.dt);
-        if (write_phase) (c_po + T * q)[uo] = ph;
-        const f4 v = (c_in + T * q)[uo];
-        float s, c;
-        mw_sincos(ph, &s, &c);
-        h[q] = animate(v.x, v.y, v.z, v.w, c, s);  // h0*pv + h0conj*Conj(pv), F/Spectrum.shader:45
+    for (int q0 = 0; q0 < P; q0 += CH) {
+        float om[CH], pi[CH];
+        f4 v[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            om[k] = (c_om + T * (q0 + k))[uo];
+            pi[k] = (c_pi + T * (q0 + k))[uo];
+            v[k] = (c_in + T * (q0 + k))[uo];
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const float ph = or_phase_step(om[k], pi[k], A.dt);
+            if (write_phase) (c_po + T * (q0 + k))[uo] = ph;
+            float s, c;
+            mw_sincos(ph, &s, &c);
+            h[q0 + k] = animate(v[k].x, v[k].y, v[k].z, v[k].w, c, s);  // h0*pv + h0conj*Conj(pv), F/Spectrum.shader:45
+        }
     }
 }
 // f = 0: h (height);  f = 1: hx = -i h kx/w chop;  f = 2: hz   (F/Spectrum.shader:47-49)

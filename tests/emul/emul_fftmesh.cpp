@@ -316,7 +316,7 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
         std::vector<St> st(NT);
         for (int jb = 0; jb < N / 4; jb++)
             for (int f = 0; f < 3; f++) {  // grid (N/4, 3): one field per block
-                for (int tid = 0; tid < NT; tid++) or_p1_animate<N, P>(A, jb, tid, f == 0, st[tid].h);
+                for (int tid = 0; tid < NT; tid++) or_p1_animate<N, P, 8>(A, jb, tid, f == 0, st[tid].h);
                 for (int tid = 0; tid < NT; tid++) {
                     or_p1_build<N, P>(A, jb, tid, f, st[tid].h, st[tid].x);
                     stage0_store<N, P, -1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
