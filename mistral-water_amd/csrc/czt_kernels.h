@@ -52,20 +52,15 @@ struct CztArgs {
 // error is relative to the plane's largest entry (Dz packed with Sx measured 7e-6 there instead of 2e-7).  omega(N - i, N - j) = omega(i, j) bit for bit, so one sine serves both halves.  Three planes of
 // (N + 1) x (N + 1) go through the chirp-z launches instead of five of N x N: 0.6 of the transform work.
 #define MW_CZT_PLANES 3
-MW_HD cf czt_packed_value(const OceanConsts& C, const cf* h0, const cf* h0c, float t, int i, int j, int plane) {
+// the arithmetic of one element from the four spectrum values it needs: (a0, b0) = (h0, h0conj)(i, j) where in0, (a1, b1) = the same at the
+// mirrored index (N - i, N - j) where in1
+MW_HD cf czt_packed_from(const OceanConsts& C, cf a0, cf b0, bool in0, cf a1, cf b1, bool in1, float t, int i, int j, int plane) {
     const int N = C.N;
     float s, c;
     mw_sincos(omega_t_f32(N, C.length, C.gravity, i, j, t), &s, &c);
-    cf h = mk(0.f, 0.f), hm = mk(0.f, 0.f);
-    if (i < N && j < N) {
-        const cf a = h0[(size_t)i * N + j], b = h0c[(size_t)i * N + j];
-        h = mk(a.x * c - a.y * s + b.x * c + b.y * s, a.x * s + a.y * c - b.x * s + b.y * c);  // :188
-    }
-    if (i > 0 && j > 0) {
-        const size_t m = (size_t)(N - i) * N + (N - j);
-        const cf a = h0[m], b = h0c[m];
-        hm = mk(a.x * c - a.y * s + b.x * c + b.y * s, a.x * s + a.y * c - b.x * s + b.y * c);
-    }
+    const cf z = mk(0.f, 0.f);
+    const cf h = in0 ? animate(a0.x, a0.y, b0.x, b0.y, c, s) : z;   // :188
+    const cf hm = in1 ? animate(a1.x, a1.y, b1.x, b1.y, c, s) : z;
     const cf Hh = mk(0.5f * (h.x + hm.x), 0.5f * (h.y - hm.y));
     const float kx = wave_k(N, C.length, i), kz = wave_k(N, C.length, j);
     if (plane == 1) return cmul(Hh, mk(kz, -kx));  // Hh (kz - i kx): real part Sx (= Im sum kx h~), imaginary part Sz
@@ -74,6 +69,12 @@ MW_HD cf czt_packed_value(const OceanConsts& C, const cf* h0, const cf* h0c, flo
     if (!(kl < MW_EPS_F)) { ux = kx / kl; uz = kz / kl; }  // |k| < EPSILON: skipped, :213-215
     if (plane == 0) return cscale(Hh, 1.0f + ux);  // real part H, imaginary part Dx
     return mk(-(Hh.y * uz), Hh.x * uz);            // Hh (i kz/|k|): real part Dz (= Im sum (-kz/|k|) h~)
+}
+MW_HD cf czt_packed_value(const OceanConsts& C, const cf* h0, const cf* h0c, float t, int i, int j, int plane) {
+    const int N = C.N;
+    const bool in0 = i < N && j < N, in1 = i > 0 && j > 0;
+    const size_t i0 = in0 ? (size_t)i * N + j : 0, i1 = in1 ? (size_t)(N - i) * N + (N - j) : 0;
+    return czt_packed_from(C, h0[i0], h0c[i0], in0, h0[i1], h0c[i1], in1, t, i, j, plane);
 }
 
 // transform size and points per thread for a grid of N points per axis (0: N too large for one workgroup-resident transform)
@@ -86,14 +87,60 @@ inline int czt_size(int N) { return czt_size_io(N + 1, N); }  // the packed plan
 constexpr int czt_points(int M) { return M >= 256 ? 16 : 8; }
 constexpr int czt_rows(int M) { return (512 / (M / czt_points(M))) < 1 ? 1 : ((512 / (M / czt_points(M))) > 8 ? 8 : (512 / (M / czt_points(M)))); }
 
-template <int M, int P>
+// Pre-chirped, zero-padded input of a line.  The loads of four elements are requested before the first of them is used (round 5):
+// written element by element -- bounds test, load, arithmetic, next element -- each element's loads sat in a branch of their own behind the
+// previous element's arithmetic (`j L L W W j L L W W ...` in the ISA: two memory latencies per element, 16-32 per line, in the launch whose
+// input is formed from the spectrum).  Out-of-range elements load element 0 (no branch around a load); the arithmetic stays behind the bounds test.
+// CH_: elements requested together (their loaded values are live until used: 10 registers per element of the spectrum form)
+#ifndef MW_CZT_LOAD_CHUNK
+#define MW_CZT_LOAD_CHUNK 4  // 1: element by element (A/B); 8: slower from M = 2048 up (140 registers)
+#endif
+template <int M, int P, int CH_ = MW_CZT_LOAD_CHUNK>
 MW_HD void czt_load(const CztArgs& A, int f, int row, int u, bool live, cf (&x)[P]) {
-    constexpr int T = M / P;
-    const cf* __restrict__ r = A.in + (size_t)f * A.in_plane + (size_t)row * A.in_ld;
+    constexpr int T = M / P, CH = P < CH_ ? P : CH_;
+    const cf z = mk(0.f, 0.f);
+    if (A.h0 == nullptr) {
+        const cf* __restrict__ r = A.in + (size_t)f * A.in_plane + (size_t)row * A.in_ld;
 #pragma unroll
-    for (int q = 0; q < P; q++) {
-        const int n = u + T * q;
-        x[q] = (live && n < A.nin) ? cmul(A.h0 ? czt_packed_value(A.C, A.h0, A.h0c, A.t, row, n, f) : r[n], A.w1[n]) : mk(0.f, 0.f);  // zero padding up to M
+        for (int q0 = 0; q0 < P; q0 += CH) {
+            cf rv[CH], wv[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int n = u + T * (q0 + k);
+                const int idx = (live && n < A.nin) ? n : 0;
+                rv[k] = r[idx];
+                wv[k] = A.w1[idx];
+            }
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int n = u + T * (q0 + k);
+                x[q0 + k] = (live && n < A.nin) ? cmul(rv[k], wv[k]) : z;  // zero padding up to M
+            }
+        }
+        return;
+    }
+    const int N = A.C.N;
+#pragma unroll
+    for (int q0 = 0; q0 < P; q0 += CH) {
+        cf a0[CH], b0[CH], a1[CH], b1[CH], wv[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int n = u + T * (q0 + k);
+            const bool valid = live && n < A.nin;
+            const bool in0 = valid && row < N && n < N, in1 = valid && row > 0 && n > 0;
+            const size_t i0 = in0 ? (size_t)row * N + n : 0, i1 = in1 ? (size_t)(N - row) * N + (N - n) : 0;
+            a0[k] = A.h0[i0]; b0[k] = A.h0c[i0];
+            a1[k] = A.h0[i1]; b1[k] = A.h0c[i1];
+            wv[k] = A.w1[valid ? n : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int n = u + T * (q0 + k);
+            const bool valid = live && n < A.nin;
+            const bool in0 = valid && row < N && n < N, in1 = valid && row > 0 && n > 0;
+            x[q0 + k] = z;  // zero padding up to M: no arithmetic there (at N = 12 four fifths of a line are padding)
+            if (valid) x[q0 + k] = cmul(czt_packed_from(A.C, a0[k], b0[k], in0, a1[k], b1[k], in1, A.t, row, n, f), wv[k]);
+        }
     }
 }
 template <int M, int P>
