@@ -40,6 +40,12 @@ struct CztArgs {
     const cf* h0c = nullptr;
     float t = 0.f;
     OceanConsts C = {};
+    // what of an element's arithmetic does not depend on t, tabulated when the handle is created (round 5; k_czt_tables): the quantised
+    // dispersion omega(i, j) on [0, N]^2 -- row stride N + 1; omega(N - i, N - j) = omega(i, j) bit for bit, one value serves both halves -- and the
+    // wave number k(i) of an index.  Formed by omega_f32 / wave_k themselves: the same bits the launch used to recompute per element and step
+    // (three correctly rounded divisions and two square roots for omega, one division per wave number: half of the launch's instructions).
+    const float* Om = nullptr;  // [(N + 1) * (N + 1)]
+    const float* K = nullptr;   // [N + 1]
 };
 
 // HERMITIAN PACKING ON ANY GRID (round 4): five real outputs in THREE complex sums.  The outputs are real / imaginary parts of
@@ -54,15 +60,13 @@ struct CztArgs {
 #define MW_CZT_PLANES 3
 // the arithmetic of one element from the four spectrum values it needs: (a0, b0) = (h0, h0conj)(i, j) where in0, (a1, b1) = the same at the
 // mirrored index (N - i, N - j) where in1
-MW_HD cf czt_packed_from(const OceanConsts& C, cf a0, cf b0, bool in0, cf a1, cf b1, bool in1, float t, int i, int j, int plane) {
-    const int N = C.N;
+MW_HD cf czt_packed_from(const OceanConsts& C, cf a0, cf b0, bool in0, cf a1, cf b1, bool in1, float t, float om, float kx, float kz, int plane) {
     float s, c;
-    mw_sincos(omega_t_f32(N, C.length, C.gravity, i, j, t), &s, &c);
+    mw_sincos(smul(om, t), &s, &c);  // omega * t: one float32 product (omega_t_f32)
     const cf z = mk(0.f, 0.f);
     const cf h = in0 ? animate(a0.x, a0.y, b0.x, b0.y, c, s) : z;   // :188
     const cf hm = in1 ? animate(a1.x, a1.y, b1.x, b1.y, c, s) : z;
     const cf Hh = mk(0.5f * (h.x + hm.x), 0.5f * (h.y - hm.y));
-    const float kx = wave_k(N, C.length, i), kz = wave_k(N, C.length, j);
     if (plane == 1) return cmul(Hh, mk(kz, -kx));  // Hh (kz - i kx): real part Sx (= Im sum kx h~), imaginary part Sz
     const float kl = sqrtf(kx * kx + kz * kz);
     float ux = 0.f, uz = 0.f;
@@ -70,11 +74,19 @@ MW_HD cf czt_packed_from(const OceanConsts& C, cf a0, cf b0, bool in0, cf a1, cf
     if (plane == 0) return cscale(Hh, 1.0f + ux);  // real part H, imaginary part Dx
     return mk(-(Hh.y * uz), Hh.x * uz);            // Hh (i kz/|k|): real part Dz (= Im sum (-kz/|k|) h~)
 }
+// one element with everything formed in place (what the tables hold is what these calls return)
 MW_HD cf czt_packed_value(const OceanConsts& C, const cf* h0, const cf* h0c, float t, int i, int j, int plane) {
     const int N = C.N;
     const bool in0 = i < N && j < N, in1 = i > 0 && j > 0;
     const size_t i0 = in0 ? (size_t)i * N + j : 0, i1 = in1 ? (size_t)(N - i) * N + (N - j) : 0;
-    return czt_packed_from(C, h0[i0], h0c[i0], in0, h0[i1], h0c[i1], in1, t, i, j, plane);
+    return czt_packed_from(C, h0[i0], h0c[i0], in0, h0[i1], h0c[i1], in1, t, omega_f32(N, C.length, C.gravity, i, j), wave_k(N, C.length, i),
+                           wave_k(N, C.length, j), plane);
+}
+// the tables of CztArgs::Om / K, element e of the (N + 1)^2 index set (and of the N + 1 wave numbers)
+MW_HD void czt_table_element(int N, float length, float gravity, int e, float* Om, float* K) {
+    const int i = e / (N + 1), j = e % (N + 1);
+    Om[e] = omega_f32(N, length, gravity, i, j);
+    if (e <= N) K[e] = wave_k(N, length, e);
 }
 
 // transform size and points per thread for a grid of N points per axis (0: N too large for one workgroup-resident transform)
@@ -120,9 +132,12 @@ MW_HD void czt_load(const CztArgs& A, int f, int row, int u, bool live, cf (&x)[
         return;
     }
     const int N = A.C.N;
+    const float kx = A.K[row];  // (row is 0 for a line past the end)
+    const float* __restrict__ omrow = A.Om + (size_t)row * (N + 1);
 #pragma unroll
     for (int q0 = 0; q0 < P; q0 += CH) {
         cf a0[CH], b0[CH], a1[CH], b1[CH], wv[CH];
+        float om[CH], kz[CH];
 #pragma unroll
         for (int k = 0; k < CH; k++) {
             const int n = u + T * (q0 + k);
@@ -132,6 +147,8 @@ MW_HD void czt_load(const CztArgs& A, int f, int row, int u, bool live, cf (&x)[
             a0[k] = A.h0[i0]; b0[k] = A.h0c[i0];
             a1[k] = A.h0[i1]; b1[k] = A.h0c[i1];
             wv[k] = A.w1[valid ? n : 0];
+            om[k] = omrow[valid ? n : 0];
+            kz[k] = A.K[valid ? n : 0];
         }
 #pragma unroll
         for (int k = 0; k < CH; k++) {
@@ -139,7 +156,7 @@ MW_HD void czt_load(const CztArgs& A, int f, int row, int u, bool live, cf (&x)[
             const bool valid = live && n < A.nin;
             const bool in0 = valid && row < N && n < N, in1 = valid && row > 0 && n > 0;
             x[q0 + k] = z;  // zero padding up to M: no arithmetic there (at N = 12 four fifths of a line are padding)
-            if (valid) x[q0 + k] = cmul(czt_packed_from(A.C, a0[k], b0[k], in0, a1[k], b1[k], in1, A.t, row, n, f), wv[k]);
+            if (valid) x[q0 + k] = cmul(czt_packed_from(A.C, a0[k], b0[k], in0, a1[k], b1[k], in1, A.t, om[k], kx, kz[k], f), wv[k]);
         }
     }
 }

@@ -25,6 +25,8 @@ struct CztState {
     int M = 0;
     cf *w1 = nullptr, *w2 = nullptr, *Hh = nullptr, *TWf = nullptr, *TWi = nullptr;
     cf *TT = nullptr, *O = nullptr;  // packed planes (czt_packed_value): [3][N][N + 1] after the z sum (transposed), [3][N][N] after the x sum
+    float *Om = nullptr, *K = nullptr;  // CztArgs::Om / K (k_czt_tables)
+    float table_gravity = -1.f;
     float table_length = -1.f, table_unit_width = -1.f;
 };
 
@@ -503,7 +505,7 @@ __global__ void k_czt_assemble_white(OceanConsts C, const cf* O, cf* hds, float*
 std::vector<cf> build_twiddle_table(int N, int P, int sgn);  // mistral_water.hip
 
 static inline void czt_free(CztState& z) {
-    hipFree(z.w1); hipFree(z.w2); hipFree(z.Hh); hipFree(z.TWf); hipFree(z.TWi); hipFree(z.TT); hipFree(z.O);
+    hipFree(z.w1); hipFree(z.w2); hipFree(z.Hh); hipFree(z.TWf); hipFree(z.TWi); hipFree(z.TT); hipFree(z.O); hipFree(z.Om); hipFree(z.K);
     z = CztState();
 }
 static inline int czt_alloc(CztState& z, int N) {
@@ -517,6 +519,7 @@ static inline int czt_alloc(CztState& z, int N) {
         hipMalloc((void**)&z.TWi, sizeof(cf) * ti.size()) != hipSuccess ||
         hipMalloc((void**)&z.TT, sizeof(cf) * MW_CZT_PLANES * (size_t)N * (N + 1)) != hipSuccess ||
         hipMalloc((void**)&z.O, sizeof(cf) * MW_CZT_PLANES * NN) != hipSuccess ||
+        hipMalloc((void**)&z.Om, sizeof(float) * (size_t)(N + 1) * (N + 1)) != hipSuccess || hipMalloc((void**)&z.K, sizeof(float) * (N + 1)) != hipSuccess ||
         hipMemcpy(z.TWf, tf.data(), sizeof(cf) * tf.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(z.TWi, ti.data(), sizeof(cf) * ti.size(), hipMemcpyHostToDevice) != hipSuccess) {
         czt_free(z);
@@ -526,16 +529,27 @@ static inline int czt_alloc(CztState& z, int N) {
 }
 // chirps and the transform of the wrapped kernel (f64 on the host): uploaded when the handle is created and when its length changes
 // (mw_ocean_create / mw_ocean_reinit_spectrum) -- an enqueue never synchronises or copies
-static inline hipError_t czt_upload_tables(CztState& z, int N, float unit_width, float length, hipStream_t st) {
+__global__ void k_czt_tables(int N, float length, float gravity, float* Om, float* K) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (N + 1) * (N + 1)) czt_table_element(N, length, gravity, e, Om, K);
+}
+static inline hipError_t czt_upload_tables(CztState& z, int N, float unit_width, float length, float gravity, hipStream_t st) {
     std::vector<cf> w1, w2, Hh;
     czt_build_tables(N, N + 1, z.M, unit_width, length, w1, w2, Hh);
     hipError_t e = hipStreamSynchronize(st);  // a step still in flight may be reading the old tables
+    if (e == hipSuccess) {
+        const unsigned ne = (unsigned)((N + 1) * (N + 1));
+        hipLaunchKernelGGL(k_czt_tables, dim3((ne + 255) / 256), dim3(256), 0, st, N, length, gravity, z.Om, z.K);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
     if (e == hipSuccess) e = hipMemcpy(z.w1, w1.data(), sizeof(cf) * (N + 1), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(z.w2, w2.data(), sizeof(cf) * N, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(z.Hh, Hh.data(), sizeof(cf) * z.M, hipMemcpyHostToDevice);
     if (e != hipSuccess) return e;
     z.table_length = length;
     z.table_unit_width = unit_width;
+    z.table_gravity = gravity;
     return hipSuccess;
 }
 #ifndef MW_CZT_FUSED_MAX_M
@@ -585,15 +599,15 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
     CztState& z = d.czt;
     const int N = C.N;
     const unsigned nb = (unsigned)(((size_t)N * N + 127) / 128);
-    if (z.table_length != C.length || z.table_unit_width != C.unit_width) {  // safety net only: the tables are uploaded at creation and at a
-        hipError_t e = czt_upload_tables(z, N, C.unit_width, C.length, st);    // length change (direct_prepare_tables), never inside an enqueue
+    if (z.table_length != C.length || z.table_unit_width != C.unit_width || z.table_gravity != C.gravity) {  // safety net only: the tables are uploaded at creation and at a
+        hipError_t e = czt_upload_tables(z, N, C.unit_width, C.length, C.gravity, st);    // length change (direct_prepare_tables), never inside an enqueue
         if (e != hipSuccess) return e;
     }
     const char* fe = std::getenv("MW_CZT_FUSED");  // read per call: the GPU test flips it inside one process
     const bool fused = !(fe && std::atoi(fe) == 0) && z.M <= MW_CZT_FUSED_MAX_M;
     if (ev) { hipEventRecord(ev[0], st); hipEventRecord(ev[1], st); }
     CztArgs A;
-    A.w1 = z.w1; A.w2 = z.w2; A.Hh = z.Hh; A.TWf = z.TWf; A.TWi = z.TWi;
+    A.w1 = z.w1; A.w2 = z.w2; A.Hh = z.Hh; A.TWf = z.TWf; A.TWi = z.TWi; A.Om = z.Om; A.K = z.K;
     A.nin = N + 1; A.nout = N;  // the packed planes live on the index set [0, N]^2 (czt_packed_value)
     if (czt_one_launch(z, N)) {  // tiny grids: both axes and the assembly in one workgroup (k_czt_one)
         A.h0 = h0; A.h0c = h0c; A.t = t; A.C = C;
@@ -665,8 +679,8 @@ static inline int direct_alloc(DirectState& d, int N, hipStream_t st) {
     return 0;
 }
 // tables that depend on (unit_width, length) but not on t: built when the handle is created and when its length changes
-static inline hipError_t direct_prepare_tables(DirectState& d, int N, float unit_width, float length, hipStream_t st) {
-    if (d.use_czt) return czt_upload_tables(d.czt, N, unit_width, length, st);
+static inline hipError_t direct_prepare_tables(DirectState& d, int N, float unit_width, float length, float gravity, hipStream_t st) {
+    if (d.use_czt) return czt_upload_tables(d.czt, N, unit_width, length, gravity, st);
     return hipSuccess;  // GEMM form: k_direct_tables runs on the stream, inside the first enqueue after a change (asynchronous)
 }
 // flop of one step as the GEMMs execute it (padded), and algorithmically (60 N^3)

@@ -1085,7 +1085,7 @@ static mw_status ocean_create_impl(const mw_params* params, int tiles, mw_ocean*
             }
         } else {
             if (direct_alloc(o->direct, N, o->stream) != 0) { mw_ocean_destroy(o); return fail(MW_ENOMEM, "direct path alloc failed"); }
-            if (direct_prepare_tables(o->direct, N, params->unit_width, params->length, o->stream) != hipSuccess) {
+            if (direct_prepare_tables(o->direct, N, params->unit_width, params->length, params->gravity, o->stream) != hipSuccess) {
                 mw_ocean_destroy(o);
                 return fail(MW_EDEVICE, "direct path: chirp tables could not be uploaded");
             }
@@ -1251,7 +1251,7 @@ mw_status mw_ocean_reinit_spectrum(mw_ocean* o, float length, float wind_x, floa
         if (e == hipSuccess) s = run_prep(o);
         if (s == MW_OK && e == hipSuccess) e = hipStreamSynchronize(o->stream);
         if (s == MW_OK && e == hipSuccess && !o->use_fft && length != old_length)  // chirp tables of the new length, here and not inside the next enqueue
-            e = direct_prepare_tables(o->direct, N, o->p.unit_width, length, o->stream);
+            e = direct_prepare_tables(o->direct, N, o->p.unit_width, length, o->p.gravity, o->stream);
         if (s != MW_OK || e != hipSuccess) {
             o->h0 = old0; o->h0c = old0c;
             o->p.length = old_length;

@@ -604,6 +604,9 @@ int emul_czt_packed(int N, float unit_width, float length, float gravity, const 
     A.nin = N + 1; A.nout = N;
     A.C.N = N; A.C.length = length; A.C.gravity = gravity; A.C.unit_width = unit_width; A.C.choppiness = 1.f;
     A.h0 = reinterpret_cast<const cf*>(h0_xy); A.h0c = reinterpret_cast<const cf*>(h0c_xy); A.t = t;
+    std::vector<float> Om((size_t)(N + 1) * (N + 1)), K(N + 1);  // k_czt_tables
+    for (int e = 0; e < (N + 1) * (N + 1); e++) czt_table_element(N, length, gravity, e, Om.data(), K.data());
+    A.Om = Om.data(); A.K = K.data();
     A.in = tmp.data(); A.out = tmp.data();
     A.rows = N + 1; A.in_ld = N + 1; A.in_plane = (long long)N * (N + 1); A.out_ld = N + 1; A.out_plane = (long long)N * (N + 1);
     int r = czt_pass(M, A, MW_CZT_PLANES);
