@@ -108,9 +108,10 @@ constexpr int czt_rows(int M) { return (512 / (M / czt_points(M))) < 1 ? 1 : ((5
 #define MW_CZT_LOAD_CHUNK 4  // 1: element by element (A/B); 8: slower from M = 2048 up (140 registers)
 #endif
 template <int M, int P, int CH_ = MW_CZT_LOAD_CHUNK>
-MW_HD void czt_load(const CztArgs& A, int f, int row, int u, bool live, cf (&x)[P]) {
+MW_HD void czt_load(const CztArgs& A, int f, int row_, int u, bool live, cf (&x)[P]) {
     constexpr int T = M / P, CH = P < CH_ ? P : CH_;
     const cf z = mk(0.f, 0.f);
+    const int row = live ? row_ : 0;  // a line past the end reads row 0 (and keeps nothing): every address below is in range whatever the caller passed
     if (A.h0 == nullptr) {
         const cf* __restrict__ r = A.in + (size_t)f * A.in_plane + (size_t)row * A.in_ld;
 #pragma unroll

@@ -129,6 +129,9 @@ MW_HD void gerstner_step_vertex(const GerstnerWaves& wv, const GerstnerPhases& p
 // and go, issued in address order, instead of one long-lived workgroup walking all 32 slabs -- on this memory system fresh
 // workgroups beat long-lived ones for every store stream (profiles/r03_hbm_probe.txt); 8 steps per workgroup measured best (the
 // position part, 8 sincos per vertex, is then re-formed 4 times per launch: +13 % VALU, still well under the store time).
+#ifndef MW_POND_LOADS_FIRST
+#define MW_POND_LOADS_FIRST 1
+#endif
 template <int NW>
 __global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict__ pos, float* __restrict__ out, int64_t nverts,
                                                         GerstnerWaves wv, GerstnerPhases ph, int nsteps, float amplitude,
@@ -153,12 +156,17 @@ __global__ __launch_bounds__(256) void k_gerstner_steps(const float* __restrict_
         float sa[4][NW], ca[4][NW];
         bool ok[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int64_t vid = v0 + k * 64 + lane;
+        for (int k = 0; k < 4; k++) {  // the four position loads first (round 5: written load, position part, load, ... the compiler kept each
+            const int64_t vid = v0 + k * 64 + lane;  // load behind the previous vertex's eight sines: four memory latencies at the head of a workgroup)
             ok[k] = vid < nverts;
             const float* p = pos + 3 * (ok[k] ? vid : v0);
             v[3 * k] = p[0]; v[3 * k + 1] = p[1]; v[3 * k + 2] = p[2];
-            gerstner_position_part<NW>(wv, frequency, v[3 * k], v[3 * k + 2], sa[k], ca[k]);
+            if (!MW_POND_LOADS_FIRST) gerstner_position_part<NW>(wv, frequency, v[3 * k], v[3 * k + 2], sa[k], ca[k]);
+        }
+        if (MW_POND_LOADS_FIRST) {
+            mw_sched_fence();
+#pragma unroll
+            for (int k = 0; k < 4; k++) gerstner_position_part<NW>(wv, frequency, v[3 * k], v[3 * k + 2], sa[k], ca[k]);
         }
         for (int step = step_lo; step < step_hi; step++) {
             float* dst = out + (size_t)step * nverts * 3 + 3 * v0;
