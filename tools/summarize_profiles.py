@@ -48,15 +48,25 @@ for f in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
         if any(t in k for t in ("k_pass", "gerstner", "k_or_", "k_pond", "k_gemm", "k_direct")):
             pmc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
             pmc[k]["_dur_ns_" + row["Counter_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            pmc[k]["_grid_" + row["Counter_Name"]].append(row.get("Grid_Size"))
 line = json.loads(bench_line[-1]) if bench_line else None
 out = {"source": src, "build_id": (line or {}).get("build_id"), "bench_line": line, "pmc_mean_per_launch": {}}
 for k, d in pmc.items():
     # drop the short warm-up launches: keep launches within 15 % of the median duration of that counter pass
     o = {}
     for c, vals in d.items():
-        if c.startswith("_dur_ns_"):
+        if c.startswith("_dur_ns_") or c.startswith("_grid_"):
             continue
         durs = d["_dur_ns_" + c]
+        # the launches of the TIMED size first: the launch geometry with the most launches, as in the kernel trace above (a 20-step run also
+        # holds bench.py's 32-step context launches, which are LONGER: the duration cluster below alone once averaged those instead)
+        grids = d["_grid_" + c]
+        if any(g is not None for g in grids):
+            from collections import Counter
+            top = Counter(grids).most_common(1)[0][0]
+            sel = [i for i, g in enumerate(grids) if g == top]
+            vals = [vals[i] for i in sel]
+            durs = [durs[i] for i in sel]
         # bench.py also issues 1-step launches (parity gate, the single-step latency figure): the per-launch means are those
         # of the FULL-batch launches, i.e. of the long-duration cluster
         big = sorted(t for t in durs if t >= 0.5 * max(durs))
