@@ -592,6 +592,27 @@ int emul_czt2d(int N, float unit_width, float length, int nfields, const float* 
     A.in = tmp.data(); A.out = reinterpret_cast<cf*>(out_xy);               // along i: out[f][a][b]
     return czt_pass(M, A, nfields);
 }
+// the tabulated form of an element (what czt_load runs: omega(i, j) and the wave numbers from k_czt_tables' tables) against the form with
+// everything computed in place (czt_packed_value): number of elements of the three planes on [0, N]^2 whose bits differ
+int emul_czt_tables_vs_inline(int N, float length, float gravity, const float* h0_xy, const float* h0c_xy, float t) {
+    OceanConsts C{};
+    C.N = N; C.length = length; C.gravity = gravity; C.unit_width = 1.f; C.choppiness = 1.f;
+    const cf* h0 = reinterpret_cast<const cf*>(h0_xy);
+    const cf* h0c = reinterpret_cast<const cf*>(h0c_xy);
+    std::vector<float> Om((size_t)(N + 1) * (N + 1)), K(N + 1);
+    for (int e = 0; e < (N + 1) * (N + 1); e++) czt_table_element(N, length, gravity, e, Om.data(), K.data());
+    int bad = 0;
+    for (int plane = 0; plane < MW_CZT_PLANES; plane++)
+        for (int i = 0; i <= N; i++)
+            for (int j = 0; j <= N; j++) {
+                const bool in0 = i < N && j < N, in1 = i > 0 && j > 0;
+                const size_t i0 = in0 ? (size_t)i * N + j : 0, i1 = in1 ? (size_t)(N - i) * N + (N - j) : 0;
+                const cf a = czt_packed_from(C, h0[i0], h0c[i0], in0, h0[i1], h0c[i1], in1, t, Om[(size_t)i * (N + 1) + j], K[i], K[j], plane);
+                const cf b = czt_packed_value(C, h0, h0c, t, i, j, plane);
+                if (std::memcmp(&a, &b, sizeof(cf)) != 0) bad++;
+            }
+    return bad;
+}
 // the product's form: the three Hermitian-packed planes formed from (h0, h0conj, t) on the index set [0, N]^2 (czt_packed_value),
 // through the same two launches as czt_evaluate runs them; out [3][a][b] = (H + i Dx, Sx + i Sz, Dz + i 0)
 int emul_czt_packed(int N, float unit_width, float length, float gravity, const float* h0_xy, const float* h0c_xy, float t, float* out_xy) {

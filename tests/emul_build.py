@@ -141,6 +141,12 @@ class Emul:
         assert r == 0, f"emul_czt_packed -> {r}"
         return out[..., 0] + 1j * out[..., 1]
 
+    def czt_tables_vs_inline(self, p, h0, h0c, t):
+        """Elements of the three packed planes on [0, N]^2 whose tabulated form (omega and wave numbers from k_czt_tables' tables: what the
+        launches run) differs in any bit from the form with everything computed in place (czt_packed_value)."""
+        return int(self.L.emul_czt_tables_vs_inline(int(p.N), C.c_float(p.length), C.c_float(p.gravity),
+                                                    _p(np.ascontiguousarray(h0, np.float32)), _p(np.ascontiguousarray(h0c, np.float32)), C.c_float(t)))
+
     def gerstner_steps(self, pos, waves, amplitude, frequency, steepness, times):
         pos = np.ascontiguousarray(pos, np.float32)
         wv = np.ascontiguousarray(waves, np.float32).reshape(-1, 3)

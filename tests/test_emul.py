@@ -350,6 +350,9 @@ def test_chirp_z_form_equals_the_separable_sum(emul, oracle, N, u, L):
         scale = max(np.abs(wantr).max(), np.abs(S[0].real).max() if nm in ("H", "Dx", "Dz") else np.abs(S[3].imag).max())
         assert np.abs(gotr - wantr).max() <= 3e-6 * scale, (nm, np.abs(gotr - wantr).max() / scale)
     assert np.abs(pk[2].imag).max() <= 3e-6 * np.abs(S[0].real).max()
+    # round 5: omega(i, j) and the wave numbers come from tables formed once per handle (k_czt_tables) -- every element of the three planes is
+    # the same bit pattern as with the dispersion and the wave numbers computed in place (czt_packed_value), at two times
+    assert emul.czt_tables_vs_inline(p, h0, h0c, 1.25) == 0 and emul.czt_tables_vs_inline(p, h0, h0c, 3600.5) == 0
 
 
 @pytest.mark.parametrize("N,pts", [(64, 8), (128, 16), (256, 8), (512, 8), (1024, 0)])
