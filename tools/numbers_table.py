@@ -33,7 +33,7 @@ for name, wl, B, NN in (("bench_ocean1024_driver_k20", "ocean1024", 20, 1024 ** 
 b = J("bench_pond"); row("pond", b, f"frac {b['roofline']['frac']:.3f}; " + "; ".join(f"PMC {k} {us:.1f} µs {bpp:.2f} B/vertex-step {tbs:.2f} TB/s" for k, us, bpp, tbs, rd, wr in pmc("pond", 32, 32e6)))
 for name, B in (("bench_renderer1024", 1), ("bench_renderer1024_tiles4", 4)):
     b = J(name); row(name, b, f"frac {b['roofline']['frac']:.3f}; " + "; ".join(f"{k} {us:.1f} µs {bpp:.0f} B {tbs:.1f} TB/s" for k, us, bpp, tbs, rd, wr in pmc("renderer1024", B, 1024 ** 2 * B) if "pass" in k or "normal" in k))
-for n in (50, 100, 1000, 2000):
+for n in (12, 50, 100, 1000, 2000):
     b = J(f"bench_direct_{n}"); print(f"| direct N={n} | {b['value']:.3g} pts/s {b['ms_per_step'] * 1e3:.1f} µs/step | | {[(k['name'][:12], round(k['us_per_step'], 1)) for k in b['roofline']['kernels']]} |")
 c = J("bench_ocean1024_driver_k20")["cpu_baseline"]
 print("cpu:", c["value"], c["sample"][:60], {k: (v.get("value") if isinstance(v, dict) else v) for k, v in c.items() if k in ("fft_port", "fft_port_c", "fft_port_c_threads")})
