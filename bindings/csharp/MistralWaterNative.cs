@@ -1,4 +1,4 @@
-// MistralWaterNative.cs -- the P/Invoke layer over libmistral_water.so (include/mistral_water.h, MW_ABI_VERSION 3).
+// MistralWaterNative.cs -- the P/Invoke layer over libmistral_water.so (include/mistral_water.h, MW_ABI_VERSION 4).
 //
 // Drop into Assets/Mistral Water/Scripts/ next to the two MonoBehaviours of this folder; the shared object goes to
 // Assets/Plugins/x86_64/libmistral_water.so.  Every extern below mirrors one prototype of the header, argument for
@@ -15,7 +15,7 @@ public static class MistralWaterNative
 {
     const string Lib = "mistral_water";
 
-    public const int AbiVersion = 3;
+    public const int AbiVersion = 4;
     public const int CommIdBytes = 128;
 
     public enum Status { OK = 0, EINVAL = 1, ENOTPOW2 = 2, ENOTCOMMENSURATE = 3, ENOMEM = 4, EDEVICE = 5, ESTATE = 6 }
@@ -101,6 +101,11 @@ public static class MistralWaterNative
     [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_device(IntPtr ocean, float deltaTime, IntPtr dHeight, IntPtr dDispXZ, IntPtr dNormal, IntPtr dWhite);
     [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_rgba(IntPtr ocean, float deltaTime, [Out] Color[] height, [Out] Color[] displacement, [Out] Color[] normal, [Out] Color[] white);
     [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_rgba_device(IntPtr ocean, float deltaTime, IntPtr dHeight, IntPtr dDisplacement, IntPtr dNormal, IntPtr dWhite);
+    // nframes consecutive GenerateTexture() calls in one enqueue (bit-identical to nframes single calls, the phase included); device destinations [nframes][...]
+    [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_steps_device(IntPtr ocean, float[] deltaTime, int nframes, IntPtr dHeight, IntPtr dDispXZ, IntPtr dNormal, IntPtr dWhite);
+    [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_steps_rgba_device(IntPtr ocean, float[] deltaTime, int nframes, IntPtr dHeight, IntPtr dDisplacement, IntPtr dNormal, IntPtr dWhite);
+    [DllImport(Lib)] public static extern int mw_ocean_max_frames(IntPtr ocean);
+    [DllImport(Lib)] public static extern Status mw_ocean_frame_textures(IntPtr ocean, int frame, out IntPtr dHeight, out IntPtr dDispXZ, out IntPtr dNormal, out IntPtr dWhite);
     [DllImport(Lib)] public static extern Status mw_ocean_displace_mesh(IntPtr ocean, [Out] Vector3[] vertices, [Out] Vector3[] normals, [Out] float[] colors);
     [DllImport(Lib)] public static extern Status mw_ocean_displace_mesh_device(IntPtr ocean, IntPtr dVertices, IntPtr dNormals, IntPtr dColors);
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MW_ABI_VERSION 3
+#define MW_ABI_VERSION 4
 
 typedef struct mw_ocean mw_ocean; /* opaque; one per FFTMesh / OceanRenderer instance */
 
@@ -177,6 +177,22 @@ mw_status mw_ocean_generate_texture(mw_ocean* o, float delta_time, float* height
 mw_status mw_ocean_generate_texture_device(mw_ocean* o, float delta_time, void* d_height, void* d_disp_xz,
                                            void* d_normal_xyz, void* d_white);
 
+/* Throughput form: nframes CONSECUTIVE GenerateTexture() calls of one ocean in one enqueue.  Frame k advances the stateful phase by
+ * delta_time[k]*mult on top of frame k-1 (F/Dispersion.shader:32-41, F/FFTCommon.cginc:101-104) -- a per-texel chain of one multiply,
+ * one add and one fmod that the spectrum kernel walks in registers -- while the three transforms and the normal / whitecap passes of
+ * different frames are independent and run as nframes-deep launches (S/OceanRenderer.cs:216-307 per frame).  Results, the phase
+ * included, are bit-identical to nframes calls of mw_ocean_generate_texture_device.  delta_time is a HOST array; device destinations
+ * are d_height [nframes][M*M], d_disp_xz [nframes][M*M*2], d_normal_xyz [nframes][M*M*3], d_white [nframes][M*M]; a NULL destination
+ * keeps that texture's frames in the handle (mw_ocean_frame_textures).  Afterwards the handle's latest frame (mw_ocean_displace_mesh,
+ * mw_ocean_get_phase) is frame nframes-1.  1 <= nframes <= mw_ocean_max_frames; single-ocean handles only (a handle of
+ * mw_ocean_create_batch fills the device with tiles instead: MW_ESTATE).  Asynchronous on the handle's stream.                        */
+mw_status mw_ocean_generate_texture_steps_device(mw_ocean* o, const float* delta_time, int32_t nframes, void* d_height,
+                                                 void* d_disp_xz, void* d_normal_xyz, void* d_white);
+int32_t mw_ocean_max_frames(const mw_ocean* o); /* largest nframes one enqueue accepts (0: not an OceanRenderer handle) */
+/* device pointers of frame `frame` of the LATEST steps call for the textures that call kept in the handle (NULL destination there);
+ * a texture that went to a caller buffer reports NULL.  Valid until the next steps call of this handle.                              */
+mw_status mw_ocean_frame_textures(mw_ocean* o, int32_t frame, void** d_height, void** d_disp_xz, void** d_normal_xyz, void** d_white);
+
 /* ---- optional: page-lock caller arrays --------------------------------------------------------------------
  * The host-pointer entry points copy results into caller memory; into ordinary (pageable) arrays that copy runs at
  * ~9 GB/s and dominates the call.  A host that keeps its output arrays for many frames -- the
@@ -198,6 +214,9 @@ mw_status mw_ocean_generate_texture_rgba(mw_ocean* o, float delta_time, float* h
                                          float* normal_rgba, float* white_rgba);
 mw_status mw_ocean_generate_texture_rgba_device(mw_ocean* o, float delta_time, void* d_height_rgba, void* d_disp_rgba,
                                                 void* d_normal_rgba, void* d_white_rgba);
+/* nframes consecutive frames (mw_ocean_generate_texture_steps_device) as the four ARGBFloat targets, [nframes][M*M*4] each.          */
+mw_status mw_ocean_generate_texture_steps_rgba_device(mw_ocean* o, const float* delta_time, int32_t nframes, void* d_height_rgba,
+                                                      void* d_disp_rgba, void* d_normal_rgba, void* d_white_rgba);
 /* The ocean material's vertex stage on the resolution x resolution mesh of S/OceanRenderer.cs:172-207, sampling the
  * textures of the LATEST GenerateTexture() bilinearly at the vertex uv (tex2Dlod, clamp):
  *   vertex = rest + (_Anim.r, _Height.r, _Anim.b) / 8      W/TestOcean.shader:65-66, W/MistralWaterCommon.cginc:22-23

@@ -1404,6 +1404,62 @@ mw_status mw_ocean_generate_texture(mw_ocean* o, float delta_time, float* height
     return MW_OK;
 }
 
+mw_status mw_ocean_generate_texture_steps_device(mw_ocean* o, const float* delta_time, int32_t nframes, void* d_height,
+                                                 void* d_disp_xz, void* d_normal_xyz, void* d_white) {
+    if (!o || !delta_time) return fail(MW_EINVAL, "mw_ocean_generate_texture_steps: NULL argument");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_generate_texture_steps: OceanRenderer semantics only");
+    if (nframes < 1 || nframes > mw_ocean_max_frames(o))
+        return fail(o->orr.tiles != 1 ? MW_ESTATE : MW_EINVAL, o->orr.tiles != 1 ? "mw_ocean_generate_texture_steps: a batched handle (mw_ocean_create_batch) advances one frame per call"
+                                                                                 : "mw_ocean_generate_texture_steps: nframes out of range (mw_ocean_max_frames)");
+    HIP_TRY(hipSetDevice(o->device));
+    o->orr.choppiness = o->p.choppiness;
+    // one frame: the lone-frame plan of mw_ocean_generate_texture_device (latency-bound launch forms); its textures are the handle's own
+    mw_status s = nframes == 1 ? or_generate(o->orr, delta_time[0], (float*)d_height, (float*)d_disp_xz, (float*)d_normal_xyz, (float*)d_white, o->stream)
+                               : or_generate_steps(o->orr, delta_time, nframes, (float*)d_height, (float*)d_disp_xz, (float*)d_normal_xyz,
+                                                   (float*)d_white, o->stream);
+    if (s != MW_OK) return fail(s, or_last_error());
+    o->orr.fr_have[0] = !d_height; o->orr.fr_have[1] = !d_disp_xz; o->orr.fr_have[2] = !d_normal_xyz; o->orr.fr_have[3] = !d_white;
+    o->orr.frames_last = nframes;
+    return MW_OK;
+}
+int32_t mw_ocean_max_frames(const mw_ocean* o) { return (o && o->sem == MW_SEM_OCEANRENDERER && o->orr.tiles == 1) ? MW_OR_MAX_FRAMES : 0; }
+mw_status mw_ocean_frame_textures(mw_ocean* o, int32_t frame, void** d_height, void** d_disp_xz, void** d_normal_xyz, void** d_white) {
+    if (!o) return fail(MW_EINVAL, "NULL handle");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_frame_textures: OceanRenderer semantics only");
+    const OrState& s = o->orr;
+    if (s.frames_last < 1) return fail(MW_ESTATE, "mw_ocean_frame_textures: no mw_ocean_generate_texture_steps_device call yet");
+    if (frame < 0 || frame >= s.frames_last) return fail(MW_EINVAL, "mw_ocean_frame_textures: frame out of range");
+    const size_t off = (size_t)frame * s.M * s.M;
+    if (s.frames_last == 1) {  // a one-frame call ran the lone-frame plan: the frame is the handle's latest
+        if (d_height) *d_height = s.fr_have[0] ? s.out_height : nullptr;
+        if (d_disp_xz) *d_disp_xz = s.fr_have[1] ? s.out_disp : nullptr;
+        if (d_normal_xyz) *d_normal_xyz = s.fr_have[2] ? s.out_normal : nullptr;
+        if (d_white) *d_white = s.fr_have[3] ? s.out_white : nullptr;
+        return MW_OK;
+    }
+    if (d_height) *d_height = s.fr_have[0] ? s.fr_height + off : nullptr;
+    if (d_disp_xz) *d_disp_xz = s.fr_have[1] ? s.fr_disp + off : nullptr;
+    if (d_normal_xyz) *d_normal_xyz = s.fr_have[2] ? s.fr_normal + 3 * off : nullptr;
+    if (d_white) *d_white = s.fr_have[3] ? s.fr_white + off : nullptr;
+    return MW_OK;
+}
+mw_status mw_ocean_generate_texture_steps_rgba_device(mw_ocean* o, const float* delta_time, int32_t nframes, void* d_height_rgba,
+                                                      void* d_disp_rgba, void* d_normal_rgba, void* d_white_rgba) {
+    if (!o || !delta_time) return fail(MW_EINVAL, "mw_ocean_generate_texture_steps_rgba: NULL argument");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_generate_texture_steps_rgba: OceanRenderer semantics only");
+    if (nframes < 1 || nframes > mw_ocean_max_frames(o))
+        return fail(o->orr.tiles != 1 ? MW_ESTATE : MW_EINVAL, "mw_ocean_generate_texture_steps_rgba: nframes out of range, or a batched handle");
+    HIP_TRY(hipSetDevice(o->device));
+    o->orr.choppiness = o->p.choppiness;
+    mw_status s = nframes == 1 ? or_generate_rgba(o->orr, delta_time[0], (f4*)d_height_rgba, (f4*)d_disp_rgba, (f4*)d_normal_rgba, (f4*)d_white_rgba, o->stream)
+                               : or_generate_steps_rgba(o->orr, delta_time, nframes, (f4*)d_height_rgba, (f4*)d_disp_rgba, (f4*)d_normal_rgba,
+                                                        (f4*)d_white_rgba, o->stream);
+    if (s != MW_OK) return fail(s, or_last_error());
+    for (int k = 0; k < 4; k++) o->orr.fr_have[k] = true;
+    o->orr.frames_last = nframes;
+    return MW_OK;
+}
+
 mw_status mw_host_register(void* ptr, size_t bytes) {
     if (!ptr || bytes == 0) return fail(MW_EINVAL, "mw_host_register: NULL pointer or zero size");
     HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));

@@ -44,6 +44,13 @@ struct OrState {
     float* out_disp = nullptr;  // alias of out_disp_cf as floats (r, b)
     float *out_height_g = nullptr, *out_disp_a = nullptr;  // Im h, Im Dz: written only once the RGBA layout was asked for
     bool want_imag = false, have_imag = false, have_frame = false;
+    // mw_ocean_generate_texture_steps_device: [frames_cap] frames of the exchange buffer and of the textures the caller did not ask for
+    // (disp.g always: OceanNormal reads it, no entry point hands it out alone); grown on demand, never shrunk
+    int frames_cap = 0, frames_last = 0;  // capacity / frames of the latest steps call
+    cf* fr_E = nullptr;
+    float *fr_height = nullptr, *fr_disp_g = nullptr, *fr_normal = nullptr, *fr_white = nullptr, *fr_height_g = nullptr, *fr_disp_a = nullptr;
+    cf* fr_disp = nullptr;
+    bool fr_have[4] = {false, false, false, false};  // which textures the latest steps call kept here
 };
 static thread_local std::string g_or_err;
 static inline const char* or_last_error() { return g_or_err.c_str(); }
@@ -124,6 +131,64 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Arg
         }
         or_p1_finish<N, P>(A, tw, jb, tid, f, x, set0);
     }
+}
+
+// nframes consecutive frames of one ocean: grid (M/4 column jobs, 1, frame groups).  KEEP: the initial spectrum of the workgroup's
+// points stays in registers over the frames of its group (else re-read per frame: an L2 hit after the first).
+template <int N, int P, bool KEEP>
+__global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1_steps(OrP1StepsArgs S) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = OrP1Geom<N, P>;
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = FftGeom<N, P>::T;
+    const int tid = threadIdx.x, jb = blockIdx.x;
+    const int k0 = (int)blockIdx.z * S.group, k1 = (k0 + S.group < S.nframes) ? k0 + S.group : S.nframes;
+    OrP1Args A = S.a;
+    const int w = tid / T, u = tid % T;
+    TwStage<N, P, G::NTHREADS, false> tws;
+    tws.load(lds, A.TW, tid);
+    const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
+    cf* set0 = lds + G::TW_LDS;
+    float om[P], ph[P];
+    f4 v[P];
+    or_p1_steps_begin<N, P>(A, jb, tid, om, ph);
+    if (KEEP) or_p1_steps_spectrum<N, P>(A, jb, tid, v);
+    tws.store(lds, tid);  // behind the phase / spectrum requests; published by the first barrier
+    for (int k = 0; k < k0; k++) or_p1_steps_advance<P>(om, ph, S.dt[k]);  // the chain over the frames of the groups before this one
+    A.E += (size_t)3 * N * N * k0;
+    for (int k = k0; k < k1; k++) {
+        cf h[P], x[P];
+        if (!KEEP) or_p1_steps_spectrum<N, P>(A, jb, tid, v);
+        or_p1_steps_advance<P>(om, ph, S.dt[k]);
+        or_p1_steps_animate<P>(v, ph, h);
+        for (int f = 0; f < 3; f++) {
+            or_p1_build<N, P>(A, jb, tid, f, h, x);
+            if (f != 0 || k != k0) __syncthreads();  // the previous field's final-pass reads of the buffers are done
+            stage0_store<N, P, -1>(x, u, set0 + w * G::BUFSTRIDE);
+            __syncthreads();
+#pragma unroll
+            for (int s = 1; s < FftGeom<N, P>::S; s++) {
+                load_slots<N, P>(x, u, set0 + w * G::BUFSTRIDE, s - 1);
+                __syncthreads();
+                stage_store<N, P, -1, false>(x, u, set0 + w * G::BUFSTRIDE, tw, s);
+                __syncthreads();
+            }
+            or_p1_finish<N, P>(A, tw, jb, tid, f, x, set0);
+        }
+        A.E += (size_t)3 * N * N;
+    }
+    if (k1 == S.nframes) or_p1_steps_store_phase<N, P>(A, jb, tid, ph);  // the last group holds the phase after every frame
+}
+
+// the textures of frame `last` of a steps call become the handle's latest frame (mw_ocean_displace_mesh, the tile gather, ...)
+__global__ __launch_bounds__(256) void k_or_copy_frame(size_t MM, const float* h, const cf* d, const float* dg, const float* n, const float* w,
+                                                       const float* hg, const float* da, float* oh, cf* od, float* odg, float* on, float* ow,
+                                                       float* ohg, float* oda) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= MM) return;
+    oh[i] = h[i]; od[i] = d[i]; odg[i] = dg[i]; ow[i] = w[i];
+    on[3 * i] = n[3 * i]; on[3 * i + 1] = n[3 * i + 1]; on[3 * i + 2] = n[3 * i + 2];
+    if (hg) { ohg[i] = hg[i]; oda[i] = da[i]; }
 }
 
 template <int N, int P>
@@ -209,6 +274,8 @@ int plan_points_host(int N);
 static inline void or_free(OrState& s) {
     hipFree(s.initT); hipFree(s.phaseT); hipFree(s.phaseT2); hipFree(s.omT); hipFree(s.TW); hipFree(s.E); hipFree(s.out_height); hipFree(s.out_disp_cf);
     hipFree(s.out_disp_g); hipFree(s.out_normal); hipFree(s.out_white); hipFree(s.out_height_g); hipFree(s.out_disp_a);
+    hipFree(s.fr_E); hipFree(s.fr_height); hipFree(s.fr_disp_g); hipFree(s.fr_normal); hipFree(s.fr_white); hipFree(s.fr_height_g);
+    hipFree(s.fr_disp_a); hipFree(s.fr_disp);
     s = OrState();
 }
 
@@ -342,6 +409,140 @@ static inline mw_status or_generate_rgba(OrState& s, float delta_time, f4* d_hei
     k_or_pack_rgba<<<dim3((unsigned)((MM + 255) / 256), s.tiles), dim3(256), 0, st>>>(s.M, s.out_height, s.out_height_g, s.out_disp_cf,
                                                                               s.out_disp_g, s.out_disp_a, s.out_normal,
                                                                               s.out_white, d_height, d_disp, d_normal, d_white);
+    if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_pack_rgba launch failed"; return MW_EDEVICE; }
+    return MW_OK;
+}
+
+// ---- nframes consecutive GenerateTexture() calls in one enqueue ------------------------------------------------------------------
+// frame buffers of the handle: the exchange buffer and disp.g for `n` frames, plus every texture the caller gave no destination for
+static inline mw_status or_frames_reserve(OrState& s, int n, const bool (&need)[4], bool imag) {
+    const size_t MM = (size_t)s.M * s.M;
+    if (n > s.frames_cap) {  // grow: drop everything (hipFree waits for the device), the arrays come back below at the new size
+        hipFree(s.fr_E); hipFree(s.fr_height); hipFree(s.fr_disp_g); hipFree(s.fr_normal); hipFree(s.fr_white); hipFree(s.fr_height_g);
+        hipFree(s.fr_disp_a); hipFree(s.fr_disp);
+        s.fr_E = nullptr; s.fr_disp = nullptr;
+        s.fr_height = s.fr_disp_g = s.fr_normal = s.fr_white = s.fr_height_g = s.fr_disp_a = nullptr;
+        s.frames_cap = 0; s.frames_last = 0;
+    }
+    const size_t cap = (size_t)(s.frames_cap ? s.frames_cap : n);
+#define OR_FR(ptr, cond, bytes) if ((cond) && !(ptr) && hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { (void)hipGetLastError(); g_or_err = "OceanRenderer: hipMalloc of the frame buffers failed"; return MW_ENOMEM; }
+    OR_FR(s.fr_E, true, sizeof(cf) * 3 * MM * cap) OR_FR(s.fr_disp_g, true, sizeof(float) * MM * cap)
+    OR_FR(s.fr_height, need[0], sizeof(float) * MM * cap) OR_FR(s.fr_disp, need[1], sizeof(cf) * MM * cap)
+    OR_FR(s.fr_normal, need[2], sizeof(float) * 3 * MM * cap) OR_FR(s.fr_white, need[3], sizeof(float) * MM * cap)
+    OR_FR(s.fr_height_g, imag, sizeof(float) * MM * cap) OR_FR(s.fr_disp_a, imag, sizeof(float) * MM * cap)
+#undef OR_FR
+    s.frames_cap = (int)cap;
+    return MW_OK;
+}
+#ifndef MW_OR_FRAME_GROUPS
+#define MW_OR_FRAME_GROUPS 4  // frame groups of a steps call = workgroups per column job (see k_or_pass1_steps)
+#endif
+#ifndef MW_OR_STEPS_KEEP
+#define MW_OR_STEPS_KEEP 1
+#endif
+#ifndef MW_OR_STEPS_MAX_N
+#define MW_OR_STEPS_MAX_N 2048  // above: the 1024-thread P = 16 workgroup has 128 VGPRs per lane, no room for a chain in registers
+#endif
+template <int N>
+static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2Args& A2, hipStream_t st) {
+    constexpr int P = Plan<N>::P;
+    constexpr bool KEEP = MW_OR_STEPS_KEEP != 0 && P <= 8;  // P = 16: 64 more live registers would halve the occupancy
+    static AttrOnce attr1, attr2;
+    {
+        hipError_t e = attr2.set(reinterpret_cast<const void*>(&k_or_pass2<N, P>), OrP2Geom<N, P>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
+    if constexpr (N <= MW_OR_STEPS_MAX_N) {
+        hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_or_pass1_steps<N, P, KEEP>), LB1);
+        if (e != hipSuccess) return e;
+        OrP1StepsArgs S;
+        S.a.initT = s.initT; S.a.omT = s.omT; S.a.phase_in = s.phaseT; S.a.phase_out = s.phaseT2; S.a.TW = s.TW; S.a.E = s.fr_E; S.a.c = s.c;
+        S.a.dt = 0.f; S.a.stream_E = 1;
+        for (int k = 0; k < MW_OR_MAX_FRAMES; k++) S.dt[k] = k < n ? dt[k] : 0.f;
+        S.nframes = n;
+        int groups = MW_OR_FRAME_GROUPS;
+        if (groups > n) groups = n;
+        S.group = (n + groups - 1) / groups;
+        groups = (n + S.group - 1) / S.group;
+        k_or_pass1_steps<N, P, KEEP><<<dim3(N / 4, 1, groups), dim3(NT1), LB1, st>>>(S);
+        std::swap(s.phaseT, s.phaseT2);
+    } else {  // one bandwidth-bound spectrum launch per frame (each already fills the device), the rest n frames deep
+        hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_or_pass1<N, P>), LB1);
+        if (e != hipSuccess) return e;
+        for (int k = 0; k < n; k++) {
+            OrP1Args A1;
+            A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.c = s.c; A1.dt = dt[k];
+            A1.E = s.fr_E + (size_t)3 * N * N * k;
+            A1.stream_E = 1;
+            k_or_pass1<N, P><<<dim3(N / 4, 1, 1), dim3(NT1), LB1, st>>>(A1);
+            std::swap(s.phaseT, s.phaseT2);
+        }
+    }
+    constexpr int NT2 = OrP2Geom<N, P>::NTHREADS, LB2 = OrP2Geom<N, P>::LDS_BYTES;
+    k_or_pass2<N, P><<<dim3(N / 4, 2, n), dim3(NT2), LB2, st>>>(A2);
+    return hipGetLastError();
+}
+// frames k = 0 .. n-1 advance the phase by delta_time[k] * mult one after the other, exactly as n calls of or_generate would; device
+// destinations are [n][M*M*...] (NULL: the frame stays in the handle's own frame buffers).  The handle's latest-frame textures
+// (out_*) receive frame n-1.
+static inline mw_status or_generate_steps(OrState& s, const float* delta_time, int n, float* d_height, float* d_disp, float* d_normal,
+                                          float* d_white, hipStream_t st) {
+    if (s.tiles != 1) { g_or_err = "generate_texture_steps: a batched handle (mw_ocean_create_batch) advances one frame per call"; return MW_ESTATE; }
+    if (n < 1 || n > MW_OR_MAX_FRAMES) { g_or_err = "generate_texture_steps: nframes out of range"; return MW_EINVAL; }
+    s.c.choppiness = s.choppiness;
+    const size_t MM = (size_t)s.M * s.M;
+    if (s.want_imag && !s.out_height_g) {
+        if (hipMalloc((void**)&s.out_height_g, sizeof(float) * MM) != hipSuccess || hipMalloc((void**)&s.out_disp_a, sizeof(float) * MM) != hipSuccess) {
+            g_or_err = "OceanRenderer: hipMalloc failed";
+            return MW_ENOMEM;
+        }
+    }
+    const bool need[4] = {!d_height, !d_disp, !d_normal, !d_white};
+    mw_status r = or_frames_reserve(s, n, need, s.want_imag);
+    if (r != MW_OK) return r;
+    float dt[MW_OR_MAX_FRAMES];
+    for (int k = 0; k < n; k++) dt[k] = delta_time[k] * s.mult;  // S/OceanRenderer.cs:223
+    float* const f_h = d_height ? d_height : s.fr_height;
+    cf* const f_d = d_disp ? reinterpret_cast<cf*>(d_disp) : s.fr_disp;
+    float* const f_n = d_normal ? d_normal : s.fr_normal;
+    float* const f_w = d_white ? d_white : s.fr_white;
+    OrP2Args A2;
+    A2.E = s.fr_E; A2.TW = s.TW; A2.height = f_h; A2.disp = f_d; A2.disp_g = s.fr_disp_g; A2.c = s.c;
+    A2.height_g = s.want_imag ? s.fr_height_g : nullptr;
+    A2.disp_a = s.want_imag ? s.fr_disp_a : nullptr;
+    hipError_t e = hipSuccess;
+    switch (s.M) {
+        case 64: e = or_launch_steps<64>(s, dt, n, A2, st); break;
+        case 128: e = or_launch_steps<128>(s, dt, n, A2, st); break;
+        case 256: e = or_launch_steps<256>(s, dt, n, A2, st); break;
+        case 512: e = or_launch_steps<512>(s, dt, n, A2, st); break;
+        case 1024: e = or_launch_steps<1024>(s, dt, n, A2, st); break;
+        case 2048: e = or_launch_steps<2048>(s, dt, n, A2, st); break;
+        case 4096: e = or_launch_steps<4096>(s, dt, n, A2, st); break;
+        default: g_or_err = "OceanRenderer: unsupported texture size"; return MW_EINVAL;
+    }
+    if (e != hipSuccess) { g_or_err = std::string("OceanRenderer steps launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
+    const unsigned nb = (unsigned)((MM + 255) / 256);
+    k_or_normal_white<true><<<dim3(nb, n), dim3(256), 0, st>>>(s.c, f_h, f_d, s.fr_disp_g, f_n, f_w);
+    const size_t last = (size_t)(n - 1) * MM;
+    k_or_copy_frame<<<dim3(nb), dim3(256), 0, st>>>(MM, f_h + last, f_d + last, s.fr_disp_g + last, f_n + 3 * last, f_w + last,
+                                                    s.want_imag ? s.fr_height_g + last : nullptr, s.want_imag ? s.fr_disp_a + last : nullptr,
+                                                    s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white, s.out_height_g, s.out_disp_a);
+    if (hipGetLastError() != hipSuccess) { g_or_err = "OceanRenderer normal/white launch failed"; return MW_EDEVICE; }
+    s.have_frame = true;
+    s.have_imag = s.want_imag;
+    return MW_OK;
+}
+// the same n frames delivered as the four ARGBFloat render targets, [n][M*M*4] each (any destination may be NULL)
+static inline mw_status or_generate_steps_rgba(OrState& s, const float* delta_time, int n, f4* d_height, f4* d_disp, f4* d_normal, f4* d_white,
+                                               hipStream_t st) {
+    s.want_imag = true;
+    mw_status r = or_generate_steps(s, delta_time, n, nullptr, nullptr, nullptr, nullptr, st);
+    if (r != MW_OK) return r;
+    const size_t MM = (size_t)s.M * s.M;
+    k_or_pack_rgba<<<dim3((unsigned)((MM + 255) / 256), n), dim3(256), 0, st>>>(s.M, s.fr_height, s.fr_height_g, s.fr_disp, s.fr_disp_g, s.fr_disp_a,
+                                                                           s.fr_normal, s.fr_white, d_height, d_disp, d_normal, d_white);
     if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_pack_rgba launch failed"; return MW_EDEVICE; }
     return MW_OK;
 }

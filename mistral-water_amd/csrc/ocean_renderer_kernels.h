@@ -151,6 +151,67 @@ MW_HD void or_p1_animate(const OrP1Args& A, int jb, int tid, bool write_phase, c
         }
     }
 }
+// ---- nframes consecutive GenerateTexture() calls of ONE ocean in one enqueue (mw_ocean_generate_texture_steps_device) ----
+// The recurrence of F/FFTCommon.cginc:101-104 chains the PHASE of a texel from frame to frame -- one multiply, one add and a
+// remainder -- and nothing else: the three transforms of frame k + 1 do not read anything frame k produced.  A workgroup keeps the
+// phases of its 4 columns in registers, advances them frame by frame with the same strict-float32 or_phase_step (so the chain
+// is, bit for bit, the one nframes single calls walk) and emits every frame's three spectra; the final phase is stored once.
+// Frames are cut into groups of `group` consecutive frames (blockIdx.z): the workgroup of group g first walks the chain over the
+// g * group frames before its own (phase steps only: ~6 VALU per texel and frame, against ~500 for a frame's spectra and transforms).
+#define MW_OR_MAX_FRAMES 32
+struct OrP1StepsArgs {
+    OrP1Args a;                    // a.dt unused; a.E = [nframes][3][M/4][M][4]
+    float dt[MW_OR_MAX_FRAMES];    // deltaTime * mult of every frame (S/OceanRenderer.cs:223)
+    int nframes, group;
+};
+// the phases and angular frequencies of this thread's P points (columns px = 4 jb + w, rows py = u + T q)
+template <int N, int P>
+MW_HD void or_p1_steps_begin(const OrP1Args& A, int jb, int tid, float (&om)[P], float (&ph)[P]) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int w = wave_uniform<(T % 64) == 0>(tid / T), u = tid % T, px = 4 * jb + w;
+    const size_t col = (size_t)px * N;
+    const float* const c_om = A.omT + col;
+    const float* const c_pi = A.phase_in + col;
+    const unsigned uo = (unsigned)u;
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        om[q] = (c_om + T * q)[uo];
+        ph[q] = (c_pi + T * q)[uo];
+    }
+}
+template <int N, int P>
+MW_HD void or_p1_steps_spectrum(const OrP1Args& A, int jb, int tid, f4 (&v)[P]) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int w = wave_uniform<(T % 64) == 0>(tid / T), u = tid % T, px = 4 * jb + w;
+    const f4* const c_in = A.initT + (size_t)px * N;
+    const unsigned uo = (unsigned)u;
+#pragma unroll
+    for (int q = 0; q < P; q++) v[q] = (c_in + T * q)[uo];
+}
+template <int P>
+MW_HD void or_p1_steps_advance(const float (&om)[P], float (&ph)[P], float dt) {
+#pragma unroll
+    for (int q = 0; q < P; q++) ph[q] = or_phase_step(om[q], ph[q], dt);
+}
+template <int P>
+MW_HD void or_p1_steps_animate(const f4 (&v)[P], const float (&ph)[P], cf (&h)[P]) {
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        float s, c;
+        mw_sincos(ph[q], &s, &c);
+        h[q] = animate(v[q].x, v[q].y, v[q].z, v[q].w, c, s);  // F/Spectrum.shader:45, as or_p1_animate
+    }
+}
+template <int N, int P>
+MW_HD void or_p1_steps_store_phase(const OrP1Args& A, int jb, int tid, const float (&ph)[P]) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int w = wave_uniform<(T % 64) == 0>(tid / T), u = tid % T, px = 4 * jb + w;
+    float* const c_po = A.phase_out + (size_t)px * N;
+    const unsigned uo = (unsigned)u;
+#pragma unroll
+    for (int q = 0; q < P; q++) (c_po + T * q)[uo] = ph[q];
+}
+
 // f = 0: h (height);  f = 1: hx = -i h kx/w chop;  f = 2: hz   (F/Spectrum.shader:47-49)
 template <int N, int P>
 MW_HD void or_p1_build(const OrP1Args& A, int jb, int tid, int f, const cf (&h)[P], cf (&x)[P]) {
@@ -163,7 +224,10 @@ MW_HD void or_p1_build(const OrP1Args& A, int jb, int tid, int f, const cf (&h)[
         const float kz = or_wave(N, A.c.length, u + T * q);
         const float wl = fmaxf(0.0001f, sqrtf(kx * kx + kz * kz));  // :47
         const float g = ((f == 1) ? kx : kz) / wl * A.c.choppiness;
-        x[q] = mk(h[q].y * g, -h[q].x * g);  // -MultByI(h * k/w) * chop
+        // -MultByI(h * k/w) * chop.  Rounded products (smul): the first butterfly adds these values, and a kernel whose field index is a
+        // compile-time constant would otherwise fuse product and sum into an FMA where the one-field-per-workgroup form (a select in
+        // between) cannot -- the frames of a steps call must equal single calls bit for bit
+        x[q] = mk(smul(h[q].y, g), smul(-h[q].x, g));
     }
 }
 template <int N, int P>

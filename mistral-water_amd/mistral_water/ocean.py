@@ -9,6 +9,22 @@ import numpy as np
 from . import _native as nat
 
 
+_hip = None
+
+
+def _d2h(ptr, shape, dtype=np.float32):
+    """Copy a raw device pointer handed out by the C ABI into a new host array (hipMemcpy, synchronous)."""
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    out = np.empty(shape, dtype)
+    rc = _hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 2)
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy D2H failed ({rc})")
+    return out
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -225,6 +241,31 @@ class Ocean:
         t = [np.empty(self._t(M, M, 4), np.float32) for _ in range(4)]
         nat.check(nat.lib().mw_ocean_generate_texture_rgba(self._h, C.c_float(delta_time), *[_p(a) for a in t]))
         return tuple(t)
+
+    def max_frames(self) -> int:
+        return nat.lib().mw_ocean_max_frames(self._h)
+
+    def generate_texture_steps_device(self, delta_times, d_height=None, d_disp=None, d_normal=None, d_white=None, rgba: bool = False):
+        """len(delta_times) consecutive GenerateTexture() calls in one enqueue (asynchronous).  Device destinations are raw
+        pointers of [n][M*M*...] arrays; None keeps the frames of that texture in the handle (frame_textures)."""
+        dts = np.ascontiguousarray(delta_times, np.float32)
+        fn = nat.lib().mw_ocean_generate_texture_steps_rgba_device if rgba else nat.lib().mw_ocean_generate_texture_steps_device
+        nat.check(fn(self._h, _p(dts), int(dts.size), d_height, d_disp, d_normal, d_white))
+
+    def frame_textures(self, frame: int):
+        """Device pointers (ints, None when that texture went to a caller buffer) of frame `frame` of the latest steps call."""
+        ptrs = [C.c_void_p() for _ in range(4)]
+        nat.check(nat.lib().mw_ocean_frame_textures(self._h, int(frame), *[C.byref(q) for q in ptrs]))
+        return tuple(q.value for q in ptrs)
+
+    def generate_texture_steps(self, delta_times):
+        """Host form of the above for tests and small jobs: -> (height [n,M,M], disp [n,M,M,2], normal [n,M,M,3], white [n,M,M])."""
+        dts = np.ascontiguousarray(delta_times, np.float32)
+        n, M = int(dts.size), self.N
+        self.generate_texture_steps_device(dts)
+        self.synchronize()
+        base = self.frame_textures(0)
+        return tuple(_d2h(ptr, (n, M, M) + tail) for ptr, tail in zip(base, ((), (2,), (3,), ())))
 
     def displace_mesh(self):
         """The ocean material's vertex stage (W/TestOcean.shader:61-79) on the resolution^2 mesh, from the textures

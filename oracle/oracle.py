@@ -285,6 +285,17 @@ def renderer_step_f64(p: RendererParams, init4, phase, delta_time: float, litera
     return hre, np.ascontiguousarray(dtex[..., [0, 2]]), n, w, np.ascontiguousarray(dtex[..., 1])
 
 
+def renderer_advance_phase(p: RendererParams, init4, phase, delta_time: float):
+    """The Dispersion pass alone (F/Dispersion.shader:32-41): `phase` advanced in place by one frame of delta_time, no textures
+    (the spectra orr_spectra_f64 also produces are dropped) -- how a test walks the oracle to frame k of a long chain."""
+    M = p.M
+    init4 = np.ascontiguousarray(init4, np.float32)
+    assert phase.dtype == np.float32 and phase.flags.c_contiguous
+    sd = np.empty((M, M, 4), np.float64)
+    sh = np.empty((M, M, 2), np.float64)
+    lib().orr_spectra_f64(C.byref(p.c()), _fp(init4), _fp(phase), C.c_float(delta_time), _fp(sd), _fp(sh))
+
+
 def renderer_textures_f64(p: RendererParams, init4, phase, delta_time: float):
     """One GenerateTexture() as the four ARGBFloat render targets of S/OceanRenderer.cs:143-146 ([M,M,4] each):
     height (Re h, Im h, Re h, Im h), displacement (Re Dx, Im Dx, Re Dz, Im Dz), normal (n, 1), white (w, w, w, 1).

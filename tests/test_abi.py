@@ -69,7 +69,7 @@ def test_params_struct_layout(mw):
 
 
 def test_abi_version_and_error_string(mw):
-    assert mw.lib().mw_abi_version() == 3
+    assert mw.lib().mw_abi_version() == 4
     assert isinstance(mw.lib().mw_last_error(), bytes)
 
 

@@ -244,6 +244,100 @@ def test_gpu_generate_texture_edge_time_steps(mw, oracle):
         o.close()
 
 
+def _frame_dts(n):
+    # an uneven frame clock (Time.deltaTime is never constant): a hitch, a paused frame and a negative step among ordinary ones
+    base = [0.016, 0.0171, 0.033, 0.0, 0.25, 0.0166, -0.02, 0.0169]
+    return np.array([base[k % len(base)] * (1.0 + 0.01 * (k // len(base))) for k in range(n)], np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resolution,nframes", [(8, 5), (32, 32), (128, 1), (128, 7), (128, 32), (256, 6), (512, 3)])
+def test_gpu_generate_texture_steps_equal_single_calls(mw, oracle, resolution, nframes):
+    """mw_ocean_generate_texture_steps_device: n consecutive GenerateTexture() calls in one enqueue (S/OceanRenderer.cs:216-307 per
+    frame; the phase chain of F/Dispersion.shader:32-41 / F/FFTCommon.cginc:101-104 walked in registers) must be, bit for bit, n
+    single calls -- every texture of every frame and the phase texture after the last one -- at the shipped 1024^2 configuration
+    (n = 1, 7, 32), the P = 16 kernels (2048^2) and the per-frame spectrum fallback (4096^2); frames 0 / mid / last also against
+    the oracle at the usual float32 bounds."""
+    rp = shipped(resolution)
+    M = rp.M
+    kw = dict(resolution=resolution, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude, choppiness=rp.choppiness,
+              gravity=rp.gravity, mult=rp.mult, seed=5, semantics=mw.MW_SEM_OCEANRENDERER)
+    dts = _frame_dts(nframes)
+    with mw.Ocean(**kw) as a, mw.Ocean(**kw) as b:
+        assert a.max_frames() == 32
+        a.generate_texture(0.05); b.generate_texture(0.05)          # not from a zero phase
+        init4 = np.concatenate(a.get_spectrum(), -1)
+        ph = a.get_phase().copy()
+        H, D, Nn, W = a.generate_texture_steps(dts)
+        assert H.shape == (nframes, M, M) and D.shape == (nframes, M, M, 2) and Nn.shape == (nframes, M, M, 3)
+        check = sorted({0, nframes // 2, nframes - 1})
+        for k in range(nframes):
+            h, d, n, w = b.generate_texture(float(dts[k]))
+            assert (H[k] == h).all() and (D[k] == d).all() and (Nn[k] == n).all() and (W[k] == w).all(), (resolution, nframes, k)
+            if k in check and M <= 1024:
+                oh, od, on, ow, og = oracle.renderer_step_f64(rp, init4, ph, float(dts[k]), literal_passes=False)
+                tol_check(h, oh, 3e-6, "height"); tol_check(d, od, 3e-6, "disp")
+                or_bounds.assert_normal_white(n, w, on, ow, rp.length, od[..., 0], og, od[..., 1], oh, tag=f"M={M} frame {k}")
+            elif M <= 1024:
+                oracle.renderer_advance_phase(rp, init4, ph, float(dts[k]))
+        assert (a.get_phase() == b.get_phase()).all()
+        if M <= 1024:
+            assert (a.get_phase() == ph).all()                        # the oracle's strict-float32 recurrence, exact
+        # the handle's latest frame is frame n-1: the vertex stage and the next single frame continue from it
+        va, vb = a.displace_mesh(), b.displace_mesh()
+        assert all((x == y).all() for x, y in zip(va, vb))
+        ta, tb = a.generate_texture(0.02), b.generate_texture(0.02)
+        assert all((x == y).all() for x, y in zip(ta, tb))
+
+
+@pytest.mark.gpu
+def test_gpu_generate_texture_steps_destinations_rgba_and_errors(mw):
+    """Caller-owned device destinations ([n][M*M*...]), the ARGBFloat form, a second call that grows the frame buffers, and the
+    argument errors of the steps entry points."""
+    import ctypes as C
+    import torch
+    rp = shipped(16)
+    M = rp.M
+    kw = dict(resolution=16, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude, choppiness=rp.choppiness,
+              gravity=rp.gravity, mult=rp.mult, seed=9, semantics=mw.MW_SEM_OCEANRENDERER)
+    with mw.Ocean(**kw) as a, mw.Ocean(**kw) as b:
+        dts = _frame_dts(3)
+        want = a.generate_texture_steps(dts)
+        dh = torch.empty((3, M, M), device="cuda"); dd = torch.empty((3, M, M, 2), device="cuda")
+        dn = torch.empty((3, M, M, 3), device="cuda"); dw = torch.empty((3, M, M), device="cuda")
+        b.generate_texture_steps_device(dts, dh.data_ptr(), dd.data_ptr(), None, dw.data_ptr())
+        b.synchronize()
+        assert b.frame_textures(1)[0] is None and b.frame_textures(1)[2] is not None      # only the normal stayed in the handle
+        assert (dh.cpu().numpy() == want[0]).all() and (dd.cpu().numpy() == want[1]).all() and (dw.cpu().numpy() == want[3]).all()
+        # ARGBFloat targets of 9 more frames (grows the frame buffers) == 9 single RGBA frames
+        dts = _frame_dts(9)
+        tex = [torch.empty((9, M, M, 4), device="cuda") for _ in range(4)]
+        a.generate_texture_steps_device(dts, *[t.data_ptr() for t in tex], rgba=True)
+        a.synchronize()
+        for k in range(9):
+            one = b.generate_texture_rgba(float(dts[k]))
+            for t, o in zip(tex, one):
+                assert (t[k].cpu().numpy() == o).all(), k
+        assert (a.get_phase() == b.get_phase()).all()
+        for bad in (0, 33):
+            with pytest.raises(mw.MistralWaterError) as e:
+                a.generate_texture_steps_device(np.zeros(bad, np.float32))
+            assert e.value.status == mw.MW_EINVAL
+        with pytest.raises(mw.MistralWaterError) as e:
+            a.frame_textures(9)
+        assert e.value.status == mw.MW_EINVAL
+    with mw.Ocean(ntiles=2, **kw) as t:
+        assert t.max_frames() == 0
+        with pytest.raises(mw.MistralWaterError) as e:
+            t.generate_texture_steps_device(_frame_dts(2))
+        assert e.value.status == mw.MW_ESTATE
+    with mw.Ocean(resolution=64, length=64.0) as f:
+        assert f.max_frames() == 0
+        with pytest.raises(mw.MistralWaterError) as e:
+            f.generate_texture_steps_device(_frame_dts(2))
+        assert e.value.status == mw.MW_ESTATE
+
+
 @pytest.mark.gpu
 def test_gpu_oceanrenderer_lifecycle(mw):
     r = mw.OceanRenderer()
