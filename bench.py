@@ -63,7 +63,8 @@ def parse():
                     help="all (default) = the ocean1024 headline + at N = 1 BASELINE configs[3] (ocean4096) and [4] (pond) under `configs`")
     ap.add_argument("--direct-n", type=int, default=1000,
                     help="direct: grid size of the non-FFT FFTMesh case (50 = the Inspector default S/FFTMesh.cs:13, 100, 1000)")
-    ap.add_argument("--batch", type=int, default=32, help="time-steps per enqueue (FFTMesh steps are independent in t)")
+    ap.add_argument("--batch", type=int, default=32, help="time-steps per enqueue (FFTMesh steps are independent in t); renderer1024: consecutive "
+                                                           "GenerateTexture() frames per enqueue (1 = one call per frame)")
     ap.add_argument("--preheat-ms", type=float, default=150.0,
                     help="untimed: keep the device busy with the workload this long before the W warm-up steps, so the "
                          "timed region starts at steady clocks (the first ~5 ms after idle run ~25 %% slower)")
@@ -81,8 +82,7 @@ def parse():
                     help="N > 1: 'tiles' = one independent ocean per rank (BASELINE configs[2], weak scaling); 'steps' = ONE ocean, "
                          "contiguous blocks of the K time-steps per rank (SURVEY 8e axis 2, strong scaling)")
     ap.add_argument("--tiles", type=int, default=1,
-                    help="renderer1024: independent oceans per GenerateTexture() (mw_ocean_create_batch); the phase recurrence "
-                         "forbids batching in time, the tile axis is what fills the device")
+                    help="renderer1024: independent oceans per GenerateTexture() (mw_ocean_create_batch), one frame of each per call")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: the library's RCCL gather of the last step of every batch to rank 0, on the side stream")
     return ap.parse_args()
@@ -348,7 +348,12 @@ def main():
             cfgs = {}
             t_extra = time.perf_counter()
             for name, fn, over in (("ocean4096", lambda aa: ocean(aa, e, 4096, extra=True), dict(steps=64, warmup=32, batch=32)),
-                                   ("pond", lambda aa: pond(aa, e, extra=True), dict(steps=3200, warmup=320, batch=32))):
+                                   ("pond", lambda aa: pond(aa, e, extra=True), dict(steps=3200, warmup=320, batch=32)),
+                                   # the reference's shipped demo scene in its own (OceanRenderer) semantics: 32 consecutive frames per
+                                   # enqueue, and one GenerateTexture() per call -- what OceanRenderer.Update drives
+                                   ("renderer1024", lambda aa: renderer(aa, e, extra=True), dict(steps=640, warmup=64, batch=32, tiles=1)),
+                                   ("renderer1024_frame", lambda aa: renderer(aa, e, extra=True),
+                                    dict(steps=400, warmup=50, batch=1, tiles=1, no_cpu_baseline=True))):
                 aa = copy.copy(a)
                 for k, v in over.items():
                     setattr(aa, k, v)
@@ -901,33 +906,120 @@ def direct(a, e):
     return out
 
 
-def renderer(a, e):
-    """OceanRenderer semantics at the reference's shipped configuration (D/Ocean Demo.unity:296-302): 1024^2 textures,
-    one GenerateTexture() per step.  The phase is stateful, so steps cannot be batched (F/FFTCommon.cginc:101-104).
-    Algorithmic bytes per texel: 20 (spectrum + phase in) + 4 (phase out) + 24 + 24 (exchange) + 16 (height, disp.rgb out)
-    + 16 (re-read by the normal/whitecap passes) + 16 (normal, white out) = 120."""
+def renderer(a, e, extra=False):
+    """OceanRenderer semantics at the reference's shipped configuration (D/Ocean Demo.unity:296-302): 1024^2 textures.
+    A "step" is one GenerateTexture() frame (S/OceanRenderer.cs:216-316).  --batch F > 1: F consecutive frames per enqueue
+    (mw_ocean_generate_texture_steps_device: the phase chain of F/FFTCommon.cginc:101-104 walked in registers, bit-identical to F single
+    calls); F = 1 or --tiles T > 1: one call per frame (of T independent oceans).
+    Algorithmic bytes per texel and frame: spectrum 16 + phase in 4 + phase out 4 (once per ENQUEUE: 24 / F) + exchange 24 + 24
+    + height, disp.rgb out 16 + re-read by the normal / whitecap pass 16 + normal, white out 16 = 96 + 24 / F   (120 at F = 1)."""
     import ctypes as C
     from mistral_water import _native as nat
     from oracle import oracle as O
     mw, torch, dev, stream, barrier, dist, rank, world = e.mw, e.torch, e.dev, e.stream, e.barrier, e.dist, e.rank, e.world
+    from mistral_water import parallel as par
     T = max(1, a.tiles)
-    o = mw.Ocean(resolution=128, length=434.48, wind=(14.45, 12.0), amplitude=0.41, choppiness=0.46, mult=1.5,
-                 seed=1 + 64 * rank, semantics=mw.MW_SEM_OCEANRENDERER, device=dev.index, ntiles=T)
+    F = 1 if T > 1 else max(1, min(a.batch, 32))
+    kw = dict(resolution=128, length=434.48, wind=(14.45, 12.0), amplitude=0.41, choppiness=0.46, mult=1.5)
+    o = mw.Ocean(seed=1 + 64 * rank, semantics=mw.MW_SEM_OCEANRENDERER, device=dev.index, ntiles=T, **kw)
     o.set_stream(stream.cuda_stream)
     M = o.N
+    MM = M * M
+    build_id = nat.build_id()
+    DT = 1.0 / 60.0
+    _lib = nat.lib()
+    B, sizes = batch_plan(max(a.steps, 1), F)
+    dest = None
+    if F > 1:       # caller-owned destinations, [F][...] like the FFTMesh enqueue's
+        dest = (torch.empty((B, M, M), dtype=torch.float32, device=dev), torch.empty((B, M, M, 2), dtype=torch.float32, device=dev),
+                torch.empty((B, M, M, 3), dtype=torch.float32, device=dev), torch.empty((B, M, M), dtype=torch.float32, device=dev))
+    _calls = {}
 
-    def step():
-        nat.check(nat.lib().mw_ocean_generate_texture_device(o.handle, C.c_float(1.0 / 60.0), None, None, None, None))
-    preheat(lambda: [step() for _ in range(8)], torch, a.preheat_ms)
-    for _ in range(a.warmup):
-        step()
+    def call(nf):
+        if nf not in _calls:
+            if F == 1:
+                _calls[nf] = (None, _lib.mw_ocean_generate_texture_device, (o.handle, C.c_float(DT), None, None, None, None))
+            else:
+                dts = np.full(nf, DT, np.float32)
+                _calls[nf] = (dts, _lib.mw_ocean_generate_texture_steps_device,
+                              (o.handle, dts.ctypes.data_as(C.c_void_p), nf) + tuple(C.c_void_p(t.data_ptr()) for t in dest))
+        return _calls[nf][1:]
+
+    def run(sz):
+        for nf in sz:
+            fn, args = call(nf)
+            if F == 1:
+                for _ in range(nf):
+                    nat.check(fn(*args))
+            else:
+                nat.check(fn(*args))
+
+    # ---- parity gate before any timing: the enqueue that is timed, frames 0 and last against the oracle, the phase bit for bit ----
+    parity = None
+    if not a.no_parity and rank == 0 and T == 1:
+        import or_bounds
+        rp = O.RendererParams(gravity=9.81, **{k: v for k, v in kw.items() if k != "wind"}, wind_x=kw["wind"][0], wind_y=kw["wind"][1])
+        init4 = np.concatenate(o.get_spectrum(), -1)
+        ph = o.get_phase().copy()
+        if F > 1:
+            run([B])
+            torch.cuda.synchronize()
+            got = {k: tuple(t[k].cpu().numpy() for t in dest) for k in sorted({0, B - 1})}
+        else:       # one frame per call: the host form of the same call (same kernels, results copied out)
+            got = {0: o.generate_texture(DT)}
+        for k in range(B if F > 1 else 1):
+            if k in got:
+                oh, od, on, ow, og = O.renderer_step_f64(rp, init4, ph, DT, literal_passes=False)
+                h, d, n, w = got[k]
+                for x, y, nm in ((h, oh, "height"), (d, od, "disp")):
+                    err, sc = float(np.abs(x - y).max()), max(float(np.abs(y).max()), 1e-6)
+                    assert err <= 3e-6 * sc, f"bench parity gate, frame {k}, {nm}: {err:.3e} vs scale {sc:.3e}"
+                or_bounds.assert_normal_white(n, w, on, ow, rp.length, od[..., 0], og, od[..., 1], oh, tag=f"bench parity gate frame {k}")
+            else:
+                O.renderer_advance_phase(rp, init4, ph, DT)
+        assert (o.get_phase() == ph).all(), "bench parity gate: phase texture differs from the oracle's strict-float32 recurrence"
+        parity = (f"ok (frames {sorted(got)} of a {B if F > 1 else 1}-frame enqueue vs oracle f64: height / disp 3e-6 of scale, normal / whitecap at "
+                  "tests/or_bounds.py; phase texture bit for bit)")
+        del got, init4
+
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    preheat_ms = preheat(lambda: run([B]), torch, a.preheat_ms)
+    run([B] * max(1, -(-a.warmup // B)) if a.warmup > 0 else [])
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    barrier()
+
+    def wall_region():
+        barrier()
+        t0 = time.perf_counter()
+        run(sizes)
+        while not stream.query():
+            pass
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        barrier()
+        return par.max_over_ranks(el, dist, e.red_dev)
+    pilot = wall_region()
+    R = scaled_repeats(pilot, a.repeats, a.min_timed_ms)
+    regions = [wall_region() for _ in range(R)]
+    el = float(np.median(regions))
+
+    # ---- in situ per-launch durations (HIP events on the launch stream between the launches of the same enqueue), rank 0 ----
+    kstats = frame = None
+    if T == 1 and rank == 0:
+        preheat(lambda: run([B]), torch, a.preheat_ms)
+        kstats = o.profile_kernels_stats(nsteps=B, iters=60 if B > 1 else 200)
+        if not a.no_latency and F > 1:      # what OceanRenderer.Update drives: one GenerateTexture() per call
+            one = (o.handle, C.c_float(DT), None, None, None, None)
+            for _ in range(50):
+                nat.check(_lib.mw_ocean_generate_texture_device(*one))
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(400):
+                nat.check(_lib.mw_ocean_generate_texture_device(*one))
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t2) / 400 * 1e6
+            frame = {"device_us_per_frame": us, "device_texels_per_s": MM / (us * 1e-6),
+                     "device_frac_of_hbm_roofline": MM * BYTES_RENDERER / (us * 1e-6) / HBM_PEAK,
+                     "what": "one GenerateTexture() per call (mw_ocean_generate_texture_device), 400 calls back to back, 120 B per texel"}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # the oracle's restatement of the shader pipeline (oracle/ocean_renderer_oracle.c: dispersion, spectrum, normal and
@@ -935,36 +1027,63 @@ def renderer(a, e):
         rp = O.RendererParams(resolution=128, length=434.48, wind_x=14.45, wind_y=12.0, amplitude=0.41, choppiness=0.46, mult=1.5)
         init4 = O.renderer_initial_spectrum(rp, 1)
         ph = np.zeros((M, M), np.float32)
-        O.renderer_step_f64(rp, init4, ph, 1.0 / 60.0, literal_passes=False)
+        O.renderer_step_f64(rp, init4, ph, DT, literal_passes=False)
         t1 = time.perf_counter()
-        frames = 3
+        frames = 8 if extra else 40
         for _ in range(frames):
-            O.renderer_step_f64(rp, init4, ph, 1.0 / 60.0, literal_passes=False)
+            O.renderer_step_f64(rp, init4, ph, DT, literal_passes=False)
         elc = (time.perf_counter() - t1) / frames
-        cpu = {"value": M * M / elc, "unit": "texels/s", "cores": 1, "kind": "port",
+        cpu = {"value": MM / elc, "unit": "texels/s", "cores": 1, "kind": "port",
                "sample": f"{frames} whole GenerateTexture() frames of the same 1024^2 texture through oracle/ocean_renderer_oracle.c "
                          f"(+ numpy fft2 for the Stockham blits), {elc:.2f} s per frame; host has {os.cpu_count()} cores"}
     out = None
     if rank == 0:
-        v = world * a.steps * M * M * T / el
-        from mistral_water import _native as nat2
-        build_id = nat2.build_id()
-        traffic, traffic_note = pmc_traffic("renderer1024", T, "k_or_", build_id)     # the frame's three kernels together
+        v = world * a.steps * MM * T / el
+        bytes_frame = 96.0 + 24.0 / F           # per texel and frame
+        traffic, traffic_note = pmc_traffic("renderer1024", B if T == 1 else T, "k_or_", build_id)     # every kernel of one enqueue
+        shares = (24.0 + 28.0 / F, 40.0, 32.0)  # pass 1: exchange out + (spectrum, omega, phase in / out) once per enqueue; pass 2: exchange in + 16 out; normal / white: 16 + 16
+        kernels, dom = None, None
+        if kstats:
+            kernels = [{"name": nm, "us_per_launch": st["mean"] * 1e3, "us_per_launch_median": st["median"] * 1e3, "us_per_launch_p10": st["p10"] * 1e3,
+                        "us_per_launch_p90": st["p90"] * 1e3,
+                        "algorithmic_bytes_per_texel_frame": (shares[i] if i < 3 else None),
+                        "frac": (shares[i] * MM * B / (st["mean"] * 1e-3) / HBM_PEAK) if i < 3 else None} for i, (nm, st) in enumerate(kstats)]
+            dom = max(range(3), key=lambda i: kstats[i][1]["mean"])
+        rpc = pcts(regions)
+        roof = {"bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s", "traffic": traffic, "traffic_note": traffic_note,
+                "traffic_what": f"HBM-side bytes of one enqueue = {B if T == 1 else T} frame(s), all its kernels",
+                "physical_bytes_per_texel_frame": (traffic / (MM * (B if T == 1 else T))) if traffic else None,
+                "whole_frame": {"algorithmic_bytes_per_texel_frame": bytes_frame, "achieved": v / world * bytes_frame / 1e9,
+                                "frac": v / world * bytes_frame / HBM_PEAK,
+                                "real_frac": (v / world * traffic / (MM * (B if T == 1 else T)) / HBM_PEAK) if traffic else None},
+                "kernels": kernels}
+        if dom is not None:     # the contract's object: the dominant kernel's algorithmic bytes per launch / its mean launch duration
+            k = kernels[dom]
+            roof.update({"kernel": k["name"], "achieved": shares[dom] * MM * B / (k["us_per_launch"] * 1e-6) / 1e9, "frac": k["frac"],
+                         "launch_us": k["us_per_launch"], "frames_per_launch": B, "algorithmic_bytes_per_texel_frame": shares[dom],
+                         "bytes_per_launch": shares[dom] * MM * B})
+        else:
+            roof.update({"kernel": "whole frame (every kernel of a call)", "achieved": v / world * bytes_frame / 1e9, "frac": v / world * bytes_frame / HBM_PEAK})
         out = ({
             "metric": "OceanRenderer-semantics texels/sec (dispersion+spectrum -> 2-D Stockham -> normal -> whitecap), 1024^2",
             "value": v, "unit": "texels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "build_id": build_id,
-            "config": {"workload": "OceanRenderer GenerateTexture(), 1024x1024 textures, shipped demo parameters "
-                                                        "(length 434.48, wind (14.45, 12), amplitude 0.41, choppiness 0.46); "
-                                                        f"{T} independent ocean(s) (seed + k) per call, one frame of each per step",
-                                            "semantics": "MW_SEM_OCEANRENDERER", "tiles_per_call": T,
-                                            "us_per_tile_frame": el / a.steps / T * 1e6},
-            "roofline": {"bound": "hbm", "kernel": "whole frame (3 kernels)", "achieved": v * BYTES_RENDERER / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": v * BYTES_RENDERER / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
-                         "traffic_what": f"HBM-side bytes of one call = {T} tile-frame(s), all three kernels",
-                         "physical_bytes_per_texel": (traffic / (M * M * T)) if traffic else None}, "cpu_baseline": cpu})
+            "data": "synthetic", "build_id": build_id, "preheat_ms": preheat_ms, "repeats": R, "timed_ms_total": sum(regions) * 1e3,
+            "region_ms_stats": {k: (round(x * 1e3, 5) if k != "n" else x) for k, x in rpc.items()},
+            "config": {"workload": "OceanRenderer GenerateTexture(), 1024x1024 textures, shipped demo parameters (D/Ocean Demo.unity:296-302: "
+                                   "length 434.48, wind (14.45, 12), amplitude 0.41, choppiness 0.46, mult 1.5), deltaTime 1/60 s; "
+                                   + (f"{T} independent ocean(s) (seed + k) per call, one frame of each per step" if F == 1 else
+                                      f"one ocean, {B} consecutive frames per enqueue (mw_ocean_generate_texture_steps_device), "
+                                      f"the timed region is {len(sizes)} enqueue(s)"),
+                       "semantics": "MW_SEM_OCEANRENDERER", "tiles_per_call": T, "frames_per_enqueue": B if T == 1 else 1,
+                       "enqueue_sizes_timed": sizes if len(sizes) <= 4 else [sizes[0], "...", sizes[-1]],
+                       "us_per_tile_frame": el / a.steps / T * 1e6},
+            "frame_at_a_time": frame, "parity": parity,
+            "roofline": roof, "cpu_baseline": cpu})
     o.close()
+    del dest
+    _calls.clear()
+    torch.cuda.empty_cache()
     return out
 
 

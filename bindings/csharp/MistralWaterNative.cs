@@ -126,6 +126,8 @@ public static class MistralWaterNative
     [DllImport(Lib)] public static extern Status mw_tiles_outputs(IntPtr tiles, int localK, out IntPtr dVertices, out IntPtr dNormals, out IntPtr dWhite);
     [DllImport(Lib)] public static extern Status mw_tiles_generate_texture(IntPtr tiles, float deltaTime);
     [DllImport(Lib)] public static extern Status mw_tiles_textures(IntPtr tiles, int localK, out IntPtr dHeight, out IntPtr dDispXZ, out IntPtr dNormal, out IntPtr dWhite);
+    [DllImport(Lib)] public static extern Status mw_tiles_generate_texture_steps(IntPtr tiles, float[] deltaTime, int nframes);
+    [DllImport(Lib)] public static extern Status mw_tiles_frames(IntPtr tiles, int localK, out IntPtr dHeight, out IntPtr dDispXZ, out IntPtr dNormal, out IntPtr dWhite);
     [DllImport(Lib)] public static extern Status mw_tiles_gather(IntPtr tiles, int step, int root);
     [DllImport(Lib)] public static extern Status mw_tiles_gathered(IntPtr tiles, out IntPtr dGathered, out long floatsPerTile);
     [DllImport(Lib)] public static extern Status mw_tiles_synchronize(IntPtr tiles);

@@ -229,8 +229,8 @@ mw_status mw_ocean_displace_mesh_device(mw_ocean* o, void* d_vertices_xyz, void*
 /* ---- independent tiles on several devices (BASELINE configs[2]) ------------------------------------
  * Tiles are independent units in both semantics: tile k is the ocean of `params` with seed params->seed + k on its own
  * device, compute stream and output buffers; there is no data-path collective.  FFTMesh tiles advance up to max_steps
- * independent time-steps per mw_tiles_evaluate; OceanRenderer tiles (max_steps must be 1: the phase recurrence,
- * F/FFTCommon.cginc:101-104, serialises time -- only the tile axis shards) one frame per mw_tiles_generate_texture.
+ * independent time-steps per mw_tiles_evaluate; OceanRenderer tiles up to max_steps CONSECUTIVE frames per
+ * mw_tiles_generate_texture_steps (mw_ocean_generate_texture_steps_device per tile; max_steps <= 32 in both semantics).
  * The only exchange is the optional gather of finished outputs to one root device over RCCL (xGMI), issued on per-device SIDE streams behind an event recorded on
  * the compute streams -- once per batch, never per step (29.4 MB per 1024^2 tile ~ 190 us on one 153 GB/s link).
  *   single process : mw_tiles_create -- one RCCL rank per distinct device (ncclCommInitAll, rccl.h:236); tiles that share
@@ -260,7 +260,13 @@ mw_status mw_tiles_outputs(mw_tiles* t, int32_t local_k, void** d_vertices, void
  * of local tile k stay in its handle: height [M*M], disp_xz [M*M*2], normal_xyz [M*M*3], white [M*M].                  */
 mw_status mw_tiles_generate_texture(mw_tiles* t, float delta_time);
 mw_status mw_tiles_textures(mw_tiles* t, int32_t local_k, void** d_height, void** d_disp_xz, void** d_normal_xyz, void** d_white);
-/* Collect step `step` of EVERY tile (OceanRenderer: the latest frame, step = 0) on the device of tile `root` (global tile
+/* OceanRenderer tiles created with max_steps > 1: nframes <= max_steps consecutive frames on every local tile in one enqueue per tile
+ * (delta_time[nframes]: HOST array), asynchronous.  mw_tiles_frames: the frames of local tile k, height [max_steps][M*M], disp_xz
+ * [max_steps][M*M*2], normal_xyz [max_steps][M*M*3], white [max_steps][M*M] (stable pointers; MW_ESTATE when max_steps is 1);
+ * mw_tiles_textures stays the latest frame.  mw_tiles_gather(step) then collects FRAME `step` of the latest call.               */
+mw_status mw_tiles_generate_texture_steps(mw_tiles* t, const float* delta_time, int32_t nframes);
+mw_status mw_tiles_frames(mw_tiles* t, int32_t local_k, void** d_height, void** d_disp_xz, void** d_normal_xyz, void** d_white);
+/* Collect step `step` of EVERY tile (OceanRenderer: frame `step` of the latest call; 0 with max_steps 1) on the device of tile `root` (global tile
  * index): asynchronous, on the side streams.  mw_tiles_gathered: the root's buffer, per tile [N*N*3 | N*N*3 | N*N*w] floats
  * (OceanRenderer: [M*M | M*M*2 | M*M*3 | M*M]); NULL on processes that do not own root.  All multi-device entry points put
  * the caller's current HIP device back before they return.                                                           */

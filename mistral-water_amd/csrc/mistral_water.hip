@@ -1558,10 +1558,62 @@ mw_status mw_ocean_profile_kernels_stats(mw_ocean* o, int32_t nsteps, int32_t it
 static mw_status profile_kernels_impl(mw_ocean* o, int32_t nsteps, int32_t iters, float* ms_out, float* stats_out, const char** names_out,
                                       int32_t* nkernels) {
     if (!o || !ms_out || !nkernels || iters < 1) return fail(MW_EINVAL, "mw_ocean_profile_kernels: bad argument");
-    if (o->sem != MW_SEM_FFTMESH) return fail(MW_ESTATE, "mw_ocean_profile_kernels: FFTMesh semantics only");
     if (nsteps < 1 || nsteps > MW_MAX_BATCH) return fail(MW_EINVAL, "nsteps out of range");
     HIP_TRY(hipSetDevice(o->device));
     HIP_TRY(hipStreamSynchronize(o->stream));
+    if (o->sem == MW_SEM_OCEANRENDERER) {
+        // nsteps frames per enqueue (1: the lone-frame plan), in situ: the launches of a call follow one another as in
+        // mw_ocean_generate_texture[_steps]_device, a HIP event between every two; the frames stay in the handle.  The phase ADVANCES.
+        if (nsteps > 1 && o->orr.tiles != 1) return fail(MW_ESTATE, "mw_ocean_profile_kernels: a batched handle advances one frame per call");
+        static const char* rnames[4] = {"k_or_pass1 (dispersion + spectrum + transform along py)", "k_or_pass2 (transform along px, height / displacement)",
+                                        "k_or_normal_white", "copies (k_or_copy_frame: the last frame becomes the handle's latest)"};
+        static const char* snames[4] = {"k_or_pass1_steps (phase chain + spectra + transform along py, all frames)", rnames[1], rnames[2], rnames[3]};
+        float dts[MW_OR_MAX_FRAMES];
+        for (int k = 0; k < MW_OR_MAX_FRAMES; k++) dts[k] = 1.0f / 60.0f;
+        o->orr.choppiness = o->p.choppiness;
+        auto call = [&](hipEvent_t* ev) {
+            return nsteps == 1 ? or_generate(o->orr, dts[0], nullptr, nullptr, nullptr, nullptr, o->stream, ev)
+                               : or_generate_steps(o->orr, dts, nsteps, nullptr, nullptr, nullptr, nullptr, o->stream, ev);
+        };
+        mw_status s = MW_OK;
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            do {
+                for (int w = 0; w < 2 && s == MW_OK; w++) s = call(nullptr);
+                hipStreamSynchronize(o->stream);
+            } while (s == MW_OK && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.12);
+        }
+        if (s != MW_OK) return fail(s, or_last_error());
+        // events of one call, per chunk j of frames (one chunk in the lone-frame plan): [3j] before its spectrum launch, [3j + 1] after it,
+        // [3j + 2] after its pass 2, [3j + 3] after its normal / whitecap pass; [3 nch + 1] after the copies
+        const int nch = nsteps == 1 ? 1 : or_steps_chunks(o->orr.M, nsteps);
+        const size_t per_it = 2 + 3 * (size_t)nch;
+        std::vector<hipEvent_t> ev(per_it * (size_t)iters);
+        for (auto& e : ev) hipEventCreate(&e);
+        for (int it = 0; it < iters && s == MW_OK; it++) s = call(&ev[per_it * (size_t)it]);
+        hipStreamSynchronize(o->stream);
+        std::vector<float> per[4];
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int it = 0; it < iters && s == MW_OK; it++) {
+            hipEvent_t* e = &ev[per_it * (size_t)it];
+            float m[4] = {0.f, 0.f, 0.f, 0.f}, x = 0.f;
+            for (int j = 0; j < nch; j++)
+                for (int k = 0; k < 3; k++) { hipEventElapsedTime(&x, e[3 * j + k], e[3 * j + k + 1]); m[k] += x; }
+            hipEventElapsedTime(&m[3], e[3 * nch], e[3 * nch + 1]);
+            for (int k = 0; k < 4; k++) { acc[k] += m[k]; per[k].push_back(m[k]); }
+        }
+        for (auto& e : ev) hipEventDestroy(e);
+        if (s != MW_OK) return fail(s, or_last_error());
+        for (int k = 0; k < 4; k++) {
+            ms_out[k] = (float)(acc[k] / iters);
+            if (names_out) names_out[k] = (nsteps == 1 ? rnames : snames)[k];
+            if (stats_out) launch_stats(per[k], stats_out + 6 * k);
+        }
+        *nkernels = 4;
+        o->orr.frames_last = nsteps;
+        for (int k = 0; k < 4; k++) o->orr.fr_have[k] = true;
+        return MW_OK;
+    }
     if (!o->use_fft) {  // direct-sum path: kernel 0 = the four GEMM launches of one step, kernel 1 = spectrum + assembly + whitecap
         if (nsteps != 1) return fail(MW_EINVAL, "mw_ocean_profile_kernels: the direct-sum path evaluates one step per enqueue");
         static const char* gnames[2] = {"k_gemm_f32_mfma (4 launches: z sum, x sum)", "k_direct_spec + k_direct_assemble + k_direct_white"};

@@ -233,6 +233,9 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
 
 // F/OceanNormal.shader + F/WhiteCap.shader in one launch: WhiteCap reads _Bump at its own texel only (:38), so the thread
 // that produced the normal goes straight on to the whitecap (its own global write is visible to itself).
+#ifndef MW_OR_NW_QUAD
+#define MW_OR_NW_QUAD 1  // four texels of a row per thread from 16-byte loads (0: one texel per thread, A/B)
+#endif
 template <bool NT>
 __global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float* height, const cf* disp, const float* disp_g,
                                                          float* normal, float* white) {
@@ -241,15 +244,22 @@ __global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float
     const unsigned nb = gridDim.x, b = blockIdx.x;
     const unsigned blk = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
     int idx = blk * blockDim.x + threadIdx.x;
-    if (idx >= c.M * c.M) return;
     {   // tile blockIdx.y of a batched handle
         const size_t toff = (size_t)blockIdx.y * c.M * c.M;
         height += toff; disp += toff; disp_g += toff; normal += 3 * toff; white += toff;
     }
+#if MW_OR_NW_QUAD
+    const int Q = c.M / 4;  // thread idx: texels 4 (idx % Q) .. + 3 of row idx / Q
+    if (idx >= c.M * Q) return;
+    or_normal_white_quad<NT>(c, 4 * (idx % Q), idx / Q, height, disp, disp_g, normal, white);
+#else
+    if (idx >= c.M * c.M) return;
     float nxz[2];
     or_normal_element<NT>(c, idx % c.M, idx / c.M, height, disp, disp_g, normal, nxz);
     or_white_element<NT>(c, idx % c.M, idx / c.M, disp, normal, white, nxz);
+#endif
 }
+static inline unsigned or_nw_blocks(size_t MM) { return (unsigned)((MM / (MW_OR_NW_QUAD ? 4 : 1) + 255) / 256); }
 
 __global__ void k_or_pack_rgba(int M, const float* height, const float* height_g, const cf* disp, const float* disp_g,
                                const float* disp_a, const float* normal, const float* white, f4* H, f4* D, f4* Nn, f4* W) {
@@ -333,7 +343,7 @@ __global__ void k_or_phase_transpose(int M, const float* src, float* dst) {
 template <int N>
 static inline bool or_call_is_big(const OrState& s) { return s.tiles >= MW_OR_STREAM_E_TILES || N >= MW_OR_STREAM_BIG_N; }
 template <int N>
-static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
+static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st, hipEvent_t* ev = nullptr) {
     constexpr int P = Plan<N>::P;
     static AttrOnce attr1, attr2;
     {
@@ -346,7 +356,9 @@ static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
     A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.E = s.E; A1.c = s.c; A1.dt = dt;
     A1.stream_E = or_call_is_big<N>(s) ? 1 : 0;
     constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
+    if (ev) hipEventRecord(ev[0], st);
     k_or_pass1<N, P><<<dim3(N / 4, (s.tiles > 1 || N >= MW_OR_BIG_N) ? 1 : 3, s.tiles), dim3(NT1), LB1, st>>>(A1);
+    if (ev) hipEventRecord(ev[1], st);
     std::swap(s.phaseT, s.phaseT2);
     OrP2Args A2;
     A2.E = s.E; A2.TW = s.TW; A2.height = s.out_height; A2.disp = s.out_disp_cf; A2.disp_g = s.out_disp_g; A2.c = s.c;
@@ -354,12 +366,14 @@ static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st) {
     A2.disp_a = s.want_imag ? s.out_disp_a : nullptr;
     constexpr int NT2 = OrP2Geom<N, P>::NTHREADS, LB2 = OrP2Geom<N, P>::LDS_BYTES;
     k_or_pass2<N, P><<<dim3(N / 4, 2, s.tiles), dim3(NT2), LB2, st>>>(A2);
+    if (ev) hipEventRecord(ev[2], st);
     return hipGetLastError();
 }
 
 // one GenerateTexture(): results land in s.out_*; optional device destinations receive copies
+// ev (measurement hook, 5 events): recorded before pass 1 and after pass 1, pass 2, the normal / whitecap pass and the copies
 static inline mw_status or_generate(OrState& s, float delta_time, float* d_height, float* d_disp, float* d_normal, float* d_white,
-                                    hipStream_t st) {
+                                    hipStream_t st, hipEvent_t* ev = nullptr) {
     s.c.choppiness = s.choppiness;
     const float dt = delta_time * s.mult;  // S/OceanRenderer.cs:223
     if (s.want_imag && !s.out_height_g) {
@@ -371,23 +385,24 @@ static inline mw_status or_generate(OrState& s, float delta_time, float* d_heigh
     }
     hipError_t e = hipSuccess;
     switch (s.M) {
-        case 64: e = or_launch_passes<64>(s, dt, st); break;
-        case 128: e = or_launch_passes<128>(s, dt, st); break;
-        case 256: e = or_launch_passes<256>(s, dt, st); break;
-        case 512: e = or_launch_passes<512>(s, dt, st); break;
-        case 1024: e = or_launch_passes<1024>(s, dt, st); break;
-        case 2048: e = or_launch_passes<2048>(s, dt, st); break;
-        case 4096: e = or_launch_passes<4096>(s, dt, st); break;
+        case 64: e = or_launch_passes<64>(s, dt, st, ev); break;
+        case 128: e = or_launch_passes<128>(s, dt, st, ev); break;
+        case 256: e = or_launch_passes<256>(s, dt, st, ev); break;
+        case 512: e = or_launch_passes<512>(s, dt, st, ev); break;
+        case 1024: e = or_launch_passes<1024>(s, dt, st, ev); break;
+        case 2048: e = or_launch_passes<2048>(s, dt, st, ev); break;
+        case 4096: e = or_launch_passes<4096>(s, dt, st, ev); break;
         default: g_or_err = "OceanRenderer: unsupported texture size"; return MW_EINVAL;
     }
     if (e != hipSuccess) { g_or_err = std::string("OceanRenderer pass launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
     const size_t MM = (size_t)s.M * s.M, TM = MM * (size_t)s.tiles;
-    const unsigned nb = (unsigned)((MM + 255) / 256);
+    const unsigned nb = or_nw_blocks(MM);
     if (s.tiles >= MW_OR_STREAM_E_TILES || s.M >= MW_OR_STREAM_BIG_N)
         k_or_normal_white<true><<<dim3(nb, s.tiles), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white);
     else
         k_or_normal_white<false><<<dim3(nb, s.tiles), dim3(256), 0, st>>>(s.c, s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white);
     if (hipGetLastError() != hipSuccess) { g_or_err = "OceanRenderer normal/white launch failed"; return MW_EDEVICE; }
+    if (ev) hipEventRecord(ev[3], st);
     s.have_frame = true;
     s.have_imag = s.want_imag;
     hipError_t ce = hipSuccess;
@@ -396,6 +411,7 @@ static inline mw_status or_generate(OrState& s, float delta_time, float* d_heigh
     if (d_normal && ce == hipSuccess) ce = hipMemcpyAsync(d_normal, s.out_normal, TM * 12, hipMemcpyDeviceToDevice, st);
     if (d_white && ce == hipSuccess) ce = hipMemcpyAsync(d_white, s.out_white, TM * 4, hipMemcpyDeviceToDevice, st);
     if (ce != hipSuccess) { g_or_err = std::string("OceanRenderer result copy: ") + hipGetErrorString(ce); return MW_EDEVICE; }
+    if (ev) hipEventRecord(ev[4], st);
     return MW_OK;
 }
 
@@ -440,11 +456,19 @@ static inline mw_status or_frames_reserve(OrState& s, int n, const bool (&need)[
 #ifndef MW_OR_STEPS_KEEP
 #define MW_OR_STEPS_KEEP 1
 #endif
+#ifndef MW_OR_STEPS_CHUNK
+#define MW_OR_STEPS_CHUNK 8  // frames per pass-2 / normal-pass launch pair at 1024^2 (scaled with the texture area)
+#endif
+static inline int or_steps_chunk(int M) {
+    const long long c = (long long)MW_OR_STEPS_CHUNK * 1024 * 1024 / ((long long)M * M);
+    return c < 1 ? 1 : (c > MW_OR_MAX_FRAMES ? MW_OR_MAX_FRAMES : (int)c);
+}
+static inline int or_steps_chunks(int M, int n) { const int c = or_steps_chunk(M); return (n + c - 1) / c; }
 #ifndef MW_OR_STEPS_MAX_N
 #define MW_OR_STEPS_MAX_N 2048  // above: the 1024-thread P = 16 workgroup has 128 VGPRs per lane, no room for a chain in registers
 #endif
 template <int N>
-static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2Args& A2, hipStream_t st) {
+static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2Args& A2, float* f_n, float* f_w, hipStream_t st, hipEvent_t* ev = nullptr) {
     constexpr int P = Plan<N>::P;
     constexpr bool KEEP = MW_OR_STEPS_KEEP != 0 && P <= 8;  // P = 16: 64 more live registers would halve the occupancy
     static AttrOnce attr1, attr2;
@@ -453,6 +477,26 @@ static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2
         if (e != hipSuccess) return e;
     }
     constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
+    if (ev) hipEventRecord(ev[0], st);
+    constexpr int NT2 = OrP2Geom<N, P>::NTHREADS, LB2 = OrP2Geom<N, P>::LDS_BYTES;
+    const size_t MM = (size_t)N * N;
+    const int chunk = or_steps_chunk(N);
+    // pass 2 and the normal / whitecap pass of the frames [c0, c0 + cn)
+    auto rest = [&](int c0, int cn, int j) {
+        OrP2Args B2 = A2;
+        const size_t off = MM * (size_t)c0;
+        B2.E += 3 * off; B2.height += off; B2.disp += off; B2.disp_g += off;
+        if (B2.height_g) B2.height_g += off;
+        if (B2.disp_a) B2.disp_a += off;
+        k_or_pass2<N, P><<<dim3(N / 4, 2, cn), dim3(NT2), LB2, st>>>(B2);
+        if (ev) hipEventRecord(ev[2 + 3 * j], st);
+        k_or_normal_white<true><<<dim3(or_nw_blocks(MM), cn), dim3(256), 0, st>>>(s.c, B2.height, B2.disp, B2.disp_g, f_n + 3 * off, f_w + off);
+        if (ev) hipEventRecord(ev[3 + 3 * j], st);
+    };
+    // Pass 2 and the normal / whitecap pass alternate over chunks of frames: the height / displacement textures a chunk writes (16 B per texel
+    // and frame) are still in the 256-MB Infinity Cache when the normal pass reads them back.  Behind 32 frames of pass-2 output (512 MB at
+    // 1024^2) every read of the normal pass went to HBM: 9.1 us per frame against 7.2 from the cache (chunks of 4 / 8 / 16 / 32 frames:
+    // 21.9 / 21.8 / 23.2 / 23.3 us per frame).
     if constexpr (N <= MW_OR_STEPS_MAX_N) {
         hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_or_pass1_steps<N, P, KEEP>), LB1);
         if (e != hipSuccess) return e;
@@ -461,33 +505,42 @@ static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2
         S.a.dt = 0.f; S.a.stream_E = 1;
         for (int k = 0; k < MW_OR_MAX_FRAMES; k++) S.dt[k] = k < n ? dt[k] : 0.f;
         S.nframes = n;
+        // ONE spectrum launch over all frames: per chunk (so that pass 2 would find the exchange buffer in the cache) it ran 195 -> 283 us per 32
+        // frames and pass 2 no faster -- the exchange buffer is written with streaming stores and does not stay
         int groups = MW_OR_FRAME_GROUPS;
         if (groups > n) groups = n;
         S.group = (n + groups - 1) / groups;
         groups = (n + S.group - 1) / S.group;
         k_or_pass1_steps<N, P, KEEP><<<dim3(N / 4, 1, groups), dim3(NT1), LB1, st>>>(S);
+        for (int c0 = 0, j = 0; c0 < n; c0 += chunk, j++) {
+            if (ev) hipEventRecord(ev[1 + 3 * j], st);
+            rest(c0, (n - c0 < chunk) ? n - c0 : chunk, j);
+        }
         std::swap(s.phaseT, s.phaseT2);
-    } else {  // one bandwidth-bound spectrum launch per frame (each already fills the device), the rest n frames deep
+    } else {  // one bandwidth-bound spectrum launch per frame (each already fills the device)
         hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_or_pass1<N, P>), LB1);
         if (e != hipSuccess) return e;
-        for (int k = 0; k < n; k++) {
-            OrP1Args A1;
-            A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.c = s.c; A1.dt = dt[k];
-            A1.E = s.fr_E + (size_t)3 * N * N * k;
-            A1.stream_E = 1;
-            k_or_pass1<N, P><<<dim3(N / 4, 1, 1), dim3(NT1), LB1, st>>>(A1);
-            std::swap(s.phaseT, s.phaseT2);
+        for (int c0 = 0, j = 0; c0 < n; c0 += chunk, j++) {
+            const int cn = (n - c0 < chunk) ? n - c0 : chunk;
+            for (int k = c0; k < c0 + cn; k++) {
+                OrP1Args A1;
+                A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.c = s.c; A1.dt = dt[k];
+                A1.E = s.fr_E + (size_t)3 * N * N * k;
+                A1.stream_E = 1;
+                k_or_pass1<N, P><<<dim3(N / 4, 1, 1), dim3(NT1), LB1, st>>>(A1);
+                std::swap(s.phaseT, s.phaseT2);
+            }
+            if (ev) hipEventRecord(ev[1 + 3 * j], st);
+            rest(c0, cn, j);
         }
     }
-    constexpr int NT2 = OrP2Geom<N, P>::NTHREADS, LB2 = OrP2Geom<N, P>::LDS_BYTES;
-    k_or_pass2<N, P><<<dim3(N / 4, 2, n), dim3(NT2), LB2, st>>>(A2);
     return hipGetLastError();
 }
 // frames k = 0 .. n-1 advance the phase by delta_time[k] * mult one after the other, exactly as n calls of or_generate would; device
 // destinations are [n][M*M*...] (NULL: the frame stays in the handle's own frame buffers).  The handle's latest-frame textures
 // (out_*) receive frame n-1.
 static inline mw_status or_generate_steps(OrState& s, const float* delta_time, int n, float* d_height, float* d_disp, float* d_normal,
-                                          float* d_white, hipStream_t st) {
+                                          float* d_white, hipStream_t st, hipEvent_t* ev = nullptr) {
     if (s.tiles != 1) { g_or_err = "generate_texture_steps: a batched handle (mw_ocean_create_batch) advances one frame per call"; return MW_ESTATE; }
     if (n < 1 || n > MW_OR_MAX_FRAMES) { g_or_err = "generate_texture_steps: nframes out of range"; return MW_EINVAL; }
     s.c.choppiness = s.choppiness;
@@ -513,23 +566,22 @@ static inline mw_status or_generate_steps(OrState& s, const float* delta_time, i
     A2.disp_a = s.want_imag ? s.fr_disp_a : nullptr;
     hipError_t e = hipSuccess;
     switch (s.M) {
-        case 64: e = or_launch_steps<64>(s, dt, n, A2, st); break;
-        case 128: e = or_launch_steps<128>(s, dt, n, A2, st); break;
-        case 256: e = or_launch_steps<256>(s, dt, n, A2, st); break;
-        case 512: e = or_launch_steps<512>(s, dt, n, A2, st); break;
-        case 1024: e = or_launch_steps<1024>(s, dt, n, A2, st); break;
-        case 2048: e = or_launch_steps<2048>(s, dt, n, A2, st); break;
-        case 4096: e = or_launch_steps<4096>(s, dt, n, A2, st); break;
+        case 64: e = or_launch_steps<64>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 128: e = or_launch_steps<128>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 256: e = or_launch_steps<256>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 512: e = or_launch_steps<512>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 1024: e = or_launch_steps<1024>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 2048: e = or_launch_steps<2048>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 4096: e = or_launch_steps<4096>(s, dt, n, A2, f_n, f_w, st, ev); break;
         default: g_or_err = "OceanRenderer: unsupported texture size"; return MW_EINVAL;
     }
     if (e != hipSuccess) { g_or_err = std::string("OceanRenderer steps launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
-    const unsigned nb = (unsigned)((MM + 255) / 256);
-    k_or_normal_white<true><<<dim3(nb, n), dim3(256), 0, st>>>(s.c, f_h, f_d, s.fr_disp_g, f_n, f_w);
     const size_t last = (size_t)(n - 1) * MM;
-    k_or_copy_frame<<<dim3(nb), dim3(256), 0, st>>>(MM, f_h + last, f_d + last, s.fr_disp_g + last, f_n + 3 * last, f_w + last,
+    k_or_copy_frame<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(MM, f_h + last, f_d + last, s.fr_disp_g + last, f_n + 3 * last, f_w + last,
                                                     s.want_imag ? s.fr_height_g + last : nullptr, s.want_imag ? s.fr_disp_a + last : nullptr,
                                                     s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white, s.out_height_g, s.out_disp_a);
     if (hipGetLastError() != hipSuccess) { g_or_err = "OceanRenderer normal/white launch failed"; return MW_EDEVICE; }
+    if (ev) hipEventRecord(ev[1 + 3 * or_steps_chunks(s.M, n)], st);
     s.have_frame = true;
     s.have_imag = s.want_imag;
     return MW_OK;

@@ -312,29 +312,46 @@ MW_HD int or_clamp(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 // of the 120-B figure, 8 tiles: 0.54 -> 0.60).  The height / displacement textures stay plain stores in every case: the
 // normal kernel reads them back at once (non-temporal: 103 -> 117 us per 4 frames).
 // normal_xz (optional): the normal's x and z as stored, for the whitecap of the same texel (F/WhiteCap.shader:38)
+// the arithmetic of the two shaders for one texel, from values already in registers.  c? = D.rgb at the texel (`center`, :44); r/l/t/b =
+// (disp.r, height, disp.b) of the right / left / top / bottom neighbour (:45-48)
+MW_HD void or_normal_math(float ts, float cx, float cy, float cz, float rx, float rh, float rz, float lx, float lh, float lz, float tx,
+                          float th, float tz, float bx, float bh, float bz, float (&n)[3]) {
+    const float r0 = ts + rx - cx, r1 = rh - cy, r2 = rz - cz;    // :45
+    const float l0 = -ts + lx - cx, l1 = lh - cy, l2 = lz - cz;   // :46
+    const float t0 = tx - cx, t1 = th - cy, t2 = -ts + tz - cz;   // :47
+    const float b0 = bx - cx, b1 = bh - cy, b2 = ts + bz - cz;    // :48
+    // topRight = right x top, topLeft = top x left, bottomLeft = left x bottom, bottomRight = bottom x right
+    float nx = (r1 * t2 - r2 * t1) + (t1 * l2 - t2 * l1) + (l1 * b2 - l2 * b1) + (b1 * r2 - b2 * r1);
+    float ny = (r2 * t0 - r0 * t2) + (t2 * l0 - t0 * l2) + (l2 * b0 - l0 * b2) + (b2 * r0 - b0 * r2);
+    float nz = (r0 * t1 - r1 * t0) + (t0 * l1 - t1 * l0) + (l0 * b1 - l1 * b0) + (b0 * r1 - b1 * r0);
+    const float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+    n[0] = nx * inv; n[1] = ny * inv; n[2] = nz * inv;  // :55
+}
+// ym / yp / xm / xp = displacement.rb at -8 / +8 texels in y and x; (nx, nz) = the normal of the texel (F/WhiteCap.shader:38)
+MW_HD float or_white_math(cf ym, cf yp, cf xm, cf xp, float nx, float nz) {
+    const float dDdy_x = -0.5f * (ym.x - yp.x) / 8.f, dDdy_y = -0.5f * (ym.y - yp.y) / 8.f;  // :36
+    const float dDdx_x = -0.5f * (xm.x - xp.x) / 8.f, dDdx_y = -0.5f * (xm.y - xp.y) / 8.f;  // :37
+    const float n0 = 0.3f * nx, n1 = 0.3f * nz;                                                // :38
+    const float jac = (1.f + dDdx_x) * (1.f + dDdy_y) - dDdx_y * dDdy_x;                       // :39
+    const float turb = fmaxf(0.f, 1.f - jac + sqrtf(n0 * n0 + n1 * n1));                      // :40
+    const float t = turb > 1.f ? 1.f : turb;
+    return t * t * (3.f - 2.f * t);  // smoothstep(0,1,turb), :43
+}
 template <bool NT = false>
 MW_HD void or_normal_element(const OrConsts& c, int px, int py, const float* height, const cf* disp, const float* disp_g,
                              float* normal, float* normal_xz = nullptr) {
     const int M = c.M;
     const float ts = c.normal_length / (float)M;  // F/OceanNormal.shader:42 with the length of SetParams
     const size_t idx = (size_t)py * M + px;
-    const float cx = disp[idx].x, cy = disp_g[idx], cz = disp[idx].y;  // center = D.rgb (:44)
     const size_t ir = (size_t)py * M + or_clamp(px + 1, M - 1), il = (size_t)py * M + or_clamp(px - 1, M - 1);
     const size_t it = (size_t)or_clamp(py - 1, M - 1) * M + px, ib = (size_t)or_clamp(py + 1, M - 1) * M + px;
-    const float r0 = ts + disp[ir].x - cx, r1 = height[ir] - cy, r2 = disp[ir].y - cz;    // :45
-    const float l0 = -ts + disp[il].x - cx, l1 = height[il] - cy, l2 = disp[il].y - cz;   // :46
-    const float t0 = disp[it].x - cx, t1 = height[it] - cy, t2 = -ts + disp[it].y - cz;   // :47
-    const float b0 = disp[ib].x - cx, b1 = height[ib] - cy, b2 = ts + disp[ib].y - cz;    // :48
-    // topRight = right x top, topLeft = top x left, bottomLeft = left x bottom, bottomRight = bottom x right
-    float nx = (r1 * t2 - r2 * t1) + (t1 * l2 - t2 * l1) + (l1 * b2 - l2 * b1) + (b1 * r2 - b2 * r1);
-    float ny = (r2 * t0 - r0 * t2) + (t2 * l0 - t0 * l2) + (l2 * b0 - l0 * b2) + (b2 * r0 - b0 * r2);
-    float nz = (r0 * t1 - r1 * t0) + (t0 * l1 - t1 * l0) + (l0 * b1 - l1 * b0) + (b0 * r1 - b1 * r0);
-    const float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
-    const float ox = nx * inv, oy = ny * inv, oz = nz * inv;  // :55
-    mw_store_stream<NT>(&normal[3 * idx], ox);
-    mw_store_stream<NT>(&normal[3 * idx + 1], oy);
-    mw_store_stream<NT>(&normal[3 * idx + 2], oz);
-    if (normal_xz) { normal_xz[0] = ox; normal_xz[1] = oz; }
+    float n[3];
+    or_normal_math(ts, disp[idx].x, disp_g[idx], disp[idx].y, disp[ir].x, height[ir], disp[ir].y, disp[il].x, height[il], disp[il].y,
+                   disp[it].x, height[it], disp[it].y, disp[ib].x, height[ib], disp[ib].y, n);
+    mw_store_stream<NT>(&normal[3 * idx], n[0]);
+    mw_store_stream<NT>(&normal[3 * idx + 1], n[1]);
+    mw_store_stream<NT>(&normal[3 * idx + 2], n[2]);
+    if (normal_xz) { normal_xz[0] = n[0]; normal_xz[1] = n[2]; }
 }
 // normal_xz: (n.x, n.z) of this texel when the caller has just computed it, else read from `normal`
 template <bool NT = false>
@@ -345,14 +362,52 @@ MW_HD void or_white_element(const OrConsts& c, int px, int py, const cf* disp, c
     // texelSize = 1/_Length with _Length = resolution = M/8 (S/OceanRenderer.cs:306): +-8 texels
     const cf ym = disp[(size_t)or_clamp(py - 8, M - 1) * M + px], yp = disp[(size_t)or_clamp(py + 8, M - 1) * M + px];
     const cf xm = disp[(size_t)py * M + or_clamp(px - 8, M - 1)], xp = disp[(size_t)py * M + or_clamp(px + 8, M - 1)];
-    const float dDdy_x = -0.5f * (ym.x - yp.x) / 8.f, dDdy_y = -0.5f * (ym.y - yp.y) / 8.f;  // :36
-    const float dDdx_x = -0.5f * (xm.x - xp.x) / 8.f, dDdx_y = -0.5f * (xm.y - xp.y) / 8.f;  // :37
-    const float n0 = 0.3f * (normal_xz ? normal_xz[0] : normal[3 * idx]);                     // :38
-    const float n1 = 0.3f * (normal_xz ? normal_xz[1] : normal[3 * idx + 2]);
-    const float jac = (1.f + dDdx_x) * (1.f + dDdy_y) - dDdx_y * dDdy_x;                     // :39
-    const float turb = fmaxf(0.f, 1.f - jac + sqrtf(n0 * n0 + n1 * n1));                    // :40
-    const float t = turb > 1.f ? 1.f : turb;
-    mw_store_stream<NT>(&white[idx], t * t * (3.f - 2.f * t));             // smoothstep(0,1,turb), :43
+    mw_store_stream<NT>(&white[idx], or_white_math(ym, yp, xm, xp, normal_xz ? normal_xz[0] : normal[3 * idx],
+                                                   normal_xz ? normal_xz[1] : normal[3 * idx + 2]));
+}
+// Both passes for the FOUR texels px0 .. px0 + 3 (px0 a multiple of 4) of row py from 16-byte loads: 6 loads and 1 store instruction per
+// texel instead of 14 and 4, the normal leaves as three float4 (48 contiguous bytes per thread).  Same arithmetic per texel.
+template <bool NT = false>
+MW_HD void or_normal_white_quad(const OrConsts& c, int px0, int py, const float* height, const cf* disp, const float* disp_g, float* normal,
+                                float* white) {
+    const int M = c.M;
+    const float ts = c.normal_length / (float)M;
+    const size_t rc = (size_t)py * M, rt = (size_t)or_clamp(py - 1, M - 1) * M, rb = (size_t)or_clamp(py + 1, M - 1) * M;
+    const size_t r8m = (size_t)or_clamp(py - 8, M - 1) * M, r8p = (size_t)or_clamp(py + 8, M - 1) * M;
+    auto ld4 = [](const void* p) { return *reinterpret_cast<const f4*>(p); };
+    cf dc[6], dt[4], db[4], dym[4], dyp[4], dxm[4], dxp[4];
+    float hc[6], ht[4], hb[4], gc[4];
+    auto split = [&](const cf* p, cf* o) {  // 4 consecutive cf = 2 x 16 bytes
+        const f4 a = ld4(p), b = ld4(p + 2);
+        o[0] = mk(a.x, a.y); o[1] = mk(a.z, a.w); o[2] = mk(b.x, b.y); o[3] = mk(b.z, b.w);
+    };
+    auto split1 = [&](const float* p, float* o) { const f4 a = ld4(p); o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; };
+    split(disp + rc + px0, dc + 1);
+    dc[0] = disp[rc + or_clamp(px0 - 1, M - 1)]; dc[5] = disp[rc + or_clamp(px0 + 4, M - 1)];
+    split1(height + rc + px0, hc + 1);
+    hc[0] = height[rc + or_clamp(px0 - 1, M - 1)]; hc[5] = height[rc + or_clamp(px0 + 4, M - 1)];
+    split1(disp_g + rc + px0, gc);
+    split(disp + rt + px0, dt); split1(height + rt + px0, ht);
+    split(disp + rb + px0, db); split1(height + rb + px0, hb);
+    split(disp + r8m + px0, dym); split(disp + r8p + px0, dyp);
+    // +-8 texels along the row: px0 - 8 .. px0 - 5 and px0 + 8 .. px0 + 11; outside the row all four clamp to the edge texel
+    split(disp + rc + or_clamp(px0 - 8, M - 4), dxm);
+    split(disp + rc + or_clamp(px0 + 8, M - 4), dxp);
+    if (px0 < 8) { const cf e = disp[rc]; dxm[0] = dxm[1] = dxm[2] = dxm[3] = e; }
+    if (px0 + 8 > M - 4) { const cf e = disp[rc + M - 1]; dxp[0] = dxp[1] = dxp[2] = dxp[3] = e; }
+    float n[4][3], w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        or_normal_math(ts, dc[k + 1].x, gc[k], dc[k + 1].y, dc[k + 2].x, hc[k + 2], dc[k + 2].y, dc[k].x, hc[k], dc[k].y, dt[k].x, ht[k], dt[k].y,
+                       db[k].x, hb[k], db[k].y, n[k]);
+        w[k] = or_white_math(dym[k], dyp[k], dxm[k], dxp[k], n[k][0], n[k][2]);
+    }
+    f4 o;
+    float* np_ = normal + 3 * (rc + px0);
+    o.x = n[0][0]; o.y = n[0][1]; o.z = n[0][2]; o.w = n[1][0]; mw_store_stream<NT>(reinterpret_cast<f4*>(np_), o);
+    o.x = n[1][1]; o.y = n[1][2]; o.z = n[2][0]; o.w = n[2][1]; mw_store_stream<NT>(reinterpret_cast<f4*>(np_ + 4), o);
+    o.x = n[2][2]; o.y = n[3][0]; o.z = n[3][1]; o.w = n[3][2]; mw_store_stream<NT>(reinterpret_cast<f4*>(np_ + 8), o);
+    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3]; mw_store_stream<NT>(reinterpret_cast<f4*>(white + rc + px0), o);
 }
 
 

@@ -59,11 +59,16 @@ BUILD_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 
 
+def csrc_files():
+    """The kernel sources (csrc/*.hip, *.h, *.inc), sorted: what the library is built from and what source_hash() covers."""
+    return sorted(os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".h", ".inc")))
+
+
 def source_hash(extra=()) -> str:
     """What mw_build_id() reports (-DMW_BUILD_HASH): SHA-256 over the kernel sources, the boundary headers and the compile flags."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted(os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)) + [HEADER_PATH, HOOKS_HEADER_PATH]:
+    for path in csrc_files() + [HEADER_PATH, HOOKS_HEADER_PATH]:
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:
             h.update(f.read())
@@ -76,7 +81,7 @@ def build_native(force: bool = False, verbose: bool = False, out: str | None = N
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU).
     `out` / `extra` / `tag`: an A/B variant (tools/build_variant.sh): other output path, extra -D flags, the tag mw_build_id() carries."""
     target = out or LIB_PATH
-    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR)] + [HEADER_PATH, HOOKS_HEADER_PATH]
+    srcs = csrc_files() + [HEADER_PATH, HOOKS_HEADER_PATH]
     if (not force and not extra and os.path.exists(target)
             and all(os.path.getmtime(s) <= os.path.getmtime(target) for s in srcs)):
         return target
@@ -138,6 +143,8 @@ def lib():
         "mw_tiles_outputs": (C.c_int, [vp, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "mw_tiles_generate_texture": (C.c_int, [vp, C.c_float]),
         "mw_tiles_textures": (C.c_int, [vp, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "mw_tiles_generate_texture_steps": (C.c_int, [vp, f32p, C.c_int32]),
+        "mw_tiles_frames": (C.c_int, [vp, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "mw_tiles_gather": (C.c_int, [vp, C.c_int32, C.c_int32]),
         "mw_tiles_gathered": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int64)]),
         "mw_tiles_synchronize": (C.c_int, [vp]),
@@ -204,6 +211,7 @@ ABI_SYMBOLS = [
     "mw_ocean_set_timer", "mw_ocean_normal_length", "mw_ocean_set_normal_length", "mw_comm_unique_id", "mw_tiles_create",
     "mw_tiles_create_rank", "mw_tiles_destroy", "mw_tiles_count",
     "mw_tiles_local_count", "mw_tiles_ocean", "mw_tiles_evaluate", "mw_tiles_outputs", "mw_tiles_generate_texture", "mw_tiles_textures",
+    "mw_tiles_generate_texture_steps", "mw_tiles_frames",
     "mw_tiles_gather", "mw_tiles_gathered",
     "mw_tiles_synchronize", "mw_ocean_rest_mesh", "mw_ocean_index_count",
     "mw_ocean_grid_size", "mw_ocean_evaluate", "mw_ocean_update", "mw_ocean_timer", "mw_ocean_reset_timer",

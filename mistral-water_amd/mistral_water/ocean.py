@@ -478,6 +478,17 @@ class Tiles:
         nat.check(nat.lib().mw_tiles_textures(self._h, int(k), C.byref(h), C.byref(d), C.byref(n), C.byref(w)))
         return h.value, d.value, n.value, w.value
 
+    def generate_texture_steps(self, delta_times):
+        """OceanRenderer tiles (max_steps > 1): len(delta_times) consecutive GenerateTexture() calls on every local tile, one enqueue each."""
+        dts = np.ascontiguousarray(delta_times, np.float32)
+        nat.check(nat.lib().mw_tiles_generate_texture_steps(self._h, _p(dts), int(dts.size)))
+
+    def frames(self, k):
+        """OceanRenderer tiles (max_steps > 1): device pointers of local tile k's [max_steps] frames: height, disp_xz, normal_xyz, white."""
+        h, d, n, w = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nat.check(nat.lib().mw_tiles_frames(self._h, int(k), C.byref(h), C.byref(d), C.byref(n), C.byref(w)))
+        return h.value, d.value, n.value, w.value
+
     def gather(self, step: int = 0, root: int = 0):
         nat.check(nat.lib().mw_tiles_gather(self._h, int(step), int(root)))
 

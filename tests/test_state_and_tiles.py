@@ -555,7 +555,7 @@ def test_oceanrenderer_tiles_and_rccl_gather(mw, ntiles, gather_path):
     kw = dict(resolution=rp.resolution, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude, choppiness=rp.choppiness,
               gravity=rp.gravity, mult=rp.mult, semantics=mw.MW_SEM_OCEANRENDERER)
     with pytest.raises(mw.MistralWaterError) as e:
-        mw.Tiles(ntiles=1, devices=[0], max_steps=2, seed=5, **kw)             # time does not batch in this semantics
+        mw.Tiles(ntiles=1, devices=[0], max_steps=33, seed=5, **kw)            # at most 32 frames per enqueue
     assert e.value.status == mw.MW_EINVAL
     singles = [mw.Ocean(seed=5 + k, **kw) for k in range(ntiles)]
     with mw.Tiles(ntiles=ntiles, devices=[0] * ntiles, max_steps=1, seed=5, **kw) as t:
@@ -580,6 +580,62 @@ def test_oceanrenderer_tiles_and_rccl_gather(mw, ntiles, gather_path):
             assert (got[k, 3 * MM:6 * MM] == n.ravel()).all() and (got[k, 6 * MM:] == w.ravel()).all(), k
             ph, pd, pn, pw = t.textures(k)
             assert (_d2h(pn, 3 * MM) == n.ravel()).all()
+    for o in singles:
+        o.close()
+
+
+@pytest.mark.parametrize("ntiles", [1, 2])
+def test_oceanrenderer_tiles_frames_per_enqueue_and_gather(mw, ntiles, gather_path):
+    """OceanRenderer tiles with max_steps > 1 (mw_tiles_generate_texture_steps): every tile runs its frames as ONE enqueue
+    (mw_ocean_generate_texture_steps_device: the phase chain of F/FFTCommon.cginc:101-104 in registers) and is, frame by frame and bit
+    for bit, the single handle of seed + k called once per frame; mw_tiles_gather(step) collects FRAME `step` of every tile."""
+    rp = shipped(resolution=16, length=60.0)
+    MM = rp.M * rp.M
+    kw = dict(resolution=rp.resolution, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude, choppiness=rp.choppiness,
+              gravity=rp.gravity, mult=rp.mult, semantics=mw.MW_SEM_OCEANRENDERER)
+    singles = [mw.Ocean(seed=5 + k, **kw) for k in range(ntiles)]
+    F = 5
+    dts = [0.016, 0.3, 0.0, 0.02, 0.017]
+    with mw.Tiles(ntiles=ntiles, devices=[0] * ntiles, max_steps=F, seed=5, **kw) as t:
+        with pytest.raises(mw.MistralWaterError) as e:
+            t.generate_texture_steps(dts + [0.1])                                # more frames than max_steps
+        assert e.value.status == mw.MW_EINVAL
+        want = None
+        for rnd in range(2):                                                     # the second enqueue continues the first one's phase
+            t.generate_texture_steps(dts)
+            want = [[o.generate_texture(dt) for dt in dts] for o in singles]
+        t.gather(step=3, root=0)
+        t.synchronize()
+        ptr, fpt = t.gathered()
+        assert ptr and fpt == MM * 7
+        got = _d2h(ptr, ntiles * fpt).reshape(ntiles, fpt)
+        for k in range(ntiles):
+            h, d, n, w = want[k][3]
+            assert (got[k, :MM] == h.ravel()).all() and (got[k, MM:3 * MM] == d.ravel()).all(), k
+            assert (got[k, 3 * MM:6 * MM] == n.ravel()).all() and (got[k, 6 * MM:] == w.ravel()).all(), k
+            ph, pd, pn, pw = t.frames(k)
+            fh, fn = _d2h(ph, F * MM).reshape(F, MM), _d2h(pn, F * 3 * MM).reshape(F, 3 * MM)
+            for f in range(F):
+                assert (fh[f] == want[k][f][0].ravel()).all() and (fn[f] == want[k][f][2].ravel()).all(), (k, f)
+            lh = t.textures(k)[0]                                                # the handle's latest frame = the last one
+            assert (_d2h(lh, MM) == want[k][F - 1][0].ravel()).all()
+        t.generate_texture_steps(dts[:2])                                        # a shorter enqueue: frame 3 is no longer there
+        with pytest.raises(mw.MistralWaterError) as e:
+            t.gather(step=3, root=0)
+        assert e.value.status == mw.MW_EINVAL
+        t.generate_texture(0.05)                                                 # one frame through the same tiles
+        t.gather(step=0, root=0)
+        t.synchronize()
+        got = _d2h(t.gathered()[0], ntiles * fpt).reshape(ntiles, fpt)
+        for k, o in enumerate(singles):
+            for dt in dts[:2]:
+                o.generate_texture(dt)
+            h = o.generate_texture(0.05)[0]
+            assert (got[k, :MM] == h.ravel()).all(), k
+    with mw.Tiles(ntiles=1, devices=[0], max_steps=1, seed=5, **kw) as t1:
+        with pytest.raises(mw.MistralWaterError) as e:
+            t1.frames(0)
+        assert e.value.status == mw.MW_ESTATE
     for o in singles:
         o.close()
 

@@ -8,12 +8,14 @@ import numpy as np
 import mistral_water as mw
 from mistral_water import _native as nat
 print("build", nat.build_id())
+import os
+NS = [int(x) for x in os.environ.get("PROBE_N", "0,1,2,4,8,16,32").split(",")]
 for res in [int(x) for x in sys.argv[1:]] or [128]:
     M = 8 * res
     o = mw.Ocean(resolution=res, length=434.48 * M / 1024, wind=(14.45, 12.0), amplitude=0.41, choppiness=0.46, mult=1.5, semantics=nat.MW_SEM_OCEANRENDERER)
     def single(): nat.check(nat.lib().mw_ocean_generate_texture_device(o.handle, C.c_float(1.0 / 60.0), None, None, None, None))
     row = []
-    for n in (0, 1, 2, 4, 8, 16, 32):
+    for n in NS:
         if n * M * M * 60 > 40e9:
             continue
         dts = np.full(max(n, 1), 1.0 / 60.0, np.float32)
