@@ -84,7 +84,11 @@ def parse():
     ap.add_argument("--tiles", type=int, default=1,
                     help="renderer1024: independent oceans per GenerateTexture() (mw_ocean_create_batch), one frame of each per call")
     ap.add_argument("--gather", action="store_true",
-                    help="N > 1: the library's RCCL gather of the last step of every batch to rank 0, on the side stream")
+                    help="the library's RCCL gather of the last step of every batch to rank 0, on the side stream, as a second set of timed "
+                         "regions (`with_gather`).  N > 1 runs it by default (SURVEY 8d config 3: with AND without the gather)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the with_gather regions")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="N > 1: skip the `strong` object (ONE ocean, the K time-steps sharded over the ranks: --shard steps as a sub-run)")
     return ap.parse_args()
 
 
@@ -324,6 +328,32 @@ def setup(a):
         torch.cuda.synchronize()
     e.barrier = barrier
     e.hung = False
+
+    # Watchdog around the phases that have never met a multi-GPU node (the RCCL gather, the strong-scaling sub-run): if one of them does
+    # not come back in time, rank 0 still prints the ONE line -- the last object handed to checkpoint(), with the phase named in it -- and
+    # every rank leaves (all ranks arm the same deadline).  A hung collective must not cost the driver its scaling curve.
+    import threading
+    e._partial, e._timer = None, None
+
+    def checkpoint(obj):
+        e._partial = obj
+
+    def arm(seconds, phase):
+        def fire():
+            if e.rank == 0 and e._partial is not None:
+                e._partial["aborted_phase"] = {"phase": phase, "after_s": seconds, "note": "did not return in time; the line carries everything measured before it"}
+                emit(e._partial)
+            os._exit(0 if e._partial is not None or e.rank != 0 else 3)
+        disarm()
+        e._timer = threading.Timer(seconds, fire)
+        e._timer.daemon = True
+        e._timer.start()
+
+    def disarm():
+        if e._timer is not None:
+            e._timer.cancel()
+            e._timer = None
+    e.checkpoint, e.arm, e.disarm = checkpoint, arm, disarm
     return e
 
 
@@ -367,8 +397,27 @@ def main():
                 e.torch.cuda.empty_cache()
             out["configs"] = cfgs
             out["configs_wall_s"] = time.perf_counter() - t_extra
-        elif extra and e.rank == 0:
-            out["configs"] = None      # N > 1: the headline only (configs[3] / [4] are single-GPU configurations)
+        elif extra:
+            if e.rank == 0:
+                out["configs"] = None      # N > 1: the headline only (configs[3] / [4] are single-GPU configurations)
+        if e.world > 1 and a.shard == "tiles" and not a.no_strong:
+            # SURVEY 8e axis 2 in the same line: ONE ocean, the K time-steps in contiguous blocks per rank (no collective at all)
+            import copy
+            aa = copy.copy(a)
+            aa.shard, aa.no_parity, aa.no_latency, aa.no_cpu_baseline = "steps", True, True, True
+            e.checkpoint(dict(out, strong={"error": "the sub-run did not finish"}) if e.rank == 0 else None)
+            e.arm(float(os.environ.get("MW_BENCH_PHASE_TIMEOUT", "240")), "strong (--shard steps sub-run)")
+            try:
+                st = ocean(aa, e, N, extra=True)
+                strong = {k: st[k] for k in ("value", "unit", "ms_per_step", "scaling", "repeats", "timed_ms_total", "region_ms_stats", "per_rank")}
+                strong["config"] = {k: st["config"][k] for k in ("workload", "steps_per_enqueue", "enqueues_per_region", "tiles", "parallelism")}
+                strong["vs_tiles_value"] = st["value"] / out["value"] if e.rank == 0 else None
+                strong["what"] = "the same K steps of ONE ocean (seed 1), rank r runs the contiguous block [lo, hi): whole-job rate = K * N^2 / the slowest rank's time"
+            except Exception as ex:      # noqa: BLE001 -- reported in the line
+                strong = {"error": repr(ex)}
+            e.disarm()
+            if e.rank == 0:
+                out["strong"] = strong
     if e.dist is not None:
         e.dist.destroy_process_group()
     emit(out if e.rank == 0 else None)
@@ -397,11 +446,16 @@ def ocean(a, e, N, extra=False):
     lo, hi = par.shard_steps(a.steps, world, rank) if shard_steps else (0, a.steps)
     k_local = hi - lo
     # MW_BENCH_FORCE_TILES=1 (test hook): the tile API path with a one-rank communicator on a 1-GPU box
-    use_tiles = ((world > 1 and not same_device) or os.environ.get("MW_BENCH_FORCE_TILES") == "1") and not shard_steps and not extra
+    use_tiles = (world > 1 or os.environ.get("MW_BENCH_FORCE_TILES") == "1") and not shard_steps and not extra
+    # test hook (gloo, every rank on cuda:0): an RCCL communicator cannot hold one device twice, so every process drives the SINGLE-process
+    # form of the tile API -- its own tile behind its own one-rank communicator; the control flow (tiles, gather, strong) is the real one
+    private_comm = use_tiles and same_device
     tiles = ocean = None
     tiles_note = None
     B, sizes = batch_plan(max(k_local, 1), max(1, min(a.batch, 32)))
-    if use_tiles:
+    if private_comm:
+        tiles = mw.Tiles(ntiles=1, devices=[local_rank], max_steps=B, seed=seed, **kw)
+    elif use_tiles:
         # the product's tile API: the LIBRARY owns the RCCL communicator; torch.distributed only carries its 128-byte id
         box = [None]
         if rank == 0:
@@ -542,7 +596,9 @@ def ocean(a, e, N, extra=False):
         sync()
         el = time.perf_counter() - t0
         barrier()
+        (local_gather if gather else local_regions).append(el)
         return par.max_over_ranks(el, dist, red_dev)      # the job took as long as its slowest rank
+    local_regions, local_gather = [], []
 
     def event_region():
         """The same K steps by HIP events on the launch stream (what the device spent; launch latency of the first enqueue and the
@@ -567,16 +623,10 @@ def ocean(a, e, N, extra=False):
         regions.append(wall_region())
     R = len(regions)
     el = float(np.median(regions))
+    del local_regions[0]            # the pilot
     R_ev = min(R, 64)
     ev_regions = [event_region() for _ in range(R_ev)] if not use_tiles else None
     el_events = float(np.median(ev_regions)) if ev_regions else None
-    el_gather = gather_regions = None
-    if a.gather and use_tiles:      # the same K steps again, now with the per-batch gather to rank 0 overlapped
-        run(warm_sizes, 0, gather=True)
-        sync()
-        gather_regions = [wall_region(gather=True) for _ in range(R)]
-        el_gather = float(np.median(gather_regions))
-
     # ---- kernel-level timing with HIP events on the launch stream (rank 0) ----------------------------
     prof = tiles_ocean = None
     if use_tiles:
@@ -724,12 +774,39 @@ def ocean(a, e, N, extra=False):
         "roofline": roofline,
         "parity": parity,
     }
+    # ---- the same K steps again with the per-batch gather to rank 0 overlapped (default at N > 1), under the watchdog ----
+    el_gather = gather_regions = None
+    do_gather = use_tiles and (a.gather or world > 1) and not a.no_gather
+    if do_gather:
+        e.checkpoint(dict(out, with_gather={"error": "the gather regions did not finish"}) if rank == 0 else None)
+        e.arm(float(os.environ.get("MW_BENCH_PHASE_TIMEOUT", "240")), "with_gather (mw_tiles_gather regions)")
+        run(warm_sizes, 0, gather=True)
+        sync()
+        gather_regions = [wall_region(gather=True) for _ in range(R)]
+        el_gather = float(np.median(gather_regions))
+        e.disarm()
+    # N > 1: what the communicator saw and what every rank did (the driver computes efficiency from `value`; these say WHY)
+    rank_el = par.all_ranks(float(np.median(local_regions)), dist, red_dev)
+    k_rank = par.all_ranks(float(k_local), dist, red_dev)
+    out["rccl_ranks"] = int(tiles.count) if use_tiles else 0          # mw_tiles_count(): ranks of the library's communicator (0: tile API not in use)
+    out["tile_api"] = {"in_use": bool(use_tiles), "communicator": ("one per process, 1 rank each (test hook: every rank on one device)" if private_comm
+                                                                    else ("ncclCommInitRank over the job's ranks" if use_tiles else None)),
+                       "note": tiles_note}
+    out["per_rank"] = {"median_region_ms": [round(x * 1e3, 5) for x in rank_el], "steps": [int(k) for k in k_rank],
+                       "grid_points_per_s": [k * NN / x for k, x in zip(k_rank, rank_el)],
+                       "slowest_over_fastest": max(rank_el) / min(rank_el)}
     if el_gather is not None:
+        g_el = par.all_ranks(float(np.median(local_gather)), dist, red_dev)
         out["with_gather"] = {"value": world * a.steps * NN / el_gather, "ms_per_step": el_gather / a.steps * 1e3,
-                              "gathers": gathers[0], "bytes_per_gather_per_tile": NN * 28,
+                              "relative_to_value": (world * a.steps * NN / el_gather) / value,
+                              "gathers": gathers[0], "gathers_per_region": len(sizes), "bytes_per_gather_per_tile": NN * 28,
+                              "root": 0, "rccl_ranks": int(tiles.count),
                               "region_ms": [round(x * 1e3, 5) for x in gather_regions[:8]],
+                              "per_rank_median_region_ms": [round(x * 1e3, 5) for x in g_el],
                               "what": "the same K steps with the library's RCCL gather of every batch's last step to rank 0 "
                                       "(mw_tiles_gather: ncclSend/ncclRecv on the side stream behind an event)"}
+    elif world > 1 and not shard_steps:
+        out["with_gather"] = {"skipped": "--no-gather" if a.no_gather else f"tile API not in use: {tiles_note}"}
     # free the device before the CPU legs (and before the next config of the default line)
     if tiles is not None:
         tiles.close()

@@ -41,3 +41,14 @@ def max_over_ranks(value: float, dist=None, device=None) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_ranks(value: float, dist=None, device=None) -> List[float]:
+    """`value` of every rank, in rank order, on every rank (one all-reduce of a one-hot vector: works on gloo and on RCCL alike)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    import torch
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=device)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]

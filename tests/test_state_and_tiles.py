@@ -709,6 +709,21 @@ def test_bench_two_rank_control_flow_on_one_device():
     assert abs(d["value"] - 2 * 64 * NN / (d["ms_per_step"] * 1e-3 * 64)) < 1e-6 * d["value"]
     assert d["parity"].startswith("ok") and d["cpu_baseline"] is None
     assert "amplitude 0.41" in d["config"]["workload"] and d["build_id"]
+    # the DEFAULT N > 1 line answers by itself: did RCCL see the ranks, what does the gather cost, what does one ocean sharded in time do
+    # (SURVEY 8d config 3 "with and without the final RCCL gather", 8e axis 2).  On this box every rank sits on cuda:0, so each process holds
+    # its own one-rank communicator (the line says so); with one rank per GPU the same fields carry ncclCommInitRank's world.
+    assert d["config"]["api"].startswith("mw_tiles_") and d["tile_api"]["in_use"] and "through mw_tiles_" in d["parity"]
+    assert isinstance(d["rccl_ranks"], int) and d["rccl_ranks"] == 1 and "1 rank each" in d["tile_api"]["communicator"]
+    pr = d["per_rank"]
+    assert len(pr["median_region_ms"]) == 2 and pr["steps"] == [64, 64] and len(pr["grid_points_per_s"]) == 2 and pr["slowest_over_fastest"] >= 1.0
+    assert max(pr["median_region_ms"]) <= d["ms_per_step"] * 64 * 1.5          # the job's region is the slowest rank's
+    g = d["with_gather"]
+    assert g["gathers"] > 0 and g["gathers_per_region"] == 2 and g["rccl_ranks"] == 1 and g["bytes_per_gather_per_tile"] == 28 * NN
+    assert g["value"] > 0 and 0.3 < g["relative_to_value"] < 1.3 and len(g["per_rank_median_region_ms"]) == 2
+    st = d["strong"]
+    assert "error" not in st, st
+    assert st["scaling"] == "strong" and st["config"]["parallelism"] == "steps2" and st["config"]["tiles"] == 1 and st["per_rank"]["steps"] == [32, 32]
+    assert abs(st["value"] - 64 * NN / (st["ms_per_step"] * 1e-3 * 64)) < 1e-6 * st["value"] and st["vs_tiles_value"] > 0
     # --shard steps: ONE ocean, the K steps split in contiguous blocks (SURVEY 8e axis 2): strong scaling, K steps in total
     s = _run_bench(["--steps", "64", "--warmup", "32", "--no-cpu-baseline", "--preheat-ms", "20", "--shard", "steps"],
                    {"MW_BENCH_BACKEND": "gloo", "MW_BENCH_SAME_DEVICE": "1"}, nproc=2)

@@ -2,9 +2,10 @@
 # tools/scale_preflight.sh -- run ON AN N-GPU BOX before trusting a scaling curve (no such box has been available to
 # the builder: nothing below has produced a number yet, and none is quoted anywhere).
 #   1. the real multi-device tests (tile gather over xGMI on 2 / 4 / 8 devices; skipped where fewer are visible)
-#   2. bench.py --gpus {2,4,8} in the three N > 1 forms -- one tile per rank (weak), the same with the library's RCCL gather of every
-#      batch's last step, one ocean with the time-steps sharded (strong) -- and checks on every line: n_gpus, the tile API really in use
-#      (library-owned RCCL communicator with world ranks), parity gate green on rank 0, per-GPU rate within 10 % of the N = 1 headline of
+#   2. the driver's command, bench.py --gpus {2,4,8}: its ONE line carries the three N > 1 forms -- one tile per rank (`value`, weak), the same
+#      with the library's RCCL gather of every batch's last step (`with_gather`), one ocean with the time-steps sharded (`strong`) -- and
+#      `rccl_ranks` / `per_rank`; checked here: n_gpus, the tile API really in use (library-owned RCCL communicator with world ranks),
+#      parity gate green on rank 0, per-GPU rate within 10 % of the N = 1 headline of
 #      the SAME box (the path has no data-path collective: anything else is a placement or clock problem worth knowing before the curve).
 # usage: bash tools/scale_preflight.sh [max_gpus] [steps]        -> gpurun_out/scale_preflight.txt (+ one JSON line per run beside it)
 cd "$(dirname "$0")/.."
@@ -18,12 +19,10 @@ timeout 600 python bench.py --workload ocean1024 --steps $K --warmup 64 --no-cpu
 port=29610
 for n in 2 4 8; do
   [ $n -le $MAXG ] && [ $n -le $NDEV ] || continue
-  for form in "tiles" "tiles --gather" "steps"; do
-    tag=n${n}_$(echo $form | tr -d ' -')
-    port=$((port + 1))
-    timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
-      bench.py --gpus $n --workload ocean1024 --steps $K --warmup 64 --no-cpu-baseline --no-latency --shard $form 2> $OUT/$tag.err | grep '^{' | tail -1 > $OUT/$tag.json
-  done
+  port=$((port + 1))
+  # the driver's own command: ONE line carries value (tiles), with_gather, strong, rccl_ranks and per-rank rates
+  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port \
+    bench.py --gpus $n --steps $K --warmup 64 --no-cpu-baseline --no-latency 2> $OUT/n$n.err | grep '^{' | tail -1 > $OUT/n${n}_default.json
 done
 python - "$OUT" <<'PY' | tee -a $OUT/summary.txt
 import glob, json, os, sys
@@ -36,25 +35,30 @@ def load(p):
 base = load(os.path.join(out, "n1.json"))
 print("N=1 headline of this box: %.4g pts/s" % base.get("value", float("nan")), base.get("parity"))
 ok = True
-for p in sorted(glob.glob(os.path.join(out, "n[248]_*.json"))):
+for p in sorted(glob.glob(os.path.join(out, "n[248]_default.json"))):
     d = load(p); tag = os.path.basename(p)[:-5]
     if "error" in d:
         print(tag, "NO RESULT LINE", d["error"]); ok = False; continue
-    n = int(tag[1]); strong = tag.endswith("steps")
+    n = int(tag[1])
     per_gpu = d["value"] / n
+    g, st = d.get("with_gather") or {}, d.get("strong") or {}
     checks = {
         "n_gpus": d["n_gpus"] == n,
-        "scaling": d["scaling"] == ("strong" if strong else "weak"),
+        "scaling": d["scaling"] == "weak",
         "parity": (d.get("parity") or "").startswith("ok"),
-        "tile_api": strong or d["config"]["api"].startswith("mw_tiles_"),
-        "tiles": d["config"]["tiles"] == (1 if strong else n),
+        "tile_api": d["config"]["api"].startswith("mw_tiles_"),
+        "rccl_ranks": d.get("rccl_ranks") == n,
+        "tiles": d["config"]["tiles"] == n,
         "per_gpu_within_10pct_of_n1": abs(per_gpu / base["value"] - 1.0) < 0.10 if "value" in base else False,
+        "ranks_even": d["per_rank"]["slowest_over_fastest"] < 1.10,
+        "gather_ran": g.get("gathers", 0) > 0 and g.get("rccl_ranks") == n,
+        "gather_within_5pct": g.get("value", 0) > 0.95 * d["value"],
+        "strong_ran": st.get("scaling") == "strong" and st.get("config", {}).get("parallelism") == f"steps{n}",
     }
-    if "gather" in tag:
-        checks["gather_ran"] = bool(d.get("with_gather")) and d["with_gather"]["gathers"] > 0
-        checks["gather_within_5pct"] = bool(d.get("with_gather")) and d["with_gather"]["value"] > 0.95 * d["value"]
     bad = [k for k, v in checks.items() if not v]
     ok = ok and not bad
-    print("%-16s %.4g pts/s  per GPU %.4g (%.3f of N=1)  eff %.3f  %s" % (tag, d["value"], per_gpu, per_gpu / base.get("value", 1), d["value"] / (n * base.get("value", 1)), "OK" if not bad else "FAILED: " + ", ".join(bad)))
+    print("%-12s %.4g pts/s  per GPU %.4g (%.3f of N=1)  eff %.3f  with gather %.3f  strong %.4g pts/s  %s" % (
+        tag, d["value"], per_gpu, per_gpu / base.get("value", 1), d["value"] / (n * base.get("value", 1)), g.get("relative_to_value", float("nan")),
+        st.get("value", float("nan")), "OK" if not bad else "FAILED: " + ", ".join(bad)))
 print("PREFLIGHT", "OK" if ok else "FAILED")
 PY
