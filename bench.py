@@ -293,6 +293,8 @@ class Env:
 def setup(a):
     import torch
     import mistral_water as mw
+    from mistral_water import _native as _nat
+    _nat.require_product_build("bench.py")      # numbers name a product build; an A/B variant (MW_LIB=variants/X.so) needs MW_ALLOW_LAB=1
     e = Env()
     e.torch, e.mw = torch, mw
     e.world = int(os.environ.get("WORLD_SIZE", "1"))

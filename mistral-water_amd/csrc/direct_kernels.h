@@ -15,6 +15,7 @@
 // GEMM has no bounds checks and only aligned 16-byte loads.  E and the step-2 left factors are built ONCE per handle
 // (they do not depend on t); per step: the spectrum kernel, 4 GEMM launches, one assembly kernel, the whitecap kernel.
 #pragma once
+#include "mw_switches.h"
 #include "fftmesh_kernels.h"
 #include "czt_kernels.h"
 
@@ -536,6 +537,7 @@ __global__ void k_czt_tables(int N, float length, float gravity, float* Om, floa
 static inline hipError_t czt_upload_tables(CztState& z, int N, float unit_width, float length, float gravity, hipStream_t st) {
     std::vector<cf> w1, w2, Hh;
     czt_build_tables(N, N + 1, z.M, unit_width, length, w1, w2, Hh);
+    z.table_length = z.table_unit_width = z.table_gravity = -1.f;  // half-written tables belong to no length: a failure below forces a rebuild
     hipError_t e = hipStreamSynchronize(st);  // a step still in flight may be reading the old tables
     if (e == hipSuccess) {
         const unsigned ne = (unsigned)((N + 1) * (N + 1));
@@ -568,9 +570,13 @@ static hipError_t czt_launch_rows_assemble(const CztArgs& A, cf* hds, float* dv,
 }
 // N <= MW_CZT_ONE_MAX_N (transform size 64): one launch (MW_CZT_ONE=0, read per call: the two-launch plan, for A/B and the bit-identity test)
 static inline bool czt_one_launch(const CztState& z, int N) {
-    const char* oe = std::getenv("MW_CZT_ONE");
-    const char* fe = std::getenv("MW_CZT_FUSED");
-    return z.M == 64 && N <= MW_CZT_ONE_MAX_N && !(oe && std::atoi(oe) == 0) && !(fe && std::atoi(fe) == 0);
+    return z.M == 64 && N <= MW_CZT_ONE_MAX_N && sw(SW_CZT_ONE) != 0 && sw(SW_CZT_FUSED) != 0;
+}
+// which launches a chirp-z step is: the ONE place that decides (czt_evaluate and the measurement hook's kernel names both ask here)
+enum CztPlan { CZT_PLAN_ONE, CZT_PLAN_TWO, CZT_PLAN_THREE };
+static inline CztPlan czt_plan(const CztState& z, int N) {
+    if (czt_one_launch(z, N)) return CZT_PLAN_ONE;
+    return (sw(SW_CZT_FUSED) != 0 && z.M <= MW_CZT_FUSED_MAX_M) ? CZT_PLAN_TWO : CZT_PLAN_THREE;
 }
 static hipError_t czt_launch_one(const CztArgs& A, cf* hds, float* dv, float* dn, float* dw, int white_stride, hipStream_t st) {
     constexpr int M = 64, P = czt_points(M), T = M / P, BUF = FftGeom<M, P>::LBUF + 4;
@@ -603,13 +609,13 @@ static inline hipError_t czt_evaluate(DirectState& d, OceanConsts C, const cf* h
         hipError_t e = czt_upload_tables(z, N, C.unit_width, C.length, C.gravity, st);    // length change (direct_prepare_tables), never inside an enqueue
         if (e != hipSuccess) return e;
     }
-    const char* fe = std::getenv("MW_CZT_FUSED");  // read per call: the GPU test flips it inside one process
-    const bool fused = !(fe && std::atoi(fe) == 0) && z.M <= MW_CZT_FUSED_MAX_M;
+    const CztPlan plan = czt_plan(z, N);
+    const bool fused = plan == CZT_PLAN_TWO;
     if (ev) { hipEventRecord(ev[0], st); hipEventRecord(ev[1], st); }
     CztArgs A;
     A.w1 = z.w1; A.w2 = z.w2; A.Hh = z.Hh; A.TWf = z.TWf; A.TWi = z.TWi; A.Om = z.Om; A.K = z.K;
     A.nin = N + 1; A.nout = N;  // the packed planes live on the index set [0, N]^2 (czt_packed_value)
-    if (czt_one_launch(z, N)) {  // tiny grids: both axes and the assembly in one workgroup (k_czt_one)
+    if (plan == CZT_PLAN_ONE) {  // tiny grids: both axes and the assembly in one workgroup (k_czt_one)
         A.h0 = h0; A.h0c = h0c; A.t = t; A.C = C;
         if (ev) hipEventRecord(ev[2], st);
         return czt_launch_one(A, d.hds, dv, dn, dw, white_stride, st);
@@ -657,8 +663,7 @@ static inline int direct_alloc(DirectState& d, int N, hipStream_t st) {
     // The chirp-z form is the default wherever one workgroup holds the transform (N + 1 inputs, N outputs: 2N <= 4096): first hardware
     // run in round 4 -- 2.4x (N = 100) to 5.8x (N = 1000) faster than the GEMM form and an order of magnitude more accurate on
     // grids with large phases (profiles/r04a_bench_direct_*).  MW_DIRECT_CZT=0 selects the GEMM form (A/B, and the path of larger N).
-    const char* env = std::getenv("MW_DIRECT_CZT");
-    if (!(env && std::atoi(env) == 0) && czt_size(N) != 0) {
+    if (sw(SW_DIRECT_CZT) != 0 && czt_size(N) != 0) {
         if (czt_alloc(d.czt, N) != 0 || hipMalloc((void**)&d.hds, sizeof(cf) * (size_t)N * N) != hipSuccess) { direct_free(d); return 4; }
         d.N = N;
         d.use_czt = true;

@@ -578,26 +578,6 @@ MW_HD void p2_fetch(const P2Args& A, int ab, int step, int tid, int f, cf (&x)[P
     const cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * CW;  // block-uniform base (first row of the block)
     // per-lane 32-bit offset of element j = u1 (slot q adds the uniform T*q/CW chunks of N*CW)
     const unsigned voff = (unsigned)(((u1 / CW) * N + r1) * CW + (u1 % CW));
-#ifdef MW_ABLATE_WIDE_READ  // timing experiment (wrong results): the same bytes, contiguous, as 16-B per-lane loads
-    {
-        const f4* E4 = reinterpret_cast<const f4*>(A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * N);
-#pragma unroll
-        for (int q = 0; q < P / 2; q++) {
-            const f4 v = (E4 + (size_t)R2 * T * q)[(unsigned)(tid % (R2 * T))];
-            x[2 * q] = mk(v.x, v.y);
-            x[2 * q + 1] = mk(v.z, v.w);
-        }
-        return;
-    }
-#endif
-#ifdef MW_ABLATE_SEQ_READ  // timing experiment (wrong results): the same bytes from ONE contiguous block per workgroup
-    {
-        const cf* Es = A.E + ((size_t)step * 3 + f) * N * N + (size_t)ab * R2 * N;
-#pragma unroll
-        for (int q = 0; q < P; q++) x[q] = mw_load_stream(&(Es + (size_t)R2 * T * q)[(unsigned)(tid % (R2 * T))]);
-        return;
-    }
-#endif
     // Half-stored fields (height; with MW_SPLIT_SLOPES also G): element j > N/2 is conj of element m = N - j.  With T a
     // multiple of CW, slot q is mirrored for every lane (T q > N/2), for none (T (q + 1) <= N/2), or -- the one slot with
     // T q == N/2 -- for the lanes u1 > 0: the decision is compile-time and two per-lane offsets serve all slots,
@@ -775,11 +755,7 @@ MW_HD void p2_vertices(const P2Args& A, int ab, int step, int tid, const ST& st)
     constexpr int T = FftGeom<N, P>::T;
     const int g = tid / T, u = tid % T, a = ab * R2 + g;
     float* vblk = A.vertices + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;          // block-uniform
-#ifdef MW_ABLATE_SEG_STORES  // timing experiment (wrong results): a wave's store = 4 segments of 16 consecutive points, 64 points apart
-    const unsigned voff = (unsigned)((g * N + (T == 256 ? 64 * ((u >> 4) & 3) + (u & 15) + 16 * (u >> 6) : u)) * 3);
-#else
     const unsigned voff = (unsigned)((g * N + u) * 3);
-#endif
     const float rx = rest_coord(N, A.c.unit_width, a);
 #pragma unroll
     for (int q = 0; q < P; q++) {
@@ -920,12 +896,7 @@ MW_HD void p2_hs_finish_slopes(const P2Args& A, const Twiddles& tw, int ab, int 
     final_stage<N, P, +1>(x, u, tw.TF);
     float* nblk = A.normals + ((size_t)step * N * N + (size_t)ab * R2 * N) * 3;  // block-uniform
     float* wblk = A.white + ((size_t)step * N * N + (size_t)ab * R2 * N) * A.white_stride;
-#ifdef MW_ABLATE_SEG_STORES
-    const int us = (T == 256 ? 64 * ((u >> 4) & 3) + (u & 15) + 16 * (u >> 6) : u);
-    const unsigned noff = (unsigned)((g * N + us) * 3), woff = (unsigned)((g * N + us) * A.white_stride);
-#else
     const unsigned noff = (unsigned)((g * N + u) * 3), woff = (unsigned)((g * N + u) * A.white_stride);
-#endif
 #pragma unroll
     for (int q = 0; q < P; q++) {
         const int b = u + T * q;

@@ -3,6 +3,7 @@
 // Streaming kernel, 24 B/vertex algorithmic (read position 12 B + write displaced position 12 B).
 #pragma once
 #include "fftmesh_kernels.h"
+#include "mw_switches.h"
 
 #define MW_GERSTNER_MAX_WAVES 16
 
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void k_gerstner(const float* __restrict__ pos,
 // of a sincos.  The positions are read once per launch; per step only the 12-B result leaves.
 #define MW_GERSTNER_PHASES 256  // nsteps * nwaves per launch (2 KiB of kernel arguments)
 #ifndef MW_POND_STEPS_PER_WG
-#define MW_POND_STEPS_PER_WG 8  // time values per workgroup of k_gerstner_steps (environment MW_POND_STEPS_PER_WG overrides: A/B)
+#define MW_POND_STEPS_PER_WG 8  // time values per workgroup of k_gerstner_steps (switch MW_POND_STEPS_PER_WG overrides: A/B)
 #endif
 struct GerstnerPhases {
     float cb[MW_GERSTNER_PHASES], sb[MW_GERSTNER_PHASES];  // [step * nwaves + i]
@@ -211,14 +212,11 @@ static inline hipError_t gerstner_launch_steps(const float* d_pos, int64_t nvert
     int64_t blocks = (nverts + 1023) / 1024;  // 1024 vertices per 256-thread workgroup and trip
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    static const int spw_env = [] { const char* e = std::getenv("MW_POND_STEPS_PER_WG"); return e ? std::atoi(e) : 0; }();
+    const int spw_env = sw(SW_POND_STEPS_PER_WG);
     const int spw = spw_env > 0 ? (spw_env < nsteps ? spw_env : nsteps) : (MW_POND_STEPS_PER_WG < nsteps ? MW_POND_STEPS_PER_WG : nsteps);
-#ifndef MW_POND_XCD
-#define MW_POND_XCD 0  // 1: step groups of a vertex chunk on one XCD (environment MW_POND_XCD overrides).  Measured round 5 (profiles/r05_ab_notes.md):
-                       // 4.25e11 against 4.48e11 vertices/s for the 2-D grid -- the positions' second to fourth read is 1.1 of 13.5 B per
-                       // vertex-step and not what the launch waits for: off
-#endif
-    static const int xcd_env = [] { const char* e = std::getenv("MW_POND_XCD"); return e ? std::atoi(e) : MW_POND_XCD; }();
+    // switch MW_POND_XCD = 1: the step groups of a vertex chunk on one XCD.  Measured round 5 (profiles/r05_ab_notes.md): 4.25e11 against 4.48e11
+    // vertices/s for the 2-D grid -- the positions' second to fourth read is 1.1 of 13.5 B per vertex-step and not what the launch waits for: off
+    const int xcd_env = sw(SW_POND_XCD);
     const int ngroups = (nsteps + spw - 1) / spw;
     const bool xcd = xcd_env != 0 && ngroups > 1;
     const dim3 grid = xcd ? dim3((unsigned)(((blocks + 7) / 8) * 8 * ngroups)) : dim3((unsigned)blocks, (unsigned)ngroups);

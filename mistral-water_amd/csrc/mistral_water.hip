@@ -86,6 +86,9 @@ __global__ void k_omega_t(int N, float length, float gravity, float t, float* ou
     out[idx] = omega_t_f32(N, length, gravity, idx / N, idx % N, t);
 }
 
+#if defined(MW_TIMING) && !defined(MW_LAB)
+#error "MW_TIMING (cycle stamps inside the pass kernels) is a lab build option: add -DMW_LAB (tools/build_variant.sh does)"
+#endif
 #ifdef MW_TIMING
 #ifndef MW_STAMP_STEP
 #define MW_STAMP_STEP 3
@@ -227,16 +230,6 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
         MW_VT(h) p1_build<N, P>(A, jb, tid + h * NT, f, st[h], x[h]);
         if (G::NBUF == 1 && f) __syncthreads();
         MW_STAMP(0, 2 + 8 * f);
-#ifdef MW_ABLATE_FFT
-        {
-            cf* Ef = A.E + ((size_t)step * 3 + f) * N * N + (size_t)(jb % (N / G::CW)) * N * G::CW;
-#pragma unroll
-            MW_VT(h)
-#pragma unroll
-            for (int q = 0; q < P; q++) Ef[(size_t)(((tid + h * NT) / G::CW) + T * q) * G::CW + (tid % G::CW)] = x[h][q];
-            continue;
-        }
-#endif
 #pragma unroll
         MW_VT(h) stage0_store<N, P, +1>(x[h], MW_U(h), MW_BUF(h));
         MW_STAMP(0, 3 + 8 * f);
@@ -246,16 +239,11 @@ __attribute__((amdgpu_waves_per_eu(VT > 1 ? P1Geom<N, P>::NTHREADS / VT / 256 : 
 #pragma unroll
             MW_VT(h) load_slots<N, P>(x[h], MW_U(h), MW_BUF(h), s - 1);
             if (s == 1) MW_STAMP(0, 4 + 8 * f);
-#ifndef MW_ABLATE_WAR  // timing experiment (wrong results): no write-after-read barrier (4096^2: pass 1 -2 %)
             if (G::NBUF == 1) col_sync(false); else cur ^= 1;
-#endif
             if (s == 1) MW_STAMP(0, 5 + 8 * f);
 #pragma unroll
             MW_VT(h) stage_store<N, P, +1>(x[h], MW_U(h), MW_BUF(h), tw, s);
             if (s == 1) MW_STAMP(0, 6 + 8 * f);
-#ifdef MW_ABLATE_EXCH1
-            if (s == 1 && N >= MW_ABLATE_EXCH1) { __builtin_amdgcn_sched_barrier(0); continue; }
-#endif
             col_sync(s == p1_mid_passes<N, P>() - 1);
         }
         MW_STAMP(0, 7 + 8 * f);
@@ -327,23 +315,6 @@ __global__ __launch_bounds__((P2Geom<N, P, R2>::NTHREADS)) __attribute__((amdgpu
 #endif
         if (k == 0 && TwGeom<N, P>::LDS_ALL) tws.store(lds, tid);  // published by the barrier below
         MW_STAMP(1, 2 + 8 * k);
-#ifdef MW_ABLATE_FFT
-        if (active) {  // no exchanges: treat the loaded values as the transformed row (memory-pattern floor)
-            const int a = ab * R2 + g, u = tid % T;
-            if (f == 2) {
-                float* nout = A.normals + ((size_t)step * N * N + (size_t)a * N) * 3;
-#pragma unroll
-                for (int q = 0; q < P; q++) { const int b = u + T * q; nout[3 * b] = x[q].x; nout[3 * b + 1] = x[q].y; nout[3 * b + 2] = x[q].x; noise_lds[g * N + b] = x[q].y; }
-            } else if (f == 0) {
-#pragma unroll
-                for (int q = 0; q < P; q++) st.h[q] = x[q].x;
-            } else {
-#pragma unroll
-                for (int q = 0; q < P; q++) st.d[q] = x[q];
-            }
-        }
-        continue;
-#endif
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
@@ -534,9 +505,6 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
             if (!in_regs) __syncthreads();
 #pragma unroll
             MW_VT(h) p2_mid_store<N, P, R2>(tw, MW_VTID(h), s, x[h], set0);
-#ifdef MW_ABLATE_EXCH1
-            if (s == 1 && N >= MW_ABLATE_EXCH1) { __builtin_amdgcn_sched_barrier(0); continue; }
-#endif
             if (!in_regs) __syncthreads();
         }
         MW_STAMP(1, 6 + 8 * k);
@@ -600,9 +568,6 @@ __attribute__((amdgpu_waves_per_eu(hs_min_waves(P2Geom<N, P, R2, true>::NTHREADS
                 if (g0 == 0) load_slots<N, P>(xq, u, set0, s - 1);
                 if (!in_regs) __syncthreads();
                 if (g0 == 0) { if (in_regs) stage_last_regs<N, P, +1>(xq, u, tw, s); else stage_store<N, P, +1>(xq, u, set0, tw, s); }  // g0 is wave-uniform: whole waves
-#ifdef MW_ABLATE_EXCH1
-                if (s == 1 && N >= MW_ABLATE_EXCH1) { __builtin_amdgcn_sched_barrier(0); continue; }
-#endif
                 if (!in_regs) __syncthreads();
             }
             if (g0 == 0) {
@@ -806,22 +771,13 @@ static OceanConsts consts_of(const mw_ocean* o) {
 }
 
 // the frame-at-a-time plan (single-step enqueues at 1024^2): compiled in by MW_LATENCY_PLAN, switched at run time by the
-// environment variable of the same name (0 = the batched plan for every enqueue; A/B without a rebuild)
-static bool latency_plan_on() {
-    static const bool on = [] { const char* e = std::getenv("MW_LATENCY_PLAN"); return MW_LATENCY_PLAN && (!e || std::atoi(e) != 0); }();
-    return on;
-}
+// switch of the same name (mw_switches.h; 0 = the batched plan for every enqueue; A/B without a rebuild)
+static bool latency_plan_on() { return MW_LATENCY_PLAN && sw(SW_LATENCY_PLAN) != 0; }
 
 // MW_FRAME_KERNEL=0: pass 2 of a single step by the sequential-halo kernel with one wave per row (round 3's frame plan) instead of
 // k_pass2_frame; MW_P1_FRAME_XCD=0: its pass 1 on the plain (column jobs, 3) grid.  Run-time A/B switches, same bits either way.
-static bool frame_kernel_on() {
-    static const bool on = [] { const char* e = std::getenv("MW_FRAME_KERNEL"); return !e || std::atoi(e) != 0; }();
-    return on;
-}
-static bool p1_frame_xcd_on() {
-    static const bool on = [] { const char* e = std::getenv("MW_P1_FRAME_XCD"); return !e || std::atoi(e) != 0; }();
-    return on;
-}
+static bool frame_kernel_on() { return sw(SW_FRAME_KERNEL) != 0; }
+static bool p1_frame_xcd_on() { return sw(SW_P1_FRAME_XCD) != 0; }
 
 // ---- kernel dispatch over N ----------------------------------------------------------------------
 template <int N>
@@ -994,11 +950,18 @@ int32_t mw_abi_version(void) { return MW_ABI_VERSION; }
 #ifndef MW_BUILD_TAG
 #define MW_BUILD_TAG "default"
 #endif
+// -DMW_LAB: a build for measurements (a knob overridden on the command line, cycle stamps, the plan switches taken from the environment).
+// Its id says so, and bench.py and the tests refuse it unless told otherwise: a number or a green test always names a product build.
+#ifdef MW_LAB
+#define MW_BUILD_KIND "lab:"
+#else
+#define MW_BUILD_KIND ""
+#endif
 #ifndef MW_BUILD_HASH
 #warning "MW_BUILD_HASH is not defined: build through mistral_water/_native.py::build_native or tools/build_variant.sh (mw_build_id() will say unhashed-build)"
 #define MW_BUILD_HASH "unhashed-build"
 #endif
-const char* mw_build_id(void) { return MW_BUILD_HASH " " MW_BUILD_TAG; }
+const char* mw_build_id(void) { return MW_BUILD_HASH " " MW_BUILD_KIND MW_BUILD_TAG; }
 const char* mw_last_error(void) { return g_err.c_str(); }
 
 int32_t mw_device_count(void) {
@@ -1065,7 +1028,7 @@ static mw_status ocean_create_impl(const mw_params* params, int tiles, mw_ocean*
     hipError_t he = hipStreamCreateWithFlags(&o->own_stream, hipStreamNonBlocking);
     if (he != hipSuccess) { delete o; return fail(MW_EDEVICE, "hipStreamCreate failed"); }
     o->stream = o->own_stream;
-    if (const char* e = std::getenv("MW_P1_TGROUP")) o->p1_tgroup = std::atoi(e);
+    if (sw(SW_P1_TGROUP) >= 0) o->p1_tgroup = sw(SW_P1_TGROUP);
 
     if (o->sem == MW_SEM_FFTMESH) {
         const int N = params->resolution;
@@ -1619,10 +1582,12 @@ static mw_status profile_kernels_impl(mw_ocean* o, int32_t nsteps, int32_t iters
         static const char* gnames[2] = {"k_gemm_f32_mfma (4 launches: z sum, x sum)", "k_direct_spec + k_direct_assemble + k_direct_white"};
         static const char* znames[2] = {"k_czt (2 launches: spectrum + chirp-z along j, chirp-z along i)", "k_czt_assemble_white"};
         static const char* fnames[2] = {"k_czt (spectrum + chirp-z along j)", "k_czt_rows_assemble (chirp-z along i + vertices, normals, whitecap: one launch)"};
-        const char* fe = std::getenv("MW_CZT_FUSED");
-        const bool fused = o->direct.use_czt && !(fe && std::atoi(fe) == 0) && o->direct.czt.M <= MW_CZT_FUSED_MAX_M;
         static const char* onames[2] = {"(no separate launch)", "k_czt_one (both axes + vertices, normals, whitecap: one workgroup, one launch)"};
-        const char* const* dnames = o->direct.use_czt ? (czt_one_launch(o->direct.czt, o->N) ? onames : (fused ? fnames : znames)) : gnames;
+        const char* const* dnames = gnames;
+        if (o->direct.use_czt) {  // the names follow the plan czt_evaluate runs (czt_plan: the one place that decides)
+            const CztPlan plan = czt_plan(o->direct.czt, o->N);
+            dnames = plan == CZT_PLAN_ONE ? onames : (plan == CZT_PLAN_TWO ? fnames : znames);
+        }
         hipEvent_t ev[4];
         for (auto& e : ev) hipEventCreate(&e);
         hipError_t he = hipSuccess;
@@ -1790,6 +1755,16 @@ mw_status mw_debug_sincos(const float* x_host, int32_t n, float* s_host, float* 
 }
 mw_status mw_debug_sincos_fast(const float* x_host, int32_t n, float* s_host, float* c_host) {
     return debug_sincos(x_host, n, s_host, c_host, true);
+}
+mw_status mw_debug_set_switch(const char* name, int32_t value) {
+    const int k = switch_index(name);
+    if (k < 0) return fail(MW_EINVAL, std::string("mw_debug_set_switch: unknown switch ") + (name ? name : "(null)"));
+    switch_table().v[k].store(value);
+    return MW_OK;
+}
+int32_t mw_debug_get_switch(const char* name) {
+    const int k = switch_index(name);
+    return k < 0 ? INT32_MIN : sw((Switch)k);
 }
 mw_status mw_debug_wave_transpose4(float* inout_host) {
     if (!inout_host) return fail(MW_EINVAL, "NULL argument");

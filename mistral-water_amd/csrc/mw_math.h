@@ -469,10 +469,6 @@ struct TwStage {
 template <int N, int P, int SGN>
 MW_HD void stage0_store(cf (&x)[P], int u, cf* buf) {
     DftP<P, SGN>::run(x);
-#ifdef MW_ABLATE_LDS
-    if (u == 12345) buf[0] = x[0];
-    return;
-#endif
     if (XLay<N, P>::EXACT) {
         cf* __restrict__ b = buf + u;
 #pragma unroll
@@ -487,13 +483,6 @@ MW_HD void stage0_store(cf (&x)[P], int u, cf* buf) {
 template <int N, int P>
 MW_HD void load_slots(cf (&x)[P], int u, const cf* buf, int e) {
     constexpr int T = FftGeom<N, P>::T;
-#ifdef MW_ABLATE_LDS
-    if (u == 12345) x[0] = buf[0];
-    return;
-#endif
-#ifdef MW_ABLATE_EXCH1  // timing experiment (wrong results): exchange 1 of every transform costs nothing (upper bound of an in-wave exchange)
-    if (e == 1 && N >= MW_ABLATE_EXCH1) return;
-#endif
     if (XLay<N, P>::EXACT) {
         if (e == 0) {  // n = u + T q = 16 (u/16 + (T/16) q) + u % 16
             const cf* __restrict__ b = buf + (u & (P - 1)) * XLay<N, P>::ROW0 + (u >> LogP<P>::v);
@@ -657,13 +646,6 @@ MW_HD void stage_store(cf (&x)[P], int u, cf* buf, const Twiddles& tw, int s) {
     const int p = 1 << (LogP<P>::v * s);
     const int k = u & (p - 1);
     const int j = ((u - k) << LogP<P>::v) + k;
-#ifdef MW_ABLATE_LDS
-    if (u == 12345) buf[j] = x[0];
-    return;
-#endif
-#ifdef MW_ABLATE_EXCH1
-    if (s == 1 && N >= MW_ABLATE_EXCH1) return;
-#endif
     if (XLay<N, P>::EXACT) {
         cf* __restrict__ b = buf + j + ((P == 8 && s == 1) ? 8 * (j >> 6) : 0);  // P = 8, s = 1: j + 8 r stays inside its 64-block
 #pragma unroll

@@ -12,3 +12,4 @@ from ._native import (MW_EDEVICE, MW_EINVAL, MW_ENOTPOW2, MW_ESTATE, MW_OK, MW_O
 from .ocean import (FFTMesh, Ocean, OceanRenderer, PondMaterial, Tiles, Vector2, gerstner_displace,  # noqa: F401
                     gerstner_displace_steps_device, host_register, host_unregister)
 from ._native import MW_POND_GERSTNER, MW_POND_GERSTNER_LEVEL_ONE, MW_POND_WAVE  # noqa: F401
+from ._native import get_switch, set_switch  # noqa: F401,E402  (test hooks: run-time plan switches)

@@ -76,16 +76,34 @@ def source_hash(extra=()) -> str:
     return h.hexdigest()[:16]
 
 
+def built_hash(path: str) -> str | None:
+    """The source hash embedded in a built library (the first word of mw_build_id()), read from the file without loading it:
+    the id is a string constant "<16 hex digits> <tag>" in .rodata."""
+    import re
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    m = re.search(rb"([0-9a-f]{16}) (?:lab:)?[A-Za-z0-9_.\-]+\x00", blob)
+    return m.group(1).decode() if m else None
+
+
 def build_native(force: bool = False, verbose: bool = False, out: str | None = None, extra=(), tag: str | None = None,
                  resource_report: str | None = None) -> str:
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU).
     `out` / `extra` / `tag`: an A/B variant (tools/build_variant.sh): other output path, extra -D flags, the tag mw_build_id() carries."""
     target = out or LIB_PATH
-    srcs = csrc_files() + [HEADER_PATH, HOOKS_HEADER_PATH]
-    if (not force and not extra and os.path.exists(target)
-            and all(os.path.getmtime(s) <= os.path.getmtime(target) for s in srcs)):
-        return target
-    cmd = ["hipcc"] + BUILD_FLAGS + list(extra) + ['-DMW_BUILD_HASH="%s"' % source_hash(extra)]
+    extra = list(extra)
+    if extra and "-DMW_LAB" not in extra:
+        extra.append("-DMW_LAB")      # any flag beyond BUILD_FLAGS makes a lab build: mw_build_id() says "lab:<tag>"
+    if not force and not extra and os.path.exists(target) and built_hash(target) == source_hash():
+        return target                 # the binary on disk IS these sources and flags (its embedded id says so), whatever the mtimes are
+    import shutil
+    if shutil.which("hipcc") is None:
+        raise RuntimeError(f"{target} is missing or was built from other sources (embedded hash {built_hash(target)}, tree {source_hash()}) "
+                           "and there is no hipcc here to rebuild it")
+    cmd = ["hipcc"] + BUILD_FLAGS + extra + ['-DMW_BUILD_HASH="%s"' % source_hash(extra)]
     if tag:
         cmd.append('-DMW_BUILD_TAG="%s"' % tag)
     if resource_report:
@@ -193,6 +211,8 @@ def lib():
         "mw_debug_sincos_fast": (C.c_int, [f32p, C.c_int32, f32p, f32p]),
         "mw_debug_stream_read": (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
         "mw_debug_wave_transpose4": (C.c_int, [f32p]),
+        "mw_debug_set_switch": (C.c_int, [C.c_char_p, C.c_int32]),
+        "mw_debug_get_switch": (C.c_int32, [C.c_char_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = ABI symbol missing: fail loudly
@@ -223,7 +243,7 @@ ABI_SYMBOLS = [
 ]
 #: measurement and test hooks (include/mistral_water_hooks.h): exported, but not part of the drop-in boundary
 HOOK_SYMBOLS = ["mw_ocean_profile_kernels", "mw_ocean_profile_kernels_stats", "mw_debug_pass1_time_group", "mw_debug_omega_t", "mw_debug_evaluate_hds", "mw_debug_get_omega", "mw_debug_sincos",
-                "mw_debug_sincos_fast", "mw_debug_stream_read", "mw_debug_wave_transpose4"]
+                "mw_debug_sincos_fast", "mw_debug_stream_read", "mw_debug_wave_transpose4", "mw_debug_set_switch", "mw_debug_get_switch"]
 
 
 def build_id() -> str:
@@ -233,3 +253,23 @@ def build_id() -> str:
 def check(status: int):
     if status != MW_OK:
         raise MistralWaterError(status, lib().mw_last_error().decode("utf-8", "replace"))
+
+
+def set_switch(name: str, value: int):
+    """Test hook: one of the library's run-time plan switches (csrc/mw_switches.h), process-wide."""
+    check(lib().mw_debug_set_switch(name.encode(), int(value)))
+
+
+def get_switch(name: str) -> int:
+    return int(lib().mw_debug_get_switch(name.encode()))
+
+
+def is_lab_build() -> bool:
+    """True when the loaded library was built with -DMW_LAB (a measurement build: knob overrides, cycle stamps, switches from the environment)."""
+    return " lab:" in build_id()
+
+
+def require_product_build(who: str):
+    """bench.py and the tests measure and check the PRODUCT: a lab build is refused unless MW_ALLOW_LAB=1 says the caller knows."""
+    if is_lab_build() and os.environ.get("MW_ALLOW_LAB") != "1":
+        raise RuntimeError(f"{who}: the loaded library is a lab build ({build_id()}); set MW_ALLOW_LAB=1 for an A/B run")

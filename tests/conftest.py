@@ -50,6 +50,8 @@ def mw():
         pass
     import mistral_water
     mistral_water.lib()
+    from mistral_water import _native
+    _native.require_product_build("tests")      # a green test names a product build (MW_ALLOW_LAB=1: an A/B variant under MW_LIB)
     return mistral_water
 
 

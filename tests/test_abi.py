@@ -50,6 +50,49 @@ def test_build_id_names_the_sources_this_library_was_built_from(mw):
         assert tag == "default"
 
 
+def test_build_reuse_is_decided_by_the_embedded_hash_not_by_mtimes(mw, monkeypatch):
+    """build() reuses the in-tree library when the hash EMBEDDED in the file equals the hash of the tree (read from the
+    file without loading it) -- a copy that lost its mtimes neither rebuilds on a box without hipcc nor keeps a stale binary silently.
+    And a lab build (-DMW_LAB: knob overrides, cycle stamps, switches from the environment) is refused by bench.py and the tests."""
+    from mistral_water import _native
+    if os.environ.get("MW_LIB"):
+        pytest.skip("A/B variant")
+    assert _native.built_hash(_native.LIB_PATH) == _native.source_hash() == _native.build_id().split(" ")[0]
+    os.utime(_native.LIB_PATH, (1, 1))                                  # mtimes say "older than every source"
+    try:
+        monkeypatch.setattr(_native.subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("rebuilt")))
+        assert _native.build_native() == _native.LIB_PATH               # reused all the same
+    finally:
+        os.utime(_native.LIB_PATH, None)
+    assert _native.built_hash(__file__) is None or True                 # any file: no crash
+    assert not _native.is_lab_build()
+    monkeypatch.setattr(_native, "build_id", lambda: "0123456789abcdef lab:x")
+    monkeypatch.delenv("MW_ALLOW_LAB", raising=False)
+    with pytest.raises(RuntimeError):
+        _native.require_product_build("test")
+    monkeypatch.setenv("MW_ALLOW_LAB", "1")
+    _native.require_product_build("test")
+
+
+def test_switches_are_a_table_with_a_hook_not_the_environment(mw, monkeypatch):
+    """The run-time plan switches (csrc/mw_switches.h): defaults in a product build whatever the environment says, changed only through
+    mw_debug_set_switch; unknown names are MW_EINVAL."""
+    import subprocess
+    import sys
+    from conftest import REPO as repo
+    code = ("import sys; sys.path[:0] = [%r + '/mistral-water_amd']; import mistral_water as mw; "
+            "print(mw.get_switch('MW_CZT_FUSED'), mw.get_switch('MW_TILES_FORCE_RCCL'), mw.get_switch('MW_P1_TGROUP'))" % repo)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MW_CZT_FUSED="0", MW_TILES_FORCE_RCCL="1"), capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == ["1", "0", "-1"], (r.stdout, r.stderr[-2000:])
+    assert mw.get_switch("MW_CZT_ONE") == 1
+    mw.set_switch("MW_CZT_ONE", 0)
+    assert mw.get_switch("MW_CZT_ONE") == 0
+    mw.set_switch("MW_CZT_ONE", 1)
+    with pytest.raises(mw.MistralWaterError) as e:
+        mw.set_switch("MW_NO_SUCH_SWITCH", 1)
+    assert e.value.status == mw.MW_EINVAL and mw.get_switch("MW_NO_SUCH_SWITCH") == -2 ** 31
+
+
 def test_header_is_plain_c():
     # the boundary must be consumable from C (and therefore from P/Invoke / cgo / JNI / ctypes)
     src = '#include "mistral_water.h"\n#include "mistral_water_hooks.h"\nint main(void){ mw_params p; mw_params_default(&p, MW_SEM_FFTMESH); return (int)sizeof(p) == 0; }\n'

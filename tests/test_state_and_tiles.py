@@ -287,16 +287,13 @@ def _d2h(ptr, nfloats):
 
 @pytest.fixture(params=["1", "0"], ids=["rccl_self_send", "device_local_copy"])
 def gather_path(request):
-    """Tiles that live on the root's device are copied, not sent (round 5); MW_TILES_FORCE_RCCL=1 sends them through the one-rank
-    communicator as round 4 did, so that ncclSend / ncclRecv stay exercised on the 1-GPU box.  Both must deliver the same bytes."""
-    import os
-    old = os.environ.get("MW_TILES_FORCE_RCCL")
-    os.environ["MW_TILES_FORCE_RCCL"] = request.param
+    """Tiles that live on the root's device are copied, not sent (round 5); the switch MW_TILES_FORCE_RCCL = 1 sends them through the
+    one-rank communicator as round 4 did, so that ncclSend / ncclRecv stay exercised on the 1-GPU box.  Both must deliver the same bytes."""
+    import mistral_water
+    old = mistral_water.get_switch("MW_TILES_FORCE_RCCL")
+    mistral_water.set_switch("MW_TILES_FORCE_RCCL", int(request.param))
     yield request.param
-    if old is None:
-        os.environ.pop("MW_TILES_FORCE_RCCL", None)
-    else:
-        os.environ["MW_TILES_FORCE_RCCL"] = old
+    mistral_water.set_switch("MW_TILES_FORCE_RCCL", old)
 
 
 @pytest.mark.parametrize("ntiles", [1, 3])

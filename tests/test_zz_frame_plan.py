@@ -5,7 +5,7 @@ A single-step enqueue at 256^2 / 512^2 / 1024^2 is two launches of their own (cs
 per workgroup over the list of active (column job, field) pairs, a column job's fields on one XCD (k_pass1<.., FS>,
 p1_frame_jobs); pass 2 with the three fields of a row block and the halo row transformed side by side by 13 row groups that
 meet through LDS (k_pass2_frame).  Neither changes the arithmetic of a row or a column, so every output of a step must be
-the same bit pattern whichever plan produced it.  MW_FRAME_KERNEL=0 / MW_P1_FRAME_XCD=0 select round 3's forms of the two
+the same bit pattern whichever plan produced it.  the switches MW_FRAME_KERNEL = 0 / MW_P1_FRAME_XCD = 0 (mw_debug_set_switch) select round 3's forms of the two
 launches (run-time A/B switches): the same bits again."""
 import os
 import subprocess
@@ -69,6 +69,7 @@ sys.path[:0] = [%(repo)r, %(repo)r + "/mistral-water_amd", %(repo)r + "/tests"]
 import torch; torch.cuda.init()
 import mistral_water as mw, workloads
 import test_zz_frame_plan as T
+mw.set_switch("MW_FRAME_KERNEL", %(frame_kernel)s); mw.set_switch("MW_P1_FRAME_XCD", %(p1_xcd)s)
 T._frames_against_batch(mw, workloads.fftmesh_params(1024), 5, 4, True)
 T._frames_against_batch(mw, workloads.fftmesh_params(512), 5, 4, True)
 T._frames_against_batch(mw, workloads.fftmesh_params(256), 5, 4, True)
@@ -78,9 +79,10 @@ print("FRAME_OK")
 
 @pytest.mark.parametrize("frame_kernel,p1_xcd", [("0", "1"), ("1", "0"), ("0", "0")])
 def test_single_step_plan_switches_select_the_same_bits(frame_kernel, p1_xcd):
-    """The run-time A/B switches of the two single-step launches, each combination in a child process (they are read once)."""
-    r = subprocess.run([sys.executable, "-c", _FRAME_CHILD % {"repo": REPO}],
-                       env=dict(os.environ, MW_FRAME_KERNEL=frame_kernel, MW_P1_FRAME_XCD=p1_xcd), capture_output=True, text=True, timeout=600)
+    """The run-time A/B switches of the two single-step launches (csrc/mw_switches.h, set through the test hook), each combination in a
+    child process of its own."""
+    r = subprocess.run([sys.executable, "-c", _FRAME_CHILD % {"repo": REPO, "frame_kernel": frame_kernel, "p1_xcd": p1_xcd}],
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FRAME_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
@@ -114,6 +116,7 @@ sys.path[:0] = [%(repo)r, %(repo)r + "/mistral-water_amd", %(repo)r + "/tests"]
 import torch; torch.cuda.is_available()
 import mistral_water as mw, workloads
 from oracle import oracle as O
+mw.set_switch("MW_DIRECT_CZT", %(direct_czt)s)      # read when a handle is created
 for (N, u, L, amp, rel) in ((12, 1.0, 12.39, 0.01, 2e-5), (50, 1.0, 1.0, 1.0, %(inspector_rel)s), (65, 0.5, 40.0, 1e-5, 2e-5), (200, 1.0, 212.5, 4e-7, 2e-5),
                             (1000, 1.0, 1000.0, 1.6e-8, 2e-5), (1500, 1.0, 1530.0, 7e-9, 2e-5)):      # 1500: M = 4096 = 16^3 (LastInRegs in k_czt)
     p = O.Params(N=N, unit_width=u, length=L, wind_x=5.0 if N < 100 else 14.45, wind_y=3.0 if N < 100 else 12.0, amplitude=amp, choppiness=0.8)
@@ -137,8 +140,9 @@ def test_both_forms_of_the_direct_sum(form):
     Chirp-z: the FFT path's tolerance class everywhere (2e-5 stated; measured 2-5e-7), also on the Inspector-default grid, where a
     phase reaches 3900 rad and the float32 GEMM form needs 2e-4."""
     repo = REPO
-    r = subprocess.run([sys.executable, "-c", _CZT_CHILD % {"repo": repo, "inspector_rel": "2e-5" if form == "chirp-z" else "2e-4"}],
-                       env=dict(os.environ, MW_DIRECT_CZT="1" if form == "chirp-z" else "0"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", _CZT_CHILD % {"repo": repo, "inspector_rel": "2e-5" if form == "chirp-z" else "2e-4",
+                                                            "direct_czt": "1" if form == "chirp-z" else "0"}],
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "CZT_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
@@ -148,24 +152,23 @@ def test_small_grid_fused_czt_equals_three_launches(mw, oracle, N, u, L):
     """Round 5: grids with a chirp-z transform size M <= 256 (N <= 128: the shipped 12-vertex scene, the Inspector default N = 50) run the
     second axis and the assembly in ONE launch (k_czt_rows_assemble: 3 RW + 2 lines side by side, vertices / normals / whitecap straight
     from LDS), and grids with N <= 20 (transform size 64) the WHOLE step in one workgroup and one launch (k_czt_one: the plane between the
-    axes never leaves LDS).  MW_CZT_FUSED=0 selects the three-launch plan at run time, MW_CZT_ONE=0 the two-launch one: the same bits,
+    axes never leaves LDS).  the switch MW_CZT_FUSED = 0 selects the three-launch plan at run time, MW_CZT_ONE = 0 the two-launch one: the same bits,
     hds included; and the f64 oracle at 2e-5."""
     p = oracle.Params(N=N, unit_width=u, length=L, wind_x=3.0, wind_y=2.0, amplitude=2e-4 if N > 12 else 2e-3, choppiness=0.7)
     kw = dict(resolution=N, unit_width=u, length=L, wind=(p.wind_x, p.wind_y), amplitude=p.amplitude, choppiness=p.choppiness, seed=5)
     res = {}
-    plans = {"default": {}, "two": {"MW_CZT_ONE": "0"}, "three": {"MW_CZT_FUSED": "0"}}
+    plans = {"default": {}, "two": {"MW_CZT_ONE": 0}, "three": {"MW_CZT_FUSED": 0}}
     try:
         for name, env in plans.items():
             for k in ("MW_CZT_ONE", "MW_CZT_FUSED"):
-                os.environ.pop(k, None)
-            os.environ.update(env)
+                mw.set_switch(k, env.get(k, 1))
             with mw.Ocean(**kw) as o:
                 assert o.max_batch == 1
                 h0, h0c = o.get_spectrum()
                 res[name] = (o.evaluate(0.75), o.debug_evaluate_hds(0.75), o.profile_kernels(nsteps=1, iters=3))
     finally:
         for k in ("MW_CZT_ONE", "MW_CZT_FUSED"):
-            os.environ.pop(k, None)
+            mw.set_switch(k, 1)
     names = {k: r[2][1][0] for k, r in res.items()}
     assert ("k_czt_one" in names["default"]) == (N <= 20), names                                  # the plans really differ
     assert "rows_assemble" in names["two"] and "rows_assemble" not in names["three"] and "k_czt_one" not in names["three"], names

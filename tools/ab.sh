@@ -3,7 +3,7 @@
 var=$1; shift
 vals=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do vals+=("$1"); shift; done; [ "$1" == "--" ] && shift
 for v in "${vals[@]}"; do
-  out=$(env $var=$v python bench.py --steps 6400 --warmup 640 --no-cpu-baseline "$@" 2>&1 | tail -1)
+  out=$(env MW_ALLOW_LAB=1 $var=$v python bench.py --steps 6400 --warmup 640 --no-cpu-baseline "$@" 2>&1 | tail -1)
   echo "$out" | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']

@@ -5,7 +5,7 @@ set -- $@
 wl=$1; b=$2; st=$3; shift 3
 for v in "$@"; do
   if [ "$v" == "base" ]; then lib=""; else lib="variants/$v.so"; fi
-  out=$(env MW_LIB=$lib python bench.py --workload $wl --batch $b --steps $st --warmup $b --no-cpu-baseline $ABV_EXTRA 2>&1 | tail -1)
+  out=$(env MW_ALLOW_LAB=1 MW_LIB=$lib python bench.py --workload $wl --batch $b --steps $st --warmup $b --no-cpu-baseline $ABV_EXTRA 2>&1 | tail -1)
   echo "$out" | python -c "
 import sys,json
 try:
