@@ -9,7 +9,7 @@ process instead of trusting every array expression:
     spends its time, so the thread gets to run; a box fills at ~10 GB/s, i.e. ~0.2 GB of overshoot.
   * optionally (MW_MEMGUARD=data | as) a kernel-enforced RLIMIT_DATA / RLIMIT_AS.  RLIMIT_AS cannot be the default:
     the ROCm runtime reserves terabytes of address space (SVM apertures) at initialisation, which an address-space
-    limit of a few dozen GB refuses (measured: tools/memguard_probe.py, profiles/r04_memguard_probe.txt).
+    limit of a few dozen GB refuses (measured in round 4: profiles/r04_memguard_probe.txt).
 
 MW_HOST_MEM_CAP_GB (default 48) sets the cap, MW_MEMGUARD=off disables the guard.
 
