@@ -233,6 +233,9 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
 
 // F/OceanNormal.shader + F/WhiteCap.shader in one launch: WhiteCap reads _Bump at its own texel only (:38), so the thread
 // that produced the normal goes straight on to the whitecap (its own global write is visible to itself).
+#ifndef MW_OR_NW_BANDS
+#define MW_OR_NW_BANDS 1  // one band of texel rows per XCD (0: rows round-robin over the XCDs, A/B)
+#endif
 #ifndef MW_OR_NW_QUAD
 #define MW_OR_NW_QUAD 1  // four texels of a row per thread from 16-byte loads (0: one texel per thread, A/B)
 #endif
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float
     // XCD-aware: block b runs on XCD b % 8; give each XCD one contiguous band of texel rows, so that the +-1 and +-8 row
     // neighbours are hits in ITS L2 (round-robin rows made every XCD fetch its own copy: 29.5 B/texel for 16 needed)
     const unsigned nb = gridDim.x, b = blockIdx.x;
-    const unsigned blk = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+    const unsigned blk = (MW_OR_NW_BANDS && nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
     int idx = blk * blockDim.x + threadIdx.x;
     {   // tile blockIdx.y of a batched handle
         const size_t toff = (size_t)blockIdx.y * c.M * c.M;
@@ -464,6 +467,9 @@ static inline int or_steps_chunk(int M) {
     return c < 1 ? 1 : (c > MW_OR_MAX_FRAMES ? MW_OR_MAX_FRAMES : (int)c);
 }
 static inline int or_steps_chunks(int M, int n) { const int c = or_steps_chunk(M); return (n + c - 1) / c; }
+#ifndef MW_OR_STEPS_NW_NT
+#define MW_OR_STEPS_NW_NT 1  // normal / whitecap textures of a steps call leave with non-temporal stores
+#endif
 #ifndef MW_OR_STEPS_MAX_N
 #define MW_OR_STEPS_MAX_N 2048  // above: the 1024-thread P = 16 workgroup has 128 VGPRs per lane, no room for a chain in registers
 #endif
@@ -490,7 +496,7 @@ static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2
         if (B2.disp_a) B2.disp_a += off;
         k_or_pass2<N, P><<<dim3(N / 4, 2, cn), dim3(NT2), LB2, st>>>(B2);
         if (ev) hipEventRecord(ev[2 + 3 * j], st);
-        k_or_normal_white<true><<<dim3(or_nw_blocks(MM), cn), dim3(256), 0, st>>>(s.c, B2.height, B2.disp, B2.disp_g, f_n + 3 * off, f_w + off);
+        k_or_normal_white<MW_OR_STEPS_NW_NT != 0><<<dim3(or_nw_blocks(MM), cn), dim3(256), 0, st>>>(s.c, B2.height, B2.disp, B2.disp_g, f_n + 3 * off, f_w + off);
         if (ev) hipEventRecord(ev[3 + 3 * j], st);
     };
     // Pass 2 and the normal / whitecap pass alternate over chunks of frames: the height / displacement textures a chunk writes (16 B per texel
