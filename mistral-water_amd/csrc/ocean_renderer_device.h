@@ -191,12 +191,15 @@ __global__ __launch_bounds__(256) void k_or_copy_frame(size_t MM, const float* h
     if (hg) { ohg[i] = hg[i]; oda[i] = da[i]; }
 }
 
+// workgroup b of nb (a multiple of 8, else the identity) -> index in an order that gives XCD b % 8 one contiguous eighth of the indices
+__device__ __forceinline__ unsigned or_xcd_band(unsigned b, unsigned nb) { return (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b; }
 template <int N, int P>
 __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = OrP2Geom<N, P>;
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int T = FftGeom<N, P>::T;
+    // (row groups banded per XCD like the normal pass's rows, so that it would find these textures in its own L2: measured no gain, round 6)
     const int tid = threadIdx.x, ab = blockIdx.x;
     {   // tile blockIdx.z of a batched handle
         const size_t toff = (size_t)blockIdx.z * N * N;
@@ -244,8 +247,7 @@ __global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float
                                                          float* normal, float* white) {
     // XCD-aware: block b runs on XCD b % 8; give each XCD one contiguous band of texel rows, so that the +-1 and +-8 row
     // neighbours are hits in ITS L2 (round-robin rows made every XCD fetch its own copy: 29.5 B/texel for 16 needed)
-    const unsigned nb = gridDim.x, b = blockIdx.x;
-    const unsigned blk = (MW_OR_NW_BANDS && nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+    const unsigned blk = MW_OR_NW_BANDS ? or_xcd_band(blockIdx.x, gridDim.x) : blockIdx.x;
     int idx = blk * blockDim.x + threadIdx.x;
     {   // tile blockIdx.y of a batched handle
         const size_t toff = (size_t)blockIdx.y * c.M * c.M;
