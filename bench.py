@@ -51,7 +51,8 @@ BYTES_PASS1 = 16 + 24      # read (P,Q) + write 3 packed complex fields
 BYTES_PASS2 = 24 + 28      # read 3 packed complex fields + write vertex 12 + normal 12 + whitecap 4
 BYTES_POND = 24            # read position 12 + write position 12
 BYTES_RENDERER = 120       # see renderer()
-PROFILE_ROUND = "r05"      # profiles/<round>_<workload>_b<B>_pmc.json carry the counters of ONE build (its build_id inside)
+OR_STEPS_CHUNK = 8         # frames per pass-2 / normal-pass launch of a steps call at 1024^2 (MW_OR_STEPS_CHUNK, csrc/ocean_renderer_device.h)
+PROFILE_ROUND = "r06"      # profiles/<round>_<workload>_b<B>_pmc.json carry the counters of ONE build (its build_id inside)
 
 
 def parse():
@@ -1119,13 +1120,27 @@ def renderer(a, e, extra=False):
     if rank == 0:
         v = world * a.steps * MM * T / el
         bytes_frame = 96.0 + 24.0 / F           # per texel and frame
-        traffic, traffic_note = pmc_traffic("renderer1024", B if T == 1 else T, "k_or_", build_id)     # every kernel of one enqueue
+        # HBM-side bytes of ONE ENQUEUE from the committed counter pass: a call per frame = its three launches; a steps call = one spectrum
+        # launch + per chunk of OR_STEPS_CHUNK frames one pass-2 and one normal-pass launch + the copy of the last frame
+        ktr = [None, None, None, None]
+        if T == 1 and B > 1:
+            nch = -(-B // OR_STEPS_CHUNK)
+            parts = [pmc_traffic_ex("renderer1024", B, k, build_id) for k in ("k_or_pass1_steps", "k_or_pass2", "k_or_normal_white", "k_or_copy_frame")]
+            if all(q["traffic"] is not None for q in parts):
+                ktr = [parts[0]["traffic"], nch * parts[1]["traffic"], nch * parts[2]["traffic"], parts[3]["traffic"]]
+                traffic, traffic_note = sum(ktr), parts[0]["note"] + f"; pass 2 and the normal pass: {nch} launches of {OR_STEPS_CHUNK} frames each per enqueue"
+            else:
+                traffic, traffic_note = None, next(q["note"] for q in parts if q["traffic"] is None)
+        else:
+            traffic, traffic_note = pmc_traffic("renderer1024", B if T == 1 else T, "k_or_", build_id)     # the three kernels of one call
         shares = (24.0 + 28.0 / F, 40.0, 32.0)  # pass 1: exchange out + (spectrum, omega, phase in / out) once per enqueue; pass 2: exchange in + 16 out; normal / white: 16 + 16
         kernels, dom = None, None
         if kstats:
             kernels = [{"name": nm, "us_per_launch": st["mean"] * 1e3, "us_per_launch_median": st["median"] * 1e3, "us_per_launch_p10": st["p10"] * 1e3,
                         "us_per_launch_p90": st["p90"] * 1e3,
                         "algorithmic_bytes_per_texel_frame": (shares[i] if i < 3 else None),
+                        "physical_bytes_per_texel_frame": (ktr[i] / (MM * B)) if ktr[i] else None,
+                        "physical_GBps": (ktr[i] / (st["mean"] * 1e-3) / 1e9) if ktr[i] else None,
                         "frac": (shares[i] * MM * B / (st["mean"] * 1e-3) / HBM_PEAK) if i < 3 else None} for i, (nm, st) in enumerate(kstats)]
             dom = max(range(3), key=lambda i: kstats[i][1]["mean"])
         rpc = pcts(regions)

@@ -45,7 +45,7 @@ pmc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        if any(t in k for t in ("k_pass", "gerstner", "k_or_", "k_pond", "k_gemm", "k_direct")):
+        if any(t in k for t in ("k_pass", "gerstner", "k_or_", "k_pond", "k_gemm", "k_direct", "k_czt")):
             pmc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
             pmc[k]["_dur_ns_" + row["Counter_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
             pmc[k]["_grid_" + row["Counter_Name"]].append(row.get("Grid_Size"))
