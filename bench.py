@@ -1133,7 +1133,11 @@ def renderer(a, e, extra=False):
                 traffic, traffic_note = None, next(q["note"] for q in parts if q["traffic"] is None)
         else:
             traffic, traffic_note = pmc_traffic("renderer1024", B if T == 1 else T, "k_or_", build_id)     # the three kernels of one call
-        shares = (24.0 + 28.0 / F, 40.0, 32.0)  # pass 1: exchange out + (spectrum, omega, phase in / out) once per enqueue; pass 2: exchange in + 16 out; normal / white: 16 + 16
+        # per kernel, the bytes ITS PLAN must move per texel and frame.  Three-transform plan: pass 1 = exchange out 24 + (spectrum 16, omega 4, phase
+        # in / out 8) once per enqueue; pass 2 = exchange in 24 + 16 out.  Packed plan (two transforms: height + i Dz share one; the default for
+        # planar textures): exchange 16 each way; pass 1 reads (h0, h0c) or (P, Q) + omega + phase per field workgroup.  Normal / whitecap: 16 + 16.
+        packed = (mw.get_switch("MW_OR_PACKED") != 0)
+        shares = ((16.0 + 52.0 / F, 32.0, 32.0) if packed else (24.0 + 28.0 / F, 40.0, 32.0))
         kernels, dom = None, None
         if kstats:
             kernels = [{"name": nm, "us_per_launch": st["mean"] * 1e3, "us_per_launch_median": st["median"] * 1e3, "us_per_launch_p10": st["p10"] * 1e3,
@@ -1147,7 +1151,10 @@ def renderer(a, e, extra=False):
         roof = {"bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s", "traffic": traffic, "traffic_note": traffic_note,
                 "traffic_what": f"HBM-side bytes of one enqueue = {B if T == 1 else T} frame(s), all its kernels",
                 "physical_bytes_per_texel_frame": (traffic / (MM * (B if T == 1 else T))) if traffic else None,
-                "whole_frame": {"algorithmic_bytes_per_texel_frame": bytes_frame, "achieved": v / world * bytes_frame / 1e9,
+                "whole_frame": {"algorithmic_bytes_per_texel_frame": bytes_frame, "plan_bytes_per_texel_frame": sum(shares),
+                                "plan": ("packed: two complex transforms per frame (exchange buffer 16 B per texel each way)" if packed
+                                         else "three complex transforms per frame, as the shaders"),
+                                "achieved": v / world * bytes_frame / 1e9,
                                 "frac": v / world * bytes_frame / HBM_PEAK,
                                 "real_frac": (v / world * traffic / (MM * (B if T == 1 else T)) / HBM_PEAK) if traffic else None},
                 "kernels": kernels}

@@ -171,7 +171,12 @@ int32_t mw_ocean_max_batch(const mw_ocean* o); /* largest nsteps one enqueue acc
  * advances the stateful phase by delta_time*mult and produces the four result textures, host side:
  * height [M*M] (= heightTexture.r), disp_xz [M*M*2] (= displacementTexture.rb),
  * normal_xyz [M*M*3] (= normalTexture.rgb), white [M*M] (= whiteTexture.r); M = 8*resolution,
- * texel (px,py) at index py*M + px.  Any pointer may be NULL.                                      */
+ * texel (px,py) at index py*M + px.  Any pointer may be NULL.
+ * Plan: these four planar textures need only Re h, Re / Im Dx and Re Dz, so the planar entry points run TWO complex transforms per frame
+ * (height + i Dz share one, built from the Hermitian parts of the initial spectrum: csrc/ocean_renderer_kernels.h) where the shaders
+ * run three; the RGBA forms below, whose channels include Im h and Im Dz, run three.  Both are within the stated float32 tolerance of
+ * the reference's pipeline; one frame through the two forms may differ in the last bits.  A phase texture injected with
+ * mw_ocean_set_phase that is not mirror-symmetric (every phase the library produced is) selects three transforms here too.        */
 mw_status mw_ocean_generate_texture(mw_ocean* o, float delta_time, float* height, float* disp_xz, float* normal_xyz,
                                     float* white);
 mw_status mw_ocean_generate_texture_device(mw_ocean* o, float delta_time, void* d_height, void* d_disp_xz,

@@ -46,8 +46,8 @@ mw_status mw_debug_sincos_fast(const float* x_host, int32_t n, float* s_host, fl
  * host emulation uses (index work: bit for bit)                                                                                      */
 mw_status mw_debug_wave_transpose4(float* inout_host);
 /* The library's run-time plan switches (csrc/mw_switches.h: MW_LATENCY_PLAN, MW_FRAME_KERNEL, MW_P1_FRAME_XCD, MW_P1_TGROUP, MW_CZT_ONE,
- * MW_CZT_FUSED, MW_DIRECT_CZT, MW_TILES_FORCE_RCCL, MW_POND_STEPS_PER_WG, MW_POND_XCD).  Every alternative plan gives the same bits as
- * the default; the tests select them here.  Process-wide; MW_DIRECT_CZT and MW_P1_TGROUP are read when a handle is created, the rest per
+ * MW_CZT_FUSED, MW_DIRECT_CZT, MW_TILES_FORCE_RCCL, MW_POND_STEPS_PER_WG, MW_POND_XCD, MW_OR_PACKED).  Every alternative plan gives the same bits as
+ * the default (MW_OR_PACKED = 0, the OceanRenderer's three-transform plan: the same textures to float32 rounding); the tests select them here.  Process-wide; MW_DIRECT_CZT and MW_P1_TGROUP are read when a handle is created, the rest per
  * call.  A product build never reads the environment; MW_EINVAL for an unknown name (get: INT32_MIN).                                 */
 mw_status mw_debug_set_switch(const char* name, int32_t value);
 int32_t mw_debug_get_switch(const char* name);

@@ -1148,7 +1148,9 @@ mw_status mw_ocean_set_spectrum(mw_ocean* o, const float* h0_xy, const float* h0
         HIP_TRY(hipMemcpyAsync(b, h0conj_xy, bytes, hipMemcpyHostToDevice, o->stream));
         k_or_set_init<<<dim3((unsigned)(((size_t)o->N * o->N + 255) / 256), tiles), dim3(256), 0, o->stream>>>(o->N, a, b, o->orr.initT,
                                                                                                           o->orr.phaseT);
+        k_or_prep<<<dim3((unsigned)(((size_t)o->N * o->N + 255) / 256), tiles), dim3(256), 0, o->stream>>>(o->N, o->orr.initT, o->orr.PQT);
         HIP_TRY(hipGetLastError());
+        o->orr.phase_sym = true;  // a fresh spectrum restarts the phase at 0
         HIP_TRY(hipStreamSynchronize(o->stream));
         return MW_OK;
     }
@@ -1263,6 +1265,20 @@ static mw_status phase_copy(mw_ocean* o, float* host_out, const float* host_in, 
         HIP_TRY(hipMemcpyAsync(tmp, host_in, bytes, hipMemcpyHostToDevice, o->stream));
         k_or_phase_transpose<<<grid, block, 0, o->stream>>>(o->N, tmp, o->orr.phaseT);
         HIP_TRY(hipGetLastError());
+        // The two-transform plan needs phase[p] == phase[m(p)], m the index mirror (csrc/ocean_renderer_kernels.h): true of every phase the library
+        // produced (omega is mirror-symmetric bit for bit), checked for what a caller hands in -- anything else runs the three-transform plan
+        bool sym = true;
+        const int M = o->N;
+        for (int t = 0; t < o->orr.tiles && sym; t++) {
+            const float* ph = host_in + (size_t)t * MM;
+            for (int py = 0; py < M && sym; py++) {
+                const float* row = ph + (size_t)py * M;
+                const float* mrow = ph + (size_t)((M - py) % M) * M;
+                for (int px = 0; px < M; px++)
+                    if (row[px] != mrow[(M - px) % M]) { sym = false; break; }
+            }
+        }
+        o->orr.phase_sym = sym;
     }
     HIP_TRY(hipStreamSynchronize(o->stream));
     return MW_OK;

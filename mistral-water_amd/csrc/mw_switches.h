@@ -1,6 +1,6 @@
 // mw_switches.h -- the library's run-time plan switches (host side).
 // Every alternative plan below produces the same bits as the default one (tests/test_zz_frame_plan.py, tests/test_state_and_tiles.py hold
-// them to that) and exists for A/B measurements and for those tests.  A product build never reads the environment: the switches carry
+// them to that; MW_OR_PACKED = 0 the same textures to float32 rounding, tests/test_ocean_renderer.py) and exists for A/B measurements and for those tests.  A product build never reads the environment: the switches carry
 // their defaults and change only through the test hook mw_debug_set_switch (include/mistral_water_hooks.h).  A lab build (-DMW_LAB: what
 // tools/build_variant.sh and build_native(extra=...) make; mw_build_id() then says "lab") also takes them from environment variables of
 // the same names, read once when the library is loaded.
@@ -22,12 +22,13 @@ enum Switch {
     SW_TILES_FORCE_RCCL,  // 1: mw_tiles_gather sends every tile through ncclSend / ncclRecv, the root's own included
     SW_POND_STEPS_PER_WG, // time values per workgroup of k_gerstner_steps; 0: the built-in 8
     SW_POND_XCD,          // 1: the step groups of a vertex chunk on one XCD (measured no faster)
+    SW_OR_PACKED,         // 1: OceanRenderer planar-texture calls with a symmetric phase run two transforms per frame; 0: always three
     SW_COUNT
 };
 struct SwitchDef { const char* name; int def; };
 static const SwitchDef g_switch_defs[SW_COUNT] = {
     {"MW_LATENCY_PLAN", 1}, {"MW_FRAME_KERNEL", 1}, {"MW_P1_FRAME_XCD", 1}, {"MW_P1_TGROUP", -1}, {"MW_CZT_ONE", 1}, {"MW_CZT_FUSED", 1},
-    {"MW_DIRECT_CZT", 1}, {"MW_TILES_FORCE_RCCL", 0}, {"MW_POND_STEPS_PER_WG", 0}, {"MW_POND_XCD", 0},
+    {"MW_DIRECT_CZT", 1}, {"MW_TILES_FORCE_RCCL", 0}, {"MW_POND_STEPS_PER_WG", 0}, {"MW_POND_XCD", 0}, {"MW_OR_PACKED", 1},
 };
 struct SwitchTable {
     std::atomic<int> v[SW_COUNT];

@@ -9,6 +9,7 @@
 
 #include "../../include/mistral_water.h"
 #include "ocean_renderer_kernels.h"
+#include "mw_switches.h"
 
 namespace mw {
 
@@ -36,6 +37,8 @@ struct OrState {
     OrConsts c{};
     float mult = 1.f, choppiness = 0.f;
     f4* initT = nullptr;
+    f4* PQT = nullptr;     // [px][py] Hermitian parts (P, Q) of the initial spectrum: the packed plan (or_prep_element), rebuilt with initT
+    bool phase_sym = true; // the phase texture equals its mirror image (true from creation on; mw_ocean_set_phase checks what it is given)
     float* omT = nullptr;  // [px][py] angular frequency (or_omega), fixed per handle
     float *phaseT = nullptr, *phaseT2 = nullptr;  // current phase / next phase (swapped after every frame)
     cf *TW = nullptr, *E = nullptr;
@@ -93,6 +96,56 @@ __global__ void k_or_get_init(int M, const f4* initT, cf* h0, cf* h0c) {
     h0c[idx] = mk(v.z, v.w);
 }
 
+__global__ void k_or_prep(int M, const f4* initT, f4* PQT) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * M) return;
+    const size_t toff = (size_t)blockIdx.y * M * M;  // tile blockIdx.y
+    or_prep_element(M, idx / M, idx % M, initT + toff, PQT + toff);
+}
+#ifndef MW_OR_PACKED
+#define MW_OR_PACKED 1  // planar-texture calls with a mirror-symmetric phase run two transforms per frame (0: always three)
+#endif
+
+// the packed plan's spectrum kernel (lone frame: gridDim.y == 2, one field per workgroup; tiles / big textures: gridDim.y == 1, both fields)
+template <int N, int P>
+__global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1_packed(OrP1Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = OrP1Geom<N, P>;
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int T = FftGeom<N, P>::T;
+    const int tid = threadIdx.x, jb = blockIdx.x;
+    const int f0 = gridDim.y == 1 ? 0 : (int)blockIdx.y, f1 = gridDim.y == 1 ? 2 : f0 + 1;
+    {   // tile blockIdx.z of a batched handle
+        const size_t toff = (size_t)blockIdx.z * N * N;
+        A.initT += toff; A.PQT += toff; A.phase_in += toff; A.phase_out += toff; A.E += 2 * toff;
+    }
+    const int w = tid / T, u = tid % T;
+    TwStage<N, P, G::NTHREADS, false> tws;
+    tws.load(lds, A.TW, tid);
+    const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
+    cf* set0 = lds + G::TW_LDS;
+    cf h[P], hh[P], x[P];
+#pragma unroll
+    for (int q = 0; q < P; q++) h[q] = hh[q] = mk(0.f, 0.f);
+    if (gridDim.y == 1) or_p1_animate_packed<N, P, MW_OR_P1_CHUNK>(A, jb, tid, true, true, true, h, hh);
+    else or_p1_animate_packed<N, P, 1>(A, jb, tid, f0 == 0, f0 == 0, f0 == 1, h, hh);
+    tws.store(lds, tid);
+    for (int f = f0; f < f1; f++) {
+        or_p1_build_packed<N, P>(A, jb, tid, f, h, hh, x);
+        if (f != f0) __syncthreads();
+        stage0_store<N, P, -1>(x, u, set0 + w * G::BUFSTRIDE);
+        __syncthreads();
+#pragma unroll
+        for (int s = 1; s < FftGeom<N, P>::S; s++) {
+            load_slots<N, P>(x, u, set0 + w * G::BUFSTRIDE, s - 1);
+            __syncthreads();
+            stage_store<N, P, -1, false>(x, u, set0 + w * G::BUFSTRIDE, tw, s);
+            __syncthreads();
+        }
+        or_p1_finish<N, P>(A, tw, jb, tid, f, x, set0);
+    }
+}
+
 template <int N, int P>
 __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -135,8 +188,9 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Arg
 
 // nframes consecutive frames of one ocean: grid (M/4 column jobs, 1, frame groups).  KEEP: the initial spectrum of the workgroup's
 // points stays in registers over the frames of its group (else re-read per frame: an L2 hit after the first).
-template <int N, int P, bool KEEP>
+template <int N, int P, bool KEEP, bool PACKED = false>
 __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1_steps(OrP1StepsArgs S) {
+    constexpr int NF = PACKED ? 2 : 3;  // planes of the exchange buffer per frame
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using G = OrP1Geom<N, P>;
     cf* lds = reinterpret_cast<cf*>(smem);
@@ -150,20 +204,27 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1_steps(O
     const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
     cf* set0 = lds + G::TW_LDS;
     float om[P], ph[P];
-    f4 v[P];
+    f4 v[P], vn;
+    const int fsel = PACKED ? (int)blockIdx.y : 0;  // packed plan: one field per workgroup (or_p1_steps_coeff)
     or_p1_steps_begin<N, P>(A, jb, tid, om, ph);
-    if (KEEP) or_p1_steps_spectrum<N, P>(A, jb, tid, v);
+    if constexpr (PACKED) { if (KEEP) or_p1_steps_coeff<N, P>(A, jb, tid, fsel, v, vn); }
+    else { if (KEEP) or_p1_steps_spectrum<N, P>(A, jb, tid, v); }
     tws.store(lds, tid);  // behind the phase / spectrum requests; published by the first barrier
     for (int k = 0; k < k0; k++) or_p1_steps_advance<P>(om, ph, S.dt[k]);  // the chain over the frames of the groups before this one
-    A.E += (size_t)3 * N * N * k0;
+    A.E += (size_t)NF * N * N * k0;
     for (int k = k0; k < k1; k++) {
-        cf h[P], x[P];
-        if (!KEEP) or_p1_steps_spectrum<N, P>(A, jb, tid, v);
+        cf h[PACKED ? 1 : P], x[P];
         or_p1_steps_advance<P>(om, ph, S.dt[k]);
-        or_p1_steps_animate<P>(v, ph, h);
-        for (int f = 0; f < 3; f++) {
-            or_p1_build<N, P>(A, jb, tid, f, h, x);
-            if (f != 0 || k != k0) __syncthreads();  // the previous field's final-pass reads of the buffers are done
+        if constexpr (PACKED) {
+            if (!KEEP) or_p1_steps_coeff<N, P>(A, jb, tid, fsel, v, vn);
+        } else {
+            if (!KEEP) or_p1_steps_spectrum<N, P>(A, jb, tid, v);
+            or_p1_steps_animate<P>(v, ph, h);
+        }
+        for (int f = PACKED ? fsel : 0; f < (PACKED ? fsel + 1 : 3); f++) {
+            if constexpr (PACKED) or_p1_steps_build_split<N, P>(A, jb, tid, f, v, vn, ph, x);
+            else or_p1_build<N, P>(A, jb, tid, f, h, x);
+            if ((!PACKED && f != 0) || k != k0) __syncthreads();  // the previous field's final-pass reads of the buffers are done
             stage0_store<N, P, -1>(x, u, set0 + w * G::BUFSTRIDE);
             __syncthreads();
 #pragma unroll
@@ -175,9 +236,9 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1_steps(O
             }
             or_p1_finish<N, P>(A, tw, jb, tid, f, x, set0);
         }
-        A.E += (size_t)3 * N * N;
+        A.E += (size_t)NF * N * N;
     }
-    if (k1 == S.nframes) or_p1_steps_store_phase<N, P>(A, jb, tid, ph);  // the last group holds the phase after every frame
+    if (k1 == S.nframes && fsel == 0) or_p1_steps_store_phase<N, P>(A, jb, tid, ph);  // the last group holds the phase after every frame
 }
 
 // the textures of frame `last` of a steps call become the handle's latest frame (mw_ocean_displace_mesh, the tile gather, ...)
@@ -234,6 +295,40 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2(OrP2Arg
     }
 }
 
+// the packed plan's second pass: plane 0 = hx (-> displacement.r, .g), plane 1 = G (-> height.r + i displacement.b); one workgroup per 4 rows
+template <int N, int P>
+__global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2_packed(OrP2Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using G = OrP2Geom<N, P>;
+    cf* lds = reinterpret_cast<cf*>(smem);
+    const int tid = threadIdx.x, ab = blockIdx.x;
+    {   // tile / frame blockIdx.z
+        const size_t toff = (size_t)blockIdx.z * N * N;
+        A.E += 2 * toff; A.height += toff; A.disp += toff; A.disp_g += toff;
+    }
+    TwStage<N, P, G::NTHREADS, false> tws;
+    tws.load(lds, A.TW, tid);
+    const Twiddles tw = TwGeom<N, P>::view(A.TW, lds);
+    cf* set0 = lds + G::TW_LDS;
+    cf x[P];
+    float dx[P];
+    for (int k = 0; k < 2; k++) {
+        if (k != 0) __syncthreads();
+        or_p2_load<N, P>(A, ab, tid, k, x, set0);
+        if (k == 0) tws.store(lds, tid);
+        __syncthreads();
+#pragma unroll
+        for (int s = 1; s < FftGeom<N, P>::S; s++) {
+            const int um = XLay<N, P>::EXACT ? tid % FftGeom<N, P>::T : tid >> 2, rm = XLay<N, P>::EXACT ? tid / FftGeom<N, P>::T : tid & 3;
+            load_slots<N, P>(x, um, set0 + rm * G::BUFSTRIDE, s - 1);
+            __syncthreads();
+            stage_store<N, P, -1, false>(x, um, set0 + rm * G::BUFSTRIDE, tw, s);
+            __syncthreads();
+        }
+        or_p2_finish<N, P>(A, tw, ab, tid, k == 0 ? 1 : 3, x, dx, set0);
+    }
+}
+
 // F/OceanNormal.shader + F/WhiteCap.shader in one launch: WhiteCap reads _Bump at its own texel only (:38), so the thread
 // that produced the normal goes straight on to the whitecap (its own global write is visible to itself).
 #ifndef MW_OR_NW_BANDS
@@ -287,7 +382,7 @@ std::vector<cf> build_twiddle_table(int N, int P, int sgn);  // mistral_water.hi
 int plan_points_host(int N);
 
 static inline void or_free(OrState& s) {
-    hipFree(s.initT); hipFree(s.phaseT); hipFree(s.phaseT2); hipFree(s.omT); hipFree(s.TW); hipFree(s.E); hipFree(s.out_height); hipFree(s.out_disp_cf);
+    hipFree(s.initT); hipFree(s.PQT); hipFree(s.phaseT); hipFree(s.phaseT2); hipFree(s.omT); hipFree(s.TW); hipFree(s.E); hipFree(s.out_height); hipFree(s.out_disp_cf);
     hipFree(s.out_disp_g); hipFree(s.out_normal); hipFree(s.out_white); hipFree(s.out_height_g); hipFree(s.out_disp_a);
     hipFree(s.fr_E); hipFree(s.fr_height); hipFree(s.fr_disp_g); hipFree(s.fr_normal); hipFree(s.fr_white); hipFree(s.fr_height_g);
     hipFree(s.fr_disp_a); hipFree(s.fr_disp);
@@ -302,7 +397,7 @@ static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStre
     const size_t MM = (size_t)M * M, TM = MM * (size_t)tiles;
     std::vector<cf> tab = build_twiddle_table(M, plan_points_host(M), -1);
 #define OR_ALLOC(ptr, bytes) if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) { g_or_err = "OceanRenderer: hipMalloc failed"; return MW_ENOMEM; }
-    OR_ALLOC(s.initT, sizeof(f4) * TM) OR_ALLOC(s.phaseT, sizeof(float) * TM) OR_ALLOC(s.phaseT2, sizeof(float) * TM) OR_ALLOC(s.omT, sizeof(float) * MM) OR_ALLOC(s.TW, sizeof(cf) * tab.size())
+    OR_ALLOC(s.initT, sizeof(f4) * TM) OR_ALLOC(s.PQT, sizeof(f4) * TM) OR_ALLOC(s.phaseT, sizeof(float) * TM) OR_ALLOC(s.phaseT2, sizeof(float) * TM) OR_ALLOC(s.omT, sizeof(float) * MM) OR_ALLOC(s.TW, sizeof(cf) * tab.size())
     OR_ALLOC(s.E, sizeof(cf) * 3 * TM) OR_ALLOC(s.out_height, sizeof(float) * TM) OR_ALLOC(s.out_disp_cf, sizeof(cf) * TM)
     OR_ALLOC(s.out_disp_g, sizeof(float) * TM) OR_ALLOC(s.out_normal, sizeof(float) * 3 * TM) OR_ALLOC(s.out_white, sizeof(float) * TM)
 #undef OR_ALLOC
@@ -311,9 +406,12 @@ static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStre
     k_or_init<<<dim3((unsigned)((MM + 255) / 256), tiles), dim3(256), 0, st>>>(M, p.length, p.wind_x, p.wind_y, p.amplitude / 10000.f,
                                                                               p.gravity, p.seed, s.initT, s.phaseT);
     k_or_omega<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(s.c, s.omT);
+    k_or_prep<<<dim3((unsigned)((MM + 255) / 256), tiles), dim3(256), 0, st>>>(M, s.initT, s.PQT);
     if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_init launch failed"; return MW_EDEVICE; }
     return MW_OK;
 }
+// the planar-texture plan of a call: two transforms per frame where the identity holds (or_prep_element), else the shaders' three
+static inline bool or_use_packed(const OrState& s) { return MW_OR_PACKED != 0 && sw(SW_OR_PACKED) != 0 && !s.want_imag && s.phase_sym; }
 
 // RenderInitial() after a parameter change (S/OceanRenderer.cs:98-109): initialTexture again from the new length / wind /
 // amplitude, dispersion and spectrum passes on the new length (:94-97); the phase textures and the normal pass's length stay
@@ -323,6 +421,7 @@ static inline mw_status or_reinit(OrState& s, float length, float wind_x, float 
     k_or_init<<<dim3((unsigned)((MM + 255) / 256), s.tiles), dim3(256), 0, st>>>(s.M, length, wind_x, wind_y, amplitude / 10000.f,
                                                                                 s.c.gravity, seed, s.initT, nullptr);
     k_or_omega<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(s.c, s.omT);
+    k_or_prep<<<dim3((unsigned)((MM + 255) / 256), s.tiles), dim3(256), 0, st>>>(s.M, s.initT, s.PQT);
     if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_init launch failed"; return MW_EDEVICE; }
     return MW_OK;
 }
@@ -358,18 +457,33 @@ static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st, hipEven
         if (e != hipSuccess) return e;
     }
     OrP1Args A1;
-    A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.E = s.E; A1.c = s.c; A1.dt = dt;
+    A1.initT = s.initT; A1.PQT = s.PQT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.E = s.E; A1.c = s.c; A1.dt = dt;
     A1.stream_E = or_call_is_big<N>(s) ? 1 : 0;
     constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
-    if (ev) hipEventRecord(ev[0], st);
-    k_or_pass1<N, P><<<dim3(N / 4, (s.tiles > 1 || N >= MW_OR_BIG_N) ? 1 : 3, s.tiles), dim3(NT1), LB1, st>>>(A1);
-    if (ev) hipEventRecord(ev[1], st);
-    std::swap(s.phaseT, s.phaseT2);
+    constexpr int NT2 = OrP2Geom<N, P>::NTHREADS, LB2 = OrP2Geom<N, P>::LDS_BYTES;
+    const bool packed = or_use_packed(s), all_fields = (s.tiles > 1 || N >= MW_OR_BIG_N);
     OrP2Args A2;
     A2.E = s.E; A2.TW = s.TW; A2.height = s.out_height; A2.disp = s.out_disp_cf; A2.disp_g = s.out_disp_g; A2.c = s.c;
     A2.height_g = s.want_imag ? s.out_height_g : nullptr;
     A2.disp_a = s.want_imag ? s.out_disp_a : nullptr;
-    constexpr int NT2 = OrP2Geom<N, P>::NTHREADS, LB2 = OrP2Geom<N, P>::LDS_BYTES;
+    if (packed) {
+        static AttrOnce attr1p, attr2p;
+        hipError_t e = attr1p.set(reinterpret_cast<const void*>(&k_or_pass1_packed<N, P>), LB1);
+        if (e != hipSuccess) return e;
+        e = attr2p.set(reinterpret_cast<const void*>(&k_or_pass2_packed<N, P>), LB2);
+        if (e != hipSuccess) return e;
+        if (ev) hipEventRecord(ev[0], st);
+        k_or_pass1_packed<N, P><<<dim3(N / 4, all_fields ? 1 : 2, s.tiles), dim3(NT1), LB1, st>>>(A1);
+        if (ev) hipEventRecord(ev[1], st);
+        std::swap(s.phaseT, s.phaseT2);
+        k_or_pass2_packed<N, P><<<dim3(N / 4, 1, s.tiles), dim3(NT2), LB2, st>>>(A2);
+        if (ev) hipEventRecord(ev[2], st);
+        return hipGetLastError();
+    }
+    if (ev) hipEventRecord(ev[0], st);
+    k_or_pass1<N, P><<<dim3(N / 4, all_fields ? 1 : 3, s.tiles), dim3(NT1), LB1, st>>>(A1);
+    if (ev) hipEventRecord(ev[1], st);
+    std::swap(s.phaseT, s.phaseT2);
     k_or_pass2<N, P><<<dim3(N / 4, 2, s.tiles), dim3(NT2), LB2, st>>>(A2);
     if (ev) hipEventRecord(ev[2], st);
     return hipGetLastError();
@@ -423,8 +537,9 @@ static inline mw_status or_generate(OrState& s, float delta_time, float* d_heigh
 // one GenerateTexture() delivered as the reference's four ARGBFloat render targets (any destination may be NULL)
 static inline mw_status or_generate_rgba(OrState& s, float delta_time, f4* d_height, f4* d_disp, f4* d_normal, f4* d_white,
                                          hipStream_t st) {
-    s.want_imag = true;
+    s.want_imag = true;  // for this call: Im h and Im Dz are channels of the targets, so it runs the three-transform plan (or_use_packed)
     mw_status r = or_generate(s, delta_time, nullptr, nullptr, nullptr, nullptr, st);
+    s.want_imag = false;
     if (r != MW_OK) return r;
     const size_t MM = (size_t)s.M * s.M;
     k_or_pack_rgba<<<dim3((unsigned)((MM + 255) / 256), s.tiles), dim3(256), 0, st>>>(s.M, s.out_height, s.out_height_g, s.out_disp_cf,
@@ -458,6 +573,9 @@ static inline mw_status or_frames_reserve(OrState& s, int n, const bool (&need)[
 #ifndef MW_OR_FRAME_GROUPS
 #define MW_OR_FRAME_GROUPS 4  // frame groups of a steps call = workgroups per column job (see k_or_pass1_steps)
 #endif
+#ifndef MW_OR_FRAME_GROUPS_PACKED
+#define MW_OR_FRAME_GROUPS_PACKED 2  // the packed plan has two workgroups per column job and group already (one per field): 1 / 2 / 3 / 4 groups measured
+#endif                               // 18.9 / 18.6 / 19.8 / 19.3 us per frame at 32 frames per enqueue
 #ifndef MW_OR_STEPS_KEEP
 #define MW_OR_STEPS_KEEP 1
 #endif
@@ -475,13 +593,17 @@ static inline int or_steps_chunks(int M, int n) { const int c = or_steps_chunk(M
 #ifndef MW_OR_STEPS_MAX_N
 #define MW_OR_STEPS_MAX_N 2048  // above: the 1024-thread P = 16 workgroup has 128 VGPRs per lane, no room for a chain in registers
 #endif
-template <int N>
+#ifndef MW_OR_STEPS_KEEP_PACKED
+#define MW_OR_STEPS_KEEP_PACKED 1  // packed plan: (h0, h0c) AND (P, Q) of a workgroup's points stay in registers over its frames
+#endif
+template <int N, bool PACKED>
 static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2Args& A2, float* f_n, float* f_w, hipStream_t st, hipEvent_t* ev = nullptr) {
-    constexpr int P = Plan<N>::P;
-    constexpr bool KEEP = MW_OR_STEPS_KEEP != 0 && P <= 8;  // P = 16: 64 more live registers would halve the occupancy
+    constexpr int P = Plan<N>::P, NF = PACKED ? 2 : 3;
+    constexpr bool KEEP = (PACKED ? MW_OR_STEPS_KEEP_PACKED : MW_OR_STEPS_KEEP) != 0 && P <= 8;  // P = 16: no registers to spare
     static AttrOnce attr1, attr2;
     {
-        hipError_t e = attr2.set(reinterpret_cast<const void*>(&k_or_pass2<N, P>), OrP2Geom<N, P>::LDS_BYTES);
+        hipError_t e = PACKED ? attr2.set(reinterpret_cast<const void*>(&k_or_pass2_packed<N, P>), OrP2Geom<N, P>::LDS_BYTES)
+                              : attr2.set(reinterpret_cast<const void*>(&k_or_pass2<N, P>), OrP2Geom<N, P>::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
     constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
@@ -493,10 +615,11 @@ static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2
     auto rest = [&](int c0, int cn, int j) {
         OrP2Args B2 = A2;
         const size_t off = MM * (size_t)c0;
-        B2.E += 3 * off; B2.height += off; B2.disp += off; B2.disp_g += off;
+        B2.E += NF * off; B2.height += off; B2.disp += off; B2.disp_g += off;
         if (B2.height_g) B2.height_g += off;
         if (B2.disp_a) B2.disp_a += off;
-        k_or_pass2<N, P><<<dim3(N / 4, 2, cn), dim3(NT2), LB2, st>>>(B2);
+        if (PACKED) k_or_pass2_packed<N, P><<<dim3(N / 4, 1, cn), dim3(NT2), LB2, st>>>(B2);
+        else k_or_pass2<N, P><<<dim3(N / 4, 2, cn), dim3(NT2), LB2, st>>>(B2);
         if (ev) hipEventRecord(ev[2 + 3 * j], st);
         k_or_normal_white<MW_OR_STEPS_NW_NT != 0><<<dim3(or_nw_blocks(MM), cn), dim3(256), 0, st>>>(s.c, B2.height, B2.disp, B2.disp_g, f_n + 3 * off, f_w + off);
         if (ev) hipEventRecord(ev[3 + 3 * j], st);
@@ -506,36 +629,38 @@ static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2
     // 1024^2) every read of the normal pass went to HBM: 9.1 us per frame against 7.2 from the cache (chunks of 4 / 8 / 16 / 32 frames:
     // 21.9 / 21.8 / 23.2 / 23.3 us per frame).
     if constexpr (N <= MW_OR_STEPS_MAX_N) {
-        hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_or_pass1_steps<N, P, KEEP>), LB1);
+        hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_or_pass1_steps<N, P, KEEP, PACKED>), LB1);
         if (e != hipSuccess) return e;
         OrP1StepsArgs S;
-        S.a.initT = s.initT; S.a.omT = s.omT; S.a.phase_in = s.phaseT; S.a.phase_out = s.phaseT2; S.a.TW = s.TW; S.a.E = s.fr_E; S.a.c = s.c;
+        S.a.initT = s.initT; S.a.PQT = s.PQT; S.a.omT = s.omT; S.a.phase_in = s.phaseT; S.a.phase_out = s.phaseT2; S.a.TW = s.TW; S.a.E = s.fr_E; S.a.c = s.c;
         S.a.dt = 0.f; S.a.stream_E = 1;
         for (int k = 0; k < MW_OR_MAX_FRAMES; k++) S.dt[k] = k < n ? dt[k] : 0.f;
         S.nframes = n;
         // ONE spectrum launch over all frames: per chunk (so that pass 2 would find the exchange buffer in the cache) it ran 195 -> 283 us per 32
         // frames and pass 2 no faster -- the exchange buffer is written with streaming stores and does not stay
-        int groups = MW_OR_FRAME_GROUPS;
+        int groups = PACKED ? MW_OR_FRAME_GROUPS_PACKED : MW_OR_FRAME_GROUPS;
         if (groups > n) groups = n;
         S.group = (n + groups - 1) / groups;
         groups = (n + S.group - 1) / S.group;
-        k_or_pass1_steps<N, P, KEEP><<<dim3(N / 4, 1, groups), dim3(NT1), LB1, st>>>(S);
+        k_or_pass1_steps<N, P, KEEP, PACKED><<<dim3(N / 4, PACKED ? 2 : 1, groups), dim3(NT1), LB1, st>>>(S);
         for (int c0 = 0, j = 0; c0 < n; c0 += chunk, j++) {
             if (ev) hipEventRecord(ev[1 + 3 * j], st);
             rest(c0, (n - c0 < chunk) ? n - c0 : chunk, j);
         }
         std::swap(s.phaseT, s.phaseT2);
     } else {  // one bandwidth-bound spectrum launch per frame (each already fills the device)
-        hipError_t e = attr1.set(reinterpret_cast<const void*>(&k_or_pass1<N, P>), LB1);
+        hipError_t e = PACKED ? attr1.set(reinterpret_cast<const void*>(&k_or_pass1_packed<N, P>), LB1)
+                              : attr1.set(reinterpret_cast<const void*>(&k_or_pass1<N, P>), LB1);
         if (e != hipSuccess) return e;
         for (int c0 = 0, j = 0; c0 < n; c0 += chunk, j++) {
             const int cn = (n - c0 < chunk) ? n - c0 : chunk;
             for (int k = c0; k < c0 + cn; k++) {
                 OrP1Args A1;
-                A1.initT = s.initT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.c = s.c; A1.dt = dt[k];
-                A1.E = s.fr_E + (size_t)3 * N * N * k;
+                A1.initT = s.initT; A1.PQT = s.PQT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.c = s.c; A1.dt = dt[k];
+                A1.E = s.fr_E + (size_t)NF * N * N * k;
                 A1.stream_E = 1;
-                k_or_pass1<N, P><<<dim3(N / 4, 1, 1), dim3(NT1), LB1, st>>>(A1);
+                if (PACKED) k_or_pass1_packed<N, P><<<dim3(N / 4, 1, 1), dim3(NT1), LB1, st>>>(A1);
+                else k_or_pass1<N, P><<<dim3(N / 4, 1, 1), dim3(NT1), LB1, st>>>(A1);
                 std::swap(s.phaseT, s.phaseT2);
             }
             if (ev) hipEventRecord(ev[1 + 3 * j], st);
@@ -573,14 +698,15 @@ static inline mw_status or_generate_steps(OrState& s, const float* delta_time, i
     A2.height_g = s.want_imag ? s.fr_height_g : nullptr;
     A2.disp_a = s.want_imag ? s.fr_disp_a : nullptr;
     hipError_t e = hipSuccess;
+    const bool packed = or_use_packed(s);
     switch (s.M) {
-        case 64: e = or_launch_steps<64>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 128: e = or_launch_steps<128>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 256: e = or_launch_steps<256>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 512: e = or_launch_steps<512>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 1024: e = or_launch_steps<1024>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 2048: e = or_launch_steps<2048>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 4096: e = or_launch_steps<4096>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 64: e = packed ? or_launch_steps<64, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<64, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 128: e = packed ? or_launch_steps<128, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<128, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 256: e = packed ? or_launch_steps<256, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<256, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 512: e = packed ? or_launch_steps<512, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<512, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 1024: e = packed ? or_launch_steps<1024, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<1024, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 2048: e = packed ? or_launch_steps<2048, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<2048, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 4096: e = packed ? or_launch_steps<4096, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<4096, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
         default: g_or_err = "OceanRenderer: unsupported texture size"; return MW_EINVAL;
     }
     if (e != hipSuccess) { g_or_err = std::string("OceanRenderer steps launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
@@ -599,6 +725,7 @@ static inline mw_status or_generate_steps_rgba(OrState& s, const float* delta_ti
                                                hipStream_t st) {
     s.want_imag = true;
     mw_status r = or_generate_steps(s, delta_time, n, nullptr, nullptr, nullptr, nullptr, st);
+    s.want_imag = false;
     if (r != MW_OK) return r;
     const size_t MM = (size_t)s.M * s.M;
     k_or_pack_rgba<<<dim3((unsigned)((MM + 255) / 256), n), dim3(256), 0, st>>>(s.M, s.fr_height, s.fr_height_g, s.fr_disp, s.fr_disp_g, s.fr_disp_a,

@@ -88,6 +88,7 @@ MW_HD float or_phase_advance(const OrConsts& c, int px, int py, float old_phase,
 
 // ---------------------------------------------------------------------------------------------------------
 struct OrP1Args {
+    const f4* PQT;    // [px][py] (P, Q): the Hermitian parts of (h0, conj h0'), packed plan only (or_prep_element)
     const f4* initT;  // [px][py] (h0, conj h0')
     const float* omT;       // [px][py] or_omega table
     const float* phase_in;  // [px][py] stateful phase of the previous frame
@@ -230,6 +231,121 @@ MW_HD void or_p1_build(const OrP1Args& A, int jb, int tid, int f, const cf (&h)[
         x[q] = mk(smul(h[q].y, g), smul(-h[q].x, g));
     }
 }
+// ---- the packed plan: TWO complex transforms per frame instead of three --------------------------------------------------------------
+// A consumer of the planar textures needs four real planes: height.r = Re F(h), displacement.r / .g = Re / Im F(hx) (OceanNormal's
+// `center = D.rgb` reads the imaginary part of Dx, F/OceanNormal.shader:44) and displacement.b = Re F(hz).  Re F(A) is the transform of
+// the Hermitian part A_h[p] = (A[p] + conj A[m(p)]) / 2, m(p) = (M - p) mod M per axis, so the two real-part-only fields share ONE transform:
+//     G = h_h + i (hz)_h        F(G) = Re F(h) + i Re F(hz)
+// With the phase texture symmetric under m (it starts at 0 and omega(m(p)) == omega(p) bit for bit, so every frame keeps it so; a
+// phase injected with mw_ocean_set_phase is checked), h_h = P e^{i phi} + Q e^{-i phi} with P = (h0 + conj h0'[m]) / 2, Q = (h0' + conj
+// h0[m]) / 2 fixed per spectrum (or_prep_element; the FFTMesh path's (P, Q) packing), and hz = -i g_z h with
+// g_z = chop kz / |k| odd under m gives (hz)_h = -i g_z h_h -- except on the Nyquist row py = M/2, its own mirror, where g_z is EVEN and
+// (hz)_h = -i g_z (h - h_h).  Hence G = h_h + g_z (py == M/2 ? h - h_h : h_h); hx keeps its full transform.  The exchange buffer carries
+// 16 instead of 24 B per texel and frame in each direction and a third of the butterflies is gone.  The RGBA form (Im h, Im Dz are
+// channels of the reference's render targets) and a handle whose phase is not symmetric run the three-transform plan.
+MW_HD void or_prep_element(int M, int px, int py, const f4* initT, f4* PQT) {
+    const int mx = (M - px) % M, my = (M - py) % M;
+    const f4 a = initT[(size_t)px * M + py], b = initT[(size_t)mx * M + my];  // a = (h0, h0c) here, b = the same at the mirror texel
+    f4 o;
+    o.x = smul(0.5f, sadd(a.x, b.z)); o.y = smul(0.5f, ssub(a.y, b.w));       // P = (h0 + conj h0c[m]) / 2
+    o.z = smul(0.5f, sadd(a.z, b.x)); o.w = smul(0.5f, ssub(a.w, b.y));       // Q = (h0c + conj h0[m]) / 2
+    PQT[(size_t)px * M + py] = o;
+}
+// field 0: X = hx = -i h kx/w chop (as or_p1_build's f = 1);  field 1: G (above).  h = the animated spectrum, hh = its Hermitian part
+template <int N, int P>
+MW_HD void or_p1_build_packed(const OrP1Args& A, int jb, int tid, int f, const cf (&h)[P], const cf (&hh)[P], cf (&x)[P]) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int w = tid / T, u = tid % T, px = 4 * jb + w;
+    const float kx = or_wave(N, A.c.length, px);
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const int py = u + T * q;
+        const float kz = or_wave(N, A.c.length, py);
+        const float wl = fmaxf(0.0001f, sqrtf(kx * kx + kz * kz));  // F/Spectrum.shader:47
+        const float g = ((f == 0) ? kx : kz) / wl * A.c.choppiness;
+        if (f == 0) { x[q] = mk(smul(h[q].y, g), smul(-h[q].x, g)); continue; }
+        const bool nyq = (py == N / 2);
+        const float tx = nyq ? ssub(h[q].x, hh[q].x) : hh[q].x, ty = nyq ? ssub(h[q].y, hh[q].y) : hh[q].y;
+        x[q] = mk(sadd(hh[q].x, smul(g, tx)), sadd(hh[q].y, smul(g, ty)));
+    }
+}
+// h and its Hermitian part for the lone-frame / tile forms: the phase advance of or_p1_animate, then both animated spectra
+template <int N, int P, int CH_>
+MW_HD void or_p1_animate_packed(const OrP1Args& A, int jb, int tid, bool write_phase, bool want_h, bool want_hh, cf (&h)[P], cf (&hh)[P]) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int w = wave_uniform<(T % 64) == 0>(tid / T), u = tid % T, px = 4 * jb + w;
+    const size_t col = (size_t)px * N;
+    const float* const c_om = A.omT + col;
+    const float* const c_pi = A.phase_in + col;
+    float* const c_po = A.phase_out + col;
+    const f4* const c_in = A.initT + col;
+    const f4* const c_pq = A.PQT + col;
+    const unsigned uo = (unsigned)u;
+    constexpr int CH = P < CH_ ? P : CH_;
+#pragma unroll
+    for (int q0 = 0; q0 < P; q0 += CH) {
+        float om[CH], pi[CH];
+        f4 v[CH], pq[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            om[k] = (c_om + T * (q0 + k))[uo];
+            pi[k] = (c_pi + T * (q0 + k))[uo];
+            // h itself: everywhere for X, on the Nyquist row (slot P/2 of the threads u == 0; loaded by every thread of that slot) for G
+            if (want_h || (q0 + k) == P / 2) v[k] = (c_in + T * (q0 + k))[uo];
+            if (want_hh) pq[k] = (c_pq + T * (q0 + k))[uo];
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const float ph = or_phase_step(om[k], pi[k], A.dt);
+            if (write_phase) (c_po + T * (q0 + k))[uo] = ph;
+            float s, c;
+            mw_sincos(ph, &s, &c);
+            if (want_h || (q0 + k) == P / 2) h[q0 + k] = animate(v[k].x, v[k].y, v[k].z, v[k].w, c, s);
+            if (want_hh) hh[q0 + k] = animate(pq[k].x, pq[k].y, pq[k].z, pq[k].w, c, s);
+        }
+    }
+}
+// The steps kernel of the packed plan runs ONE field per workgroup (blockIdx.y): field 0 keeps (h0, h0c) of its points in registers, field 1
+// (P, Q) and, for the Nyquist row, (h0, h0c) of slot P/2 -- both coefficient sets in one workgroup took it to 160 registers and three waves per SIMD
+// (spectrum kernel 198 -> 230 us per 32 frames with a third less to transform).  a = the field's own animated spectrum (h for field 0, its
+// Hermitian part for field 1), hn = h at slot P/2 (field 1); the arithmetic per element is or_p1_build_packed's.
+template <int N, int P>
+MW_HD void or_p1_steps_coeff(const OrP1Args& A, int jb, int tid, int f, f4 (&c)[P], f4& vn) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int w = wave_uniform<(T % 64) == 0>(tid / T), u = tid % T, px = 4 * jb + w;
+    const f4* const c_c = (f == 0 ? A.initT : A.PQT) + (size_t)px * N;
+    const unsigned uo = (unsigned)u;
+#pragma unroll
+    for (int q = 0; q < P; q++) c[q] = (c_c + T * q)[uo];
+    vn = (A.initT + (size_t)px * N + T * (P / 2))[uo];
+}
+template <int N, int P>
+MW_HD void or_p1_steps_build_split(const OrP1Args& A, int jb, int tid, int f, const f4 (&c)[P], const f4& vn, const float (&ph)[P], cf (&x)[P]) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int w = tid / T, u = tid % T, px = 4 * jb + w;
+    const float kx = or_wave(N, A.c.length, px);
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        float sn, cs;
+        mw_sincos(ph[q], &sn, &cs);
+        const cf a = animate(c[q].x, c[q].y, c[q].z, c[q].w, cs, sn);
+        const int py = u + T * q;
+        const float kz = or_wave(N, A.c.length, py);
+        const float wl = fmaxf(0.0001f, sqrtf(kx * kx + kz * kz));
+        const float g = ((f == 0) ? kx : kz) / wl * A.c.choppiness;
+        if (f == 0) { x[q] = mk(smul(a.y, g), smul(-a.x, g)); continue; }
+        float tx = a.x, ty = a.y;
+        if (q == P / 2) {  // only slot P/2 can hold the Nyquist row (py = N/2 <=> u = 0): h there, from its own coefficients
+            const cf hn = animate(vn.x, vn.y, vn.z, vn.w, cs, sn);
+            const bool nyq = (py == N / 2);
+            tx = nyq ? ssub(hn.x, a.x) : a.x;
+            ty = nyq ? ssub(hn.y, a.y) : a.y;
+        }
+        x[q] = mk(sadd(a.x, smul(g, tx)), sadd(a.y, smul(g, ty)));
+    }
+}
+
+// f = the field's plane in the exchange buffer (three planes per frame, two in the packed plan: the caller advances A.E per frame)
 template <int N, int P>
 MW_HD void or_p1_finish(const OrP1Args& A, const Twiddles& tw, int jb, int tid, int f, cf (&x)[P], const cf* lds) {
     constexpr int T = FftGeom<N, P>::T;
@@ -269,7 +385,7 @@ struct OrP2Geom {
 };
 MW_HD int or_p2_field(int k) { return k == 0 ? 1 : (k == 1 ? 2 : 0); }  // hx, hz, h
 template <int N, int P>
-MW_HD void or_p2_load(const OrP2Args& A, int ab, int tid, int f, cf (&x)[P], cf* lds) {
+MW_HD void or_p2_load(const OrP2Args& A, int ab, int tid, int f, cf (&x)[P], cf* lds) {  // f = plane of the exchange buffer
     constexpr int T = FftGeom<N, P>::T;
     const int r1 = tid & 3, u1 = tid >> 2, row = ab * 4 + r1;
     const cf* Ef = A.E + (size_t)f * N * N;
@@ -300,6 +416,7 @@ MW_HD void or_p2_finish(const OrP2Args& A, const Twiddles& tw, int ab, int tid, 
     for (int q = 0; q < P; q++) {
         if (f == 1) { dx[q] = x[q].x; (r_dg + T * q)[uo] = x[q].y; }
         else if (f == 2) { (r_d + T * q)[uo] = mk(dx[q], x[q].x); if (r_da) (r_da + T * q)[uo] = x[q].y; }
+        else if (f == 3) { (r_d + T * q)[uo] = mk(dx[q], x[q].y); (r_h + T * q)[uo] = x[q].x; }  // packed plan: F(G) = height + i Dz
         else { (r_h + T * q)[uo] = x[q].x; if (r_hg) (r_hg + T * q)[uo] = x[q].y; }
     }
 }

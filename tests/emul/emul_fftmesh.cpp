@@ -295,16 +295,23 @@ int fft1d_np(const float* in_xy, float* out_xy) {
 }
 
 // ---- OceanRenderer semantics: one GenerateTexture() stepped through the kernels' phase functions ----------
+// packed: the two-transform plan of planar-texture calls (k_or_pass1_packed / k_or_pass2_packed: height + i Dz from ONE transform)
 template <int N, int P>
 int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, float* height, cf* disp, float* disp_g,
-               float* normal, float* white, float* height_g, float* disp_a) {
+               float* normal, float* white, float* height_g, float* disp_a, bool packed) {
     constexpr int T = FftGeom<N, P>::T;
     Tables tb(N, P, -1);
     const Twiddles tw = TwGeom<N, P>::view(tb.TW.data());
     std::vector<cf> E((size_t)3 * N * N);
+    std::vector<f4> PQT((size_t)N * N);
+    if (packed)
+        for (int px = 0; px < N; px++)
+            for (int py = 0; py < N; py++) or_prep_element(N, px, py, initT, PQT.data());
+    const int nf = packed ? 2 : 3;
     {
         OrP1Args A;
         A.stream_E = 0;
+        A.PQT = PQT.data();
         std::vector<float> phase_next((size_t)N * N), om((size_t)N * N);
         for (int px = 0; px < N; px++)
             for (int py = 0; py < N; py++) om[(size_t)px * N + py] = or_omega(C, px, py);
@@ -312,13 +319,17 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
         A.initT = initT; A.phase_in = phaseT; A.phase_out = phase_next.data(); A.TW = tb.TW.data(); A.E = E.data(); A.c = C; A.dt = dt;
         constexpr int NT = OrP1Geom<N, P>::NTHREADS, BS = OrP1Geom<N, P>::BUFSTRIDE;
         std::vector<cf> lds(P1Geom<N, P>::CW * BS);
-        struct St { cf h[P]; cf x[P]; };
+        struct St { cf h[P]; cf hh[P]; cf x[P]; };
         std::vector<St> st(NT);
         for (int jb = 0; jb < N / 4; jb++)
-            for (int f = 0; f < 3; f++) {  // grid (N/4, 3): one field per block
-                for (int tid = 0; tid < NT; tid++) or_p1_animate<N, P, 8>(A, jb, tid, f == 0, st[tid].h);
+            for (int f = 0; f < nf; f++) {  // grid (N/4, 3 | 2): one field per block
                 for (int tid = 0; tid < NT; tid++) {
-                    or_p1_build<N, P>(A, jb, tid, f, st[tid].h, st[tid].x);
+                    if (packed) or_p1_animate_packed<N, P, 8>(A, jb, tid, f == 0, f == 0, f == 1, st[tid].h, st[tid].hh);
+                    else or_p1_animate<N, P, 8>(A, jb, tid, f == 0, st[tid].h);
+                }
+                for (int tid = 0; tid < NT; tid++) {
+                    if (packed) or_p1_build_packed<N, P>(A, jb, tid, f, st[tid].h, st[tid].hh, st[tid].x);
+                    else or_p1_build<N, P>(A, jb, tid, f, st[tid].h, st[tid].x);
                     stage0_store<N, P, -1>(st[tid].x, tid % T, lds.data() + (tid / T) * BS);
                 }
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
@@ -338,9 +349,10 @@ int or_step_np(const OrConsts& C, float dt, const f4* initT, float* phaseT, floa
         struct St { cf x[P]; float dx[P]; };
         std::vector<St> st(NT);
         for (int ab = 0; ab < N / 4; ab++)
-            for (int k = 0; k < 3; k++) {
-                const int f = or_p2_field(k);
-                for (int tid = 0; tid < NT; tid++) or_p2_load<N, P>(A, ab, tid, f, st[tid].x, lds.data());
+            for (int k = 0; k < nf; k++) {
+                const int f = packed ? (k == 0 ? 1 : 3) : or_p2_field(k);            // what the finish stores
+                const int plane = packed ? k : f;                                     // where pass 1 put it
+                for (int tid = 0; tid < NT; tid++) or_p2_load<N, P>(A, ab, tid, plane, st[tid].x, lds.data());
                 for (int s = 1; s < FftGeom<N, P>::S; s++) {
                     constexpr bool EX = XLay<N, P>::EXACT;
                     constexpr int T2 = FftGeom<N, P>::T;
@@ -457,17 +469,17 @@ void emul_or_init(int M, float length, float wind_x, float wind_y, float amplitu
             or_init_element(M, length, wind_x, wind_y, amplitude / 10000.f, gravity, seed, px, py, reinterpret_cast<f4*>(initT), phaseT);
 }
 int emul_or_step(int M, float length, float gravity, float choppiness, float dt, const float* initT, float* phaseT,
-                 float* height, float* disp, float* disp_g, float* normal, float* white, float* height_g, float* disp_a) {
+                 float* height, float* disp, float* disp_g, float* normal, float* white, float* height_g, float* disp_a, int packed) {
     OrConsts C;
     C.M = M; C.length = length; C.gravity = gravity; C.choppiness = choppiness; C.normal_length = length;
     const f4* it = reinterpret_cast<const f4*>(initT);
     cf* d = reinterpret_cast<cf*>(disp);
     switch (M) {
-        case 64: return or_step_np<64, Plan<64>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a);
-        case 128: return or_step_np<128, Plan<128>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a);
-        case 256: return or_step_np<256, Plan<256>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a);
-        case 512: return or_step_np<512, Plan<512>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a);
-        case 1024: return or_step_np<1024, Plan<1024>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a);
+        case 64: return or_step_np<64, Plan<64>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a, packed != 0);
+        case 128: return or_step_np<128, Plan<128>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a, packed != 0);
+        case 256: return or_step_np<256, Plan<256>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a, packed != 0);
+        case 512: return or_step_np<512, Plan<512>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a, packed != 0);
+        case 1024: return or_step_np<1024, Plan<1024>::P>(C, dt, it, phaseT, height, d, disp_g, normal, white, height_g, disp_a, packed != 0);
         default: return 1;
     }
 }

@@ -95,8 +95,10 @@ class Emul:
                             C.c_float(rp.gravity), C.c_uint64(seed), _p(initT), _p(phaseT))
         return initT, phaseT
 
-    def or_step(self, rp, initT, phaseT, delta_time, imag=False):
-        """imag=True also returns heightTexture.g (Im h) and displacementTexture.a (Im Dz) as two extra arrays."""
+    def or_step(self, rp, initT, phaseT, delta_time, imag=False, packed=False):
+        """imag=True also returns heightTexture.g (Im h) and displacementTexture.a (Im Dz) as two extra arrays.
+        packed=True: the two-transform plan of planar-texture calls (needs a mirror-symmetric phase; not with imag)."""
+        assert not (imag and packed)
         M = rp.M
         hg = np.empty((M, M), np.float32) if imag else None
         da = np.empty((M, M), np.float32) if imag else None
@@ -108,7 +110,7 @@ class Emul:
         dt = np.float32(delta_time) * np.float32(rp.mult)
         r = self.L.emul_or_step(M, C.c_float(rp.length), C.c_float(rp.gravity), C.c_float(rp.choppiness), C.c_float(dt),
                                 _p(initT), _p(phaseT), _p(h), _p(d), _p(g), _p(n), _p(w),
-                                _p(hg) if imag else None, _p(da) if imag else None)
+                                _p(hg) if imag else None, _p(da) if imag else None, 1 if packed else 0)
         assert r == 0
         return (h, d, n, w, g, hg, da) if imag else (h, d, n, w, g)
 

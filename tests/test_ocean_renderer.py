@@ -14,6 +14,16 @@ def shipped(resolution=8):
                           choppiness=0.46, gravity=9.81, mult=1.5)
 
 
+@pytest.fixture(params=["packed", "three"])
+def or_plan(request):
+    """The two plans of a planar-texture call: two transforms per frame (height + i Dz share one; csrc/ocean_renderer_kernels.h, "the packed
+    plan") -- the default wherever the phase texture is mirror-symmetric -- and the shaders' three (switch MW_OR_PACKED = 0)."""
+    import mistral_water
+    mistral_water.set_switch("MW_OR_PACKED", 1 if request.param == "packed" else 0)
+    yield request.param
+    mistral_water.set_switch("MW_OR_PACKED", 1)
+
+
 def tol_check(got, want, rel, name):
     sc = max(float(np.abs(want).max()), 1e-6)
     err = float(np.abs(got - want).max())
@@ -74,7 +84,10 @@ def test_phase_is_stateful_and_wrapped(oracle):
 
 
 @pytest.mark.parametrize("resolution", [8, 16, 32])
-def test_emulated_kernels_vs_oracle(emul, oracle, resolution):
+@pytest.mark.parametrize("packed", [False, True], ids=["three_transforms", "packed"])
+def test_emulated_kernels_vs_oracle(emul, oracle, resolution, packed):
+    """The kernels' phase functions stepped on the host, both plans of a planar-texture frame: the shaders' three transforms, and the packed
+    two (height + i Dz from one transform of the Hermitian parts; csrc/ocean_renderer_kernels.h)."""
     rp = shipped(resolution)
     M = rp.M
     init4 = oracle.renderer_initial_spectrum(rp, 5)
@@ -84,7 +97,7 @@ def test_emulated_kernels_vs_oracle(emul, oracle, resolution):
     initT = np.ascontiguousarray(init4.transpose(1, 0, 2))              # then inject identical spectra
     ph = np.zeros((M, M), np.float32)
     for frame, dt in enumerate((0.016, 0.033, 0.3, 25.0)):     # 25 s: phase steps beyond 4 pi (library fmod path)
-        h, d, n, w, g = emul.or_step(rp, initT, phaseT, dt)
+        h, d, n, w, g = emul.or_step(rp, initT, phaseT, dt, packed=packed)
         H, D, Nn, W, G = oracle.renderer_step_f64(rp, init4, ph, dt, literal_passes=(M <= 128))
         assert (phaseT.T == ph).all(), "stateful f32 phase must match bit for bit"
         tol_check(h, H, 3e-6, "height"); tol_check(d, D, 3e-6, "disp"); tol_check(g, G, 3e-6, "disp.g")
@@ -183,7 +196,7 @@ def test_gpu_rgba_textures_and_mesh_vertex_stage(mw, oracle, resolution):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("resolution", [8, 32, 128, 256, 512])
-def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
+def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution, or_plan):
     """BASELINE's shipped OceanRenderer configuration (1024^2 textures at resolution 128), smaller ones, the Inspector
     default resolution 256 (2048^2) and the largest supported texture (4096^2, P = 16 kernels)."""
     rp = shipped(resolution)
@@ -214,7 +227,7 @@ def test_gpu_generate_texture_vs_oracle(mw, oracle, resolution):
 
 
 @pytest.mark.gpu
-def test_gpu_generate_texture_edge_time_steps(mw, oracle):
+def test_gpu_generate_texture_edge_time_steps(mw, oracle, or_plan):
     """deltaTime corners of GenerateTexture() (S/OceanRenderer.cs:216-223; F/FFTCommon.cginc:101-104, the stateful fmod phase): a frame with
     deltaTime = 0 (a paused game: the phase must not move, the textures repeat), a negative step (time scale < 0: fmod of a negative
     argument keeps its sign in HLSL and in C), a step of ten minutes (omega dt ~ 1e4 rad before the fmod), and mult = 0 (the Inspector's
@@ -252,7 +265,7 @@ def _frame_dts(n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("resolution,nframes", [(8, 5), (32, 32), (128, 1), (128, 7), (128, 32), (256, 6), (512, 3)])
-def test_gpu_generate_texture_steps_equal_single_calls(mw, oracle, resolution, nframes):
+def test_gpu_generate_texture_steps_equal_single_calls(mw, oracle, resolution, nframes, or_plan):
     """mw_ocean_generate_texture_steps_device: n consecutive GenerateTexture() calls in one enqueue (S/OceanRenderer.cs:216-307 per
     frame; the phase chain of F/Dispersion.shader:32-41 / F/FFTCommon.cginc:101-104 walked in registers) must be, bit for bit, n
     single calls -- every texture of every frame and the phase texture after the last one -- at the shipped 1024^2 configuration
@@ -336,6 +349,78 @@ def test_gpu_generate_texture_steps_destinations_rgba_and_errors(mw):
         with pytest.raises(mw.MistralWaterError) as e:
             f.generate_texture_steps_device(_frame_dts(2))
         assert e.value.status == mw.MW_ESTATE
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resolution", [8, 128])
+def test_gpu_packed_plan_against_the_three_transform_plan(mw, oracle, resolution):
+    """Round 6: a planar-texture call runs TWO complex transforms per frame -- F(G) = height + i Dz with G built from the Hermitian parts
+    (P, Q) of the initial spectrum; hx keeps its own -- where the shaders run three (F/Spectrum.shader:47-50, S/OceanRenderer.cs:229-262).
+    (a) Both plans agree to float32 transform accuracy and (b) sit inside the oracle's bounds (also through the Nyquist row py = M/2, where
+    the odd multiplier is even: a single-bin spectrum there); (c) the identity needs a mirror-symmetric phase texture: a phase injected
+    with mw_ocean_set_phase that is NOT symmetric silently selects the three-transform plan -- bit for bit the result with the switch off --
+    and the library's own phase (get_phase -> set_phase) keeps the packed one; (d) the RGBA form always runs three."""
+    rp = shipped(resolution)
+    M = rp.M
+    kw = dict(resolution=resolution, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude, choppiness=rp.choppiness,
+              gravity=rp.gravity, mult=rp.mult, seed=5, semantics=mw.MW_SEM_OCEANRENDERER)
+    rng = np.random.default_rng(3)
+
+    def frames(o, dts):
+        return [o.generate_texture(dt) for dt in dts]
+    dts = (0.016, 0.3, 0.033)
+    try:
+        with mw.Ocean(**kw) as a, mw.Ocean(**kw) as b:
+            init4 = np.concatenate(a.get_spectrum(), -1)
+            mw.set_switch("MW_OR_PACKED", 1); fa = frames(a, dts)
+            mw.set_switch("MW_OR_PACKED", 0); fb = frames(b, dts)
+            assert (a.get_phase() == b.get_phase()).all()
+            ph = np.zeros((M, M), np.float32)
+            for k, dt in enumerate(dts):
+                H, D, Nn, W, G = oracle.renderer_step_f64(rp, init4, ph, dt, literal_passes=False)
+                for f in (fa[k], fb[k]):
+                    tol_check(f[0], H, 3e-6, "height"); tol_check(f[1], D, 3e-6, "disp")
+                    or_bounds.assert_normal_white(f[2], f[3], Nn, W, rp.length, D[..., 0], G, D[..., 1], H, tag=f"M={M} frame {k}")
+                sc = max(np.abs(H).max(), np.abs(D).max())
+                assert np.abs(fa[k][0] - fb[k][0]).max() < 2e-6 * sc and np.abs(fa[k][1] - fb[k][1]).max() < 2e-6 * sc
+                assert not (fa[k][0] == fb[k][0]).all()                       # the plans really differ (last bits)
+            # single bins on the Nyquist row / column and their neighbours: the even-multiplier special case of G
+            for (py, px) in ((M // 2, 3), (M // 2, M // 2), (M // 2 - 1, 5), (7, M // 2), (M // 2, 0), (0, M // 2)):
+                h0 = np.zeros((M, M, 2), np.float32); h0c = np.zeros((M, M, 2), np.float32)
+                h0[py, px] = (0.7, -0.2); h0c[(M - py) % M, px] = (0.1, 0.4); h0c[py, (M - px) % M] = (-0.3, 0.25)
+                i4 = np.concatenate([h0, h0c], -1)
+                mw.set_switch("MW_OR_PACKED", 1)
+                a.set_spectrum(h0, h0c)
+                h, d, n, w = a.generate_texture(0.21)
+                ph = np.zeros((M, M), np.float32)
+                H, D, Nn, W, G = oracle.renderer_step_f64(rp, i4, ph, 0.21, literal_passes=False)
+                tol_check(h, H, 3e-6, f"height bin {py},{px}"); tol_check(d, D, 3e-6, f"disp bin {py},{px}")
+            # (c) an asymmetric phase: the three-transform plan whatever the switch says
+            a.set_spectrum(init4[..., :2], init4[..., 2:]); b.set_spectrum(init4[..., :2], init4[..., 2:])
+            bad = rng.uniform(0, 6.2, (M, M)).astype(np.float32)
+            mw.set_switch("MW_OR_PACKED", 1); a.set_phase(bad); ga = a.generate_texture(0.05)
+            mw.set_switch("MW_OR_PACKED", 0); b.set_phase(bad); gb = b.generate_texture(0.05)
+            assert all((x == y).all() for x, y in zip(ga, gb))
+            ph = bad.copy()
+            H, D, Nn, W, G = oracle.renderer_step_f64(rp, init4, ph, 0.05, literal_passes=False)
+            tol_check(ga[0], H, 3e-6, "height, injected phase"); tol_check(ga[1], D, 3e-6, "disp, injected phase")
+            assert (a.get_phase() == ph).all()
+            # ... and the library's own phase texture, saved and restored, is symmetric: the packed plan again (its bits, not the other plan's)
+            mw.set_switch("MW_OR_PACKED", 1)
+            a.set_spectrum(init4[..., :2], init4[..., 2:]); b.set_spectrum(init4[..., :2], init4[..., 2:])
+            a.generate_texture(0.4); b.generate_texture(0.4)
+            saved = a.get_phase()
+            assert (saved == saved[(-np.arange(M)) % M][:, (-np.arange(M)) % M]).all()
+            a.set_phase(saved)
+            ra, rb = a.generate_texture(0.02), b.generate_texture(0.02)
+            assert all((x == y).all() for x, y in zip(ra, rb))
+            # (d) the RGBA targets carry Im h and Im Dz: three transforms, and the planar call after it is packed again
+            ta = a.generate_texture_rgba(0.02)
+            mw.set_switch("MW_OR_PACKED", 0)
+            tb = b.generate_texture_rgba(0.02)
+            assert all((x == y).all() for x, y in zip(ta, tb))
+    finally:
+        mw.set_switch("MW_OR_PACKED", 1)
 
 
 @pytest.mark.gpu
