@@ -102,6 +102,9 @@ __global__ void k_or_prep(int M, const f4* initT, f4* PQT) {
     const size_t toff = (size_t)blockIdx.y * M * M;  // tile blockIdx.y
     or_prep_element(M, idx / M, idx % M, initT + toff, PQT + toff);
 }
+#ifndef MW_OR_PACKED_MAX_M
+#define MW_OR_PACKED_MAX_M 4096  // textures from this size up keep the three-transform plan
+#endif
 #ifndef MW_OR_PACKED
 #define MW_OR_PACKED 1  // planar-texture calls with a mirror-symmetric phase run two transforms per frame (0: always three)
 #endif
@@ -411,7 +414,11 @@ static inline mw_status or_create(OrState& s, const mw_params& p, int M, hipStre
     return MW_OK;
 }
 // the planar-texture plan of a call: two transforms per frame where the identity holds (or_prep_element), else the shaders' three
-static inline bool or_use_packed(const OrState& s) { return MW_OR_PACKED != 0 && sw(SW_OR_PACKED) != 0 && !s.want_imag && s.phase_sym; }
+// (4096^2 textures keep three: their 1024-thread P = 16 workgroups have 128 registers per lane, and two animated spectra at once spill --
+// one GenerateTexture() 545 -> 637 us; 2048^2: 127 -> 110 us, 4 / 8 tiles per call 24.0 / 25.1 -> 24.3 / 23.3 us per tile-frame)
+static inline bool or_use_packed(const OrState& s) {
+    return MW_OR_PACKED != 0 && sw(SW_OR_PACKED) != 0 && !s.want_imag && s.phase_sym && s.M < MW_OR_PACKED_MAX_M;
+}
 
 // RenderInitial() after a parameter change (S/OceanRenderer.cs:98-109): initialTexture again from the new length / wind /
 // amplitude, dispersion and spectrum passes on the new length (:94-97); the phase textures and the normal pass's length stay
@@ -466,7 +473,7 @@ static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st, hipEven
     A2.E = s.E; A2.TW = s.TW; A2.height = s.out_height; A2.disp = s.out_disp_cf; A2.disp_g = s.out_disp_g; A2.c = s.c;
     A2.height_g = s.want_imag ? s.out_height_g : nullptr;
     A2.disp_a = s.want_imag ? s.out_disp_a : nullptr;
-    if (packed) {
+    if constexpr (N < MW_OR_PACKED_MAX_M) if (packed) {
         static AttrOnce attr1p, attr2p;
         hipError_t e = attr1p.set(reinterpret_cast<const void*>(&k_or_pass1_packed<N, P>), LB1);
         if (e != hipSuccess) return e;
@@ -602,8 +609,9 @@ static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2
     constexpr bool KEEP = (PACKED ? MW_OR_STEPS_KEEP_PACKED : MW_OR_STEPS_KEEP) != 0 && P <= 8;  // P = 16: no registers to spare
     static AttrOnce attr1, attr2;
     {
-        hipError_t e = PACKED ? attr2.set(reinterpret_cast<const void*>(&k_or_pass2_packed<N, P>), OrP2Geom<N, P>::LDS_BYTES)
-                              : attr2.set(reinterpret_cast<const void*>(&k_or_pass2<N, P>), OrP2Geom<N, P>::LDS_BYTES);
+        hipError_t e;
+        if constexpr (PACKED) e = attr2.set(reinterpret_cast<const void*>(&k_or_pass2_packed<N, P>), OrP2Geom<N, P>::LDS_BYTES);
+        else e = attr2.set(reinterpret_cast<const void*>(&k_or_pass2<N, P>), OrP2Geom<N, P>::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
     constexpr int NT1 = OrP1Geom<N, P>::NTHREADS, LB1 = OrP1Geom<N, P>::LDS_BYTES;
@@ -618,7 +626,7 @@ static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2
         B2.E += NF * off; B2.height += off; B2.disp += off; B2.disp_g += off;
         if (B2.height_g) B2.height_g += off;
         if (B2.disp_a) B2.disp_a += off;
-        if (PACKED) k_or_pass2_packed<N, P><<<dim3(N / 4, 1, cn), dim3(NT2), LB2, st>>>(B2);
+        if constexpr (PACKED) k_or_pass2_packed<N, P><<<dim3(N / 4, 1, cn), dim3(NT2), LB2, st>>>(B2);
         else k_or_pass2<N, P><<<dim3(N / 4, 2, cn), dim3(NT2), LB2, st>>>(B2);
         if (ev) hipEventRecord(ev[2 + 3 * j], st);
         k_or_normal_white<MW_OR_STEPS_NW_NT != 0><<<dim3(or_nw_blocks(MM), cn), dim3(256), 0, st>>>(s.c, B2.height, B2.disp, B2.disp_g, f_n + 3 * off, f_w + off);
@@ -649,8 +657,9 @@ static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2
         }
         std::swap(s.phaseT, s.phaseT2);
     } else {  // one bandwidth-bound spectrum launch per frame (each already fills the device)
-        hipError_t e = PACKED ? attr1.set(reinterpret_cast<const void*>(&k_or_pass1_packed<N, P>), LB1)
-                              : attr1.set(reinterpret_cast<const void*>(&k_or_pass1<N, P>), LB1);
+        hipError_t e;
+        if constexpr (PACKED) e = attr1.set(reinterpret_cast<const void*>(&k_or_pass1_packed<N, P>), LB1);
+        else e = attr1.set(reinterpret_cast<const void*>(&k_or_pass1<N, P>), LB1);
         if (e != hipSuccess) return e;
         for (int c0 = 0, j = 0; c0 < n; c0 += chunk, j++) {
             const int cn = (n - c0 < chunk) ? n - c0 : chunk;
@@ -659,7 +668,7 @@ static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2
                 A1.initT = s.initT; A1.PQT = s.PQT; A1.omT = s.omT; A1.phase_in = s.phaseT; A1.phase_out = s.phaseT2; A1.TW = s.TW; A1.c = s.c; A1.dt = dt[k];
                 A1.E = s.fr_E + (size_t)NF * N * N * k;
                 A1.stream_E = 1;
-                if (PACKED) k_or_pass1_packed<N, P><<<dim3(N / 4, 1, 1), dim3(NT1), LB1, st>>>(A1);
+                if constexpr (PACKED) k_or_pass1_packed<N, P><<<dim3(N / 4, 1, 1), dim3(NT1), LB1, st>>>(A1);
                 else k_or_pass1<N, P><<<dim3(N / 4, 1, 1), dim3(NT1), LB1, st>>>(A1);
                 std::swap(s.phaseT, s.phaseT2);
             }
@@ -668,6 +677,11 @@ static hipError_t or_launch_steps(OrState& s, const float* dt, int n, const OrP2
         }
     }
     return hipGetLastError();
+}
+template <int N>
+static hipError_t or_launch_steps_plan(bool packed, OrState& s, const float* dt, int n, const OrP2Args& A2, float* f_n, float* f_w, hipStream_t st, hipEvent_t* ev) {
+    if constexpr (N < MW_OR_PACKED_MAX_M) { if (packed) return or_launch_steps<N, true>(s, dt, n, A2, f_n, f_w, st, ev); }
+    return or_launch_steps<N, false>(s, dt, n, A2, f_n, f_w, st, ev);
 }
 // frames k = 0 .. n-1 advance the phase by delta_time[k] * mult one after the other, exactly as n calls of or_generate would; device
 // destinations are [n][M*M*...] (NULL: the frame stays in the handle's own frame buffers).  The handle's latest-frame textures
@@ -700,13 +714,13 @@ static inline mw_status or_generate_steps(OrState& s, const float* delta_time, i
     hipError_t e = hipSuccess;
     const bool packed = or_use_packed(s);
     switch (s.M) {
-        case 64: e = packed ? or_launch_steps<64, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<64, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 128: e = packed ? or_launch_steps<128, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<128, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 256: e = packed ? or_launch_steps<256, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<256, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 512: e = packed ? or_launch_steps<512, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<512, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 1024: e = packed ? or_launch_steps<1024, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<1024, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 2048: e = packed ? or_launch_steps<2048, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<2048, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
-        case 4096: e = packed ? or_launch_steps<4096, true>(s, dt, n, A2, f_n, f_w, st, ev) : or_launch_steps<4096, false>(s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 64: e = or_launch_steps_plan<64>(packed, s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 128: e = or_launch_steps_plan<128>(packed, s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 256: e = or_launch_steps_plan<256>(packed, s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 512: e = or_launch_steps_plan<512>(packed, s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 1024: e = or_launch_steps_plan<1024>(packed, s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 2048: e = or_launch_steps_plan<2048>(packed, s, dt, n, A2, f_n, f_w, st, ev); break;
+        case 4096: e = or_launch_steps_plan<4096>(packed, s, dt, n, A2, f_n, f_w, st, ev); break;
         default: g_or_err = "OceanRenderer: unsupported texture size"; return MW_EINVAL;
     }
     if (e != hipSuccess) { g_or_err = std::string("OceanRenderer steps launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
