@@ -952,6 +952,23 @@ def direct(a, e):
             fused_small = "rows_assemble" in kern[1][0]       # N <= 128: the second axis runs inside the assembly launch
             k_czt_s = (kern[0][1] + (kern[1][1] if fused_small else 0.0)) * 1e-3
             binding = max((b_valu, "valu"), (b_lds, "lds"), (b_hbm, "hbm"))
+            # What the counters say (round 6): k_czt issues ~2280 VALU instructions per wave at either size -- index
+            # arithmetic, table reads and the zero half of the M = 2N padding included -- which is 4 issue cycles each on a SIMD: the INSTRUCTION
+            # count, not the flop count and not the LDS, is the floor (bank conflicts 0, LDS waits 1-2 % of wave cycles, 44-46 % waiting in all).
+            issue = None
+            try:
+                jp = json.load(open(os.path.join(REPO, "profiles", f"{PROFILE_ROUND}_direct{N}_b1_pmc.json")))
+                if (jp.get("bench_line") or {}).get("build_id") == nat.build_id():
+                    kz = [v for k, v in jp["pmc_mean_per_launch"].items() if "k_czt<" in k][0]
+                    per_launch_s = kz["SQ_INSTS_VALU"] * 4.0 / (256 * 4) / 2.4e9        # wave-instructions x 4 cycles over 1024 SIMDs at 2.4 GHz
+                    issue = {"valu_instructions_per_wave": kz["SQ_INSTS_VALU"] / kz["SQ_WAVES"], "waves_per_launch": kz["SQ_WAVES"],
+                             "issue_bound_us": 2 * per_launch_s * 1e6,
+                             "wait_any_over_wave_cycles": kz["SQ_WAIT_ANY"] / kz["SQ_WAVE_CYCLES"],
+                             "lds_wait_over_wave_cycles": kz["SQ_WAIT_INST_LDS"] / kz["SQ_WAVE_CYCLES"],
+                             "lds_bank_conflict_cycles": kz["SQ_LDS_BANK_CONFLICT"],
+                             "source": f"profiles/{PROFILE_ROUND}_direct{N}_b1_pmc.json (same build)"}
+            except Exception:
+                pass
             roof["transform_bounds"] = {
                 "transform_size": M, "points_per_thread": Pz, "lds_exchanges_per_transform": n_exch, "lines_per_step": lines,
                 "flop_per_step": lines * flop_line, "lds_bytes_per_step": lines * lds_line,
@@ -959,6 +976,8 @@ def direct(a, e):
                 "valu_peak_TFLOPs": valu_peak / 1e12, "lds_peak_TBps": lds_peak / 1e12,
                 "binding": binding[1], "k_czt_us": k_czt_s * 1e6,
                 "k_czt_frac_of_binding_bound": binding[0] / k_czt_s, "step_frac_of_binding_bound": binding[0] / (step_ms * 1e-3),
+                "instruction_issue": issue,
+                "k_czt_frac_of_issue_bound": (issue["issue_bound_us"] * 1e-6 / k_czt_s) if issue else None,
                 "achieved_TFLOPs": lines * flop_line / k_czt_s / 1e12, "achieved_lds_TBps": lines * lds_line / k_czt_s / 1e12,
                 "note": "lower bounds of one step from its transform work: flop at the f32 vector peak (every op priced as if fused), LDS bytes "
                         "(exchanges + table twiddles) at the aggregate LDS rate, 92 B per point at the HBM peak.  The achieved fractions say how "
