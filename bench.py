@@ -1103,9 +1103,9 @@ def renderer(a, e, extra=False):
 
     # ---- in situ per-launch durations (HIP events on the launch stream between the launches of the same enqueue), rank 0 ----
     kstats = frame = None
-    if T == 1 and rank == 0:
+    if rank == 0:
         preheat(lambda: run([B]), torch, a.preheat_ms)
-        kstats = o.profile_kernels_stats(nsteps=B, iters=60 if B > 1 else 200)
+        kstats = o.profile_kernels_stats(nsteps=B if T == 1 else 1, iters=60 if B > 1 else 200)      # a batched handle: one call = T tile-frames
         if not a.no_latency and F > 1:      # what OceanRenderer.Update drives: one GenerateTexture() per call
             one = (o.handle, C.c_float(DT), None, None, None, None)
             for _ in range(50):
@@ -1142,8 +1142,8 @@ def renderer(a, e, extra=False):
         # HBM-side bytes of ONE ENQUEUE from the committed counter pass: a call per frame = its three launches; a steps call = one spectrum
         # launch + per chunk of OR_STEPS_CHUNK frames one pass-2 and one normal-pass launch + the copy of the last frame
         ktr = [None, None, None, None]
+        nch = -(-B // OR_STEPS_CHUNK)
         if T == 1 and B > 1:
-            nch = -(-B // OR_STEPS_CHUNK)
             parts = [pmc_traffic_ex("renderer1024", B, k, build_id) for k in ("k_or_pass1_steps", "k_or_pass2", "k_or_normal_white", "k_or_copy_frame")]
             if all(q["traffic"] is not None for q in parts):
                 ktr = [parts[0]["traffic"], nch * parts[1]["traffic"], nch * parts[2]["traffic"], parts[3]["traffic"]]
@@ -1151,20 +1151,33 @@ def renderer(a, e, extra=False):
             else:
                 traffic, traffic_note = None, next(q["note"] for q in parts if q["traffic"] is None)
         else:
-            traffic, traffic_note = pmc_traffic("renderer1024", B if T == 1 else T, "k_or_", build_id)     # the three kernels of one call
+            # the three kernels of one call (not k_or_init / k_or_omega / k_or_prep, which the counter file of the same process also holds)
+            parts = [pmc_traffic_ex("renderer1024", B if T == 1 else T, k, build_id) for k in ("k_or_pass1", "k_or_pass2", "k_or_normal_white")]
+            if all(q["traffic"] is not None for q in parts):
+                ktr = [q["traffic"] for q in parts] + [None]
+                traffic, traffic_note = sum(ktr[:3]), parts[0]["note"]
+            else:
+                traffic, traffic_note = None, next(q["note"] for q in parts if q["traffic"] is None)
         # per kernel, the bytes ITS PLAN must move per texel and frame.  Three-transform plan: pass 1 = exchange out 24 + (spectrum 16, omega 4, phase
         # in / out 8) once per enqueue; pass 2 = exchange in 24 + 16 out.  Packed plan (two transforms: height + i Dz share one; the default for
         # planar textures): exchange 16 each way; pass 1 reads (h0, h0c) or (P, Q) + omega + phase per field workgroup.  Normal / whitecap: 16 + 16.
         packed = (mw.get_switch("MW_OR_PACKED") != 0)
-        shares = ((16.0 + 52.0 / F, 32.0, 32.0) if packed else (24.0 + 28.0 / F, 40.0, 32.0))
+        # (packed pass 1 per enqueue: two field workgroups each read omega 4 + phase 4 + their coefficients 16, + (h0, h0c) of the Nyquist row, + the
+        # phase out 4 = 52; the tile form reads both coefficient sets in one workgroup: 44)
+        shares = ((16.0 + (44.0 if T > 1 else 52.0) / F, 32.0, 32.0) if packed else (24.0 + 28.0 / F, 40.0, 32.0))
         kernels, dom = None, None
+        UL = B if T == 1 else T         # texel-frames per launch, in units of one texture
+        # launches of each kernel per enqueue: a steps call runs pass 2 and the normal pass once per chunk of OR_STEPS_CHUNK frames
+        nl = [1, nch if (T == 1 and B > 1) else 1, nch if (T == 1 and B > 1) else 1, 1]
         if kstats:
-            kernels = [{"name": nm, "us_per_launch": st["mean"] * 1e3, "us_per_launch_median": st["median"] * 1e3, "us_per_launch_p10": st["p10"] * 1e3,
-                        "us_per_launch_p90": st["p90"] * 1e3,
+            kernels = [{"name": nm, "launches_per_enqueue": nl[i], "frames_per_launch": UL / nl[i],
+                        "us_per_enqueue": st["mean"] * 1e3, "us_per_launch": st["mean"] * 1e3 / nl[i],
+                        "us_per_launch_median": st["median"] * 1e3 / nl[i], "us_per_launch_p10": st["p10"] * 1e3 / nl[i],
+                        "us_per_launch_p90": st["p90"] * 1e3 / nl[i],
                         "algorithmic_bytes_per_texel_frame": (shares[i] if i < 3 else None),
-                        "physical_bytes_per_texel_frame": (ktr[i] / (MM * B)) if ktr[i] else None,
+                        "physical_bytes_per_texel_frame": (ktr[i] / (MM * UL)) if ktr[i] else None,
                         "physical_GBps": (ktr[i] / (st["mean"] * 1e-3) / 1e9) if ktr[i] else None,
-                        "frac": (shares[i] * MM * B / (st["mean"] * 1e-3) / HBM_PEAK) if i < 3 else None} for i, (nm, st) in enumerate(kstats)]
+                        "frac": (shares[i] * MM * UL / (st["mean"] * 1e-3) / HBM_PEAK) if i < 3 else None} for i, (nm, st) in enumerate(kstats)]
             dom = max(range(3), key=lambda i: kstats[i][1]["mean"])
         rpc = pcts(regions)
         roof = {"bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s", "traffic": traffic, "traffic_note": traffic_note,
@@ -1179,9 +1192,9 @@ def renderer(a, e, extra=False):
                 "kernels": kernels}
         if dom is not None:     # the contract's object: the dominant kernel's algorithmic bytes per launch / its mean launch duration
             k = kernels[dom]
-            roof.update({"kernel": k["name"], "achieved": shares[dom] * MM * B / (k["us_per_launch"] * 1e-6) / 1e9, "frac": k["frac"],
-                         "launch_us": k["us_per_launch"], "frames_per_launch": B, "algorithmic_bytes_per_texel_frame": shares[dom],
-                         "bytes_per_launch": shares[dom] * MM * B})
+            roof.update({"kernel": k["name"], "achieved": shares[dom] * MM * UL / (k["us_per_enqueue"] * 1e-6) / 1e9, "frac": k["frac"],
+                         "launch_us": k["us_per_launch"], "frames_per_launch": k["frames_per_launch"], "launches_per_enqueue": k["launches_per_enqueue"],
+                         "algorithmic_bytes_per_texel_frame": shares[dom], "bytes_per_launch": shares[dom] * MM * k["frames_per_launch"]})
         else:
             roof.update({"kernel": "whole frame (every kernel of a call)", "achieved": v / world * bytes_frame / 1e9, "frac": v / world * bytes_frame / HBM_PEAK})
         out = ({
