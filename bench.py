@@ -286,6 +286,43 @@ def cpu_baseline_ocean(p, h0, h0c, gpu_step, budget_s=12.0, quick=False):
     }
 
 
+class PhaseGuard:
+    """Watchdog around the phases that have never met a multi-GPU node (the RCCL gather, the strong-scaling sub-run): if one of them does
+    not come back in time, or fails on one rank while the others sit in its collectives, rank 0 still prints the ONE line -- the last object
+    handed to checkpoint(), with the phase named in it -- and the process leaves (every rank arms the same deadline, so the ranks left
+    behind are released by their own timer).  A hung or failed collective must not cost the driver its scaling curve."""
+
+    def __init__(self, rank, emit_fn, exit_fn=os._exit):
+        self.rank, self.emit, self.exit = rank, emit_fn, exit_fn
+        self.partial, self.timer = None, None
+
+    def checkpoint(self, obj):
+        self.partial = obj
+
+    def _leave(self, info):
+        if self.rank == 0 and self.partial is not None:
+            self.partial["aborted_phase"] = info
+            self.emit(self.partial)
+        self.exit(0 if self.partial is not None or self.rank != 0 else 3)
+
+    def arm(self, seconds, phase):
+        import threading
+        self.disarm()
+        self.timer = threading.Timer(seconds, lambda: self._leave({"phase": phase, "after_s": seconds,
+                                                                   "note": "did not return in time; the line carries everything measured before it"}))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def abandon(self, why):
+        self.disarm()
+        self._leave({"error": why, "note": "the line carries everything measured before the failing phase"})
+
+
 class Env:
     """What every workload needs from the process: torch, the package, the process group and this rank's device and stream."""
     pass
@@ -332,31 +369,8 @@ def setup(a):
     e.barrier = barrier
     e.hung = False
 
-    # Watchdog around the phases that have never met a multi-GPU node (the RCCL gather, the strong-scaling sub-run): if one of them does
-    # not come back in time, rank 0 still prints the ONE line -- the last object handed to checkpoint(), with the phase named in it -- and
-    # every rank leaves (all ranks arm the same deadline).  A hung collective must not cost the driver its scaling curve.
-    import threading
-    e._partial, e._timer = None, None
-
-    def checkpoint(obj):
-        e._partial = obj
-
-    def arm(seconds, phase):
-        def fire():
-            if e.rank == 0 and e._partial is not None:
-                e._partial["aborted_phase"] = {"phase": phase, "after_s": seconds, "note": "did not return in time; the line carries everything measured before it"}
-                emit(e._partial)
-            os._exit(0 if e._partial is not None or e.rank != 0 else 3)
-        disarm()
-        e._timer = threading.Timer(seconds, fire)
-        e._timer.daemon = True
-        e._timer.start()
-
-    def disarm():
-        if e._timer is not None:
-            e._timer.cancel()
-            e._timer = None
-    e.checkpoint, e.arm, e.disarm = checkpoint, arm, disarm
+    guard = PhaseGuard(e.rank, emit)
+    e.checkpoint, e.arm, e.disarm, e.abandon = guard.checkpoint, guard.arm, guard.disarm, guard.abandon
     return e
 
 
@@ -416,8 +430,8 @@ def main():
                 strong["config"] = {k: st["config"][k] for k in ("workload", "steps_per_enqueue", "enqueues_per_region", "tiles", "parallelism")}
                 strong["vs_tiles_value"] = st["value"] / out["value"] if e.rank == 0 else None
                 strong["what"] = "the same K steps of ONE ocean (seed 1), rank r runs the contiguous block [lo, hi): whole-job rate = K * N^2 / the slowest rank's time"
-            except Exception as ex:      # noqa: BLE001 -- reported in the line
-                strong = {"error": repr(ex)}
+            except Exception as ex:      # noqa: BLE001 -- the other ranks sit in the sub-run's barriers: print what exists and leave
+                e.abandon(f"strong: {ex!r}")
             e.disarm()
             if e.rank == 0:
                 out["strong"] = strong
@@ -783,10 +797,13 @@ def ocean(a, e, N, extra=False):
     if do_gather:
         e.checkpoint(dict(out, with_gather={"error": "the gather regions did not finish"}) if rank == 0 else None)
         e.arm(float(os.environ.get("MW_BENCH_PHASE_TIMEOUT", "240")), "with_gather (mw_tiles_gather regions)")
-        run(warm_sizes, 0, gather=True)
-        sync()
-        gather_regions = [wall_region(gather=True) for _ in range(R)]
-        el_gather = float(np.median(gather_regions))
+        try:
+            run(warm_sizes, 0, gather=True)
+            sync()
+            gather_regions = [wall_region(gather=True) for _ in range(R)]
+            el_gather = float(np.median(gather_regions))
+        except Exception as ex:      # noqa: BLE001
+            e.abandon(f"with_gather: {ex!r}")      # the other ranks sit in this phase's barriers: nobody can go on together
         e.disarm()
     # N > 1: what the communicator saw and what every rank did (the driver computes efficiency from `value`; these say WHY)
     rank_el = par.all_ranks(float(np.median(local_regions)), dist, red_dev)

@@ -89,3 +89,31 @@ def test_repeats_scale_to_a_minimum_of_timed_work():
     assert bench.scaled_repeats(1e-9, 5, 50.0) == 2000              # capped
     st = bench.pcts([5.0, 1.0, 3.0, 2.0, 4.0])
     assert (st["median"], st["min"], st["max"], st["n"]) == (3.0, 1.0, 5.0, 5) and st["p10"] <= st["median"] <= st["p90"]
+
+
+def test_phase_guard_prints_the_checkpointed_line_when_a_multi_gpu_phase_hangs_or_fails():
+    """The N > 1 line's optional phases (the RCCL gather regions, the strong-scaling sub-run) have never run on real multi-GPU hardware: a
+    hang or a failure there must still leave the driver ONE line with everything measured before it, from rank 0 only."""
+    import time
+    for rank in (0, 1):
+        printed, exits = [], []
+        g = bench.PhaseGuard(rank, printed.append, exits.append)
+        g.checkpoint({"value": 1.0, "with_gather": {"error": "the gather regions did not finish"}})
+        g.arm(0.05, "with_gather")
+        g.disarm()                                   # the phase came back: nothing happens
+        time.sleep(0.12)
+        assert not printed and not exits
+        g.arm(0.05, "with_gather")                   # the phase hangs
+        time.sleep(0.3)
+        assert exits == [0] and (len(printed) == 1) == (rank == 0)
+        if rank == 0:
+            assert printed[0]["value"] == 1.0 and printed[0]["aborted_phase"]["phase"] == "with_gather"
+        printed.clear(); exits.clear()
+        g.abandon("strong: RuntimeError('x')")       # the phase failed on this rank
+        assert exits == [0] and (len(printed) == 1) == (rank == 0)
+        if rank == 0:
+            assert "RuntimeError" in printed[0]["aborted_phase"]["error"]
+    g = bench.PhaseGuard(0, lambda o: None, exits.append)
+    exits.clear()
+    g.abandon("nothing measured yet")                # rank 0 without a line to print: a failure exit code
+    assert exits == [3]
