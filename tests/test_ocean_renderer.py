@@ -258,8 +258,9 @@ def test_gpu_generate_texture_edge_time_steps(mw, oracle, or_plan):
 
 
 def _frame_dts(n):
-    # an uneven frame clock (Time.deltaTime is never constant): a hitch, a paused frame and a negative step among ordinary ones
-    base = [0.016, 0.0171, 0.033, 0.0, 0.25, 0.0166, -0.02, 0.0169]
+    # an uneven frame clock (Time.deltaTime is never constant): a hitch, a paused frame, a negative step and a ten-minute jump (omega dt ~ 1e4
+    # rad: the library fmod path of the phase step, also inside the chain a later frame group re-walks) among ordinary ones
+    base = [0.016, 0.0171, 0.033, 0.0, 0.25, 600.0, -0.02, 0.0169]
     return np.array([base[k % len(base)] * (1.0 + 0.01 * (k // len(base))) for k in range(n)], np.float32)
 
 
