@@ -116,6 +116,16 @@ public class OceanRenderer : MonoBehaviour
         }
     }
 
+    // Not in the reference: deltaTimes.Length consecutive GenerateTexture() calls in ONE enqueue (a recorder, an offline bake, a server that
+    // produces frames ahead of display): frame k advances the phase by deltaTimes[k] * mult on top of frame k - 1, exactly as the per-frame
+    // calls would -- the results are bit-identical to them -- at about half the time per frame.  The ARGBFloat frames land in the caller's
+    // DEVICE buffers ([n][M*M*4] floats each; IntPtr.Zero skips a target); the component's own textures are not touched.
+    public void GenerateTexturesToDevice(float[] deltaTimes, IntPtr dHeight, IntPtr dDisplacement, IntPtr dNormal, IntPtr dWhite)
+    {
+        if (deltaTimes.Length > Native.mw_ocean_max_frames(ocean)) throw new ArgumentException("more frames than mw_ocean_max_frames");
+        Native.Check(Native.mw_ocean_generate_texture_steps_rgba_device(ocean, deltaTimes, deltaTimes.Length, dHeight, dDisplacement, dNormal, dWhite));
+    }
+
     void GenerateTexture()
     {
         Native.Check(Native.mw_ocean_generate_texture_rgba(ocean, Time.deltaTime, heightPixels, displacementPixels, normalPixels, whitePixels));

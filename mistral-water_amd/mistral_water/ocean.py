@@ -386,6 +386,13 @@ class OceanRenderer:
         h, d, n, w = self._ocean.generate_texture(deltaTime)
         self.heightTexture, self.displacementTexture, self.normalTexture, self.whiteTexture = h, d, n, w
 
+    def GenerateTextures(self, deltaTimes):
+        """Not in the reference: len(deltaTimes) consecutive GenerateTexture() calls in one enqueue (bit-identical to the per-frame calls);
+        returns the frames [n, M, M(, c)] and leaves the LAST one in the component's textures, as n calls of Update would."""
+        H, D, Nn, W = self._ocean.generate_texture_steps(deltaTimes)
+        self.heightTexture, self.displacementTexture, self.normalTexture, self.whiteTexture = H[-1], D[-1], Nn[-1], W[-1]
+        return H, D, Nn, W
+
     @property
     def ocean(self) -> Ocean:
         return self._ocean

@@ -436,6 +436,14 @@ def test_gpu_oceanrenderer_lifecycle(mw):
     r.Update(0.016)
     assert r.heightTexture.shape == (128, 128) and not np.array_equal(h1, r.heightTexture)
     assert np.isfinite(r.normalTexture).all() and (r.whiteTexture >= 0).all() and (r.whiteTexture <= 1).all()
+    q = mw.OceanRenderer()                 # the same component driven three frames at a time: the per-frame textures, bit for bit
+    q.resolution, q.length, q.amplitude, q.choppiness, q.mult = 16, 60.0, 0.41, 0.46, 1.5
+    q.wind = mw.Vector2(14.45, 12.0)
+    q.Awake()
+    H, D, Nn, W = q.GenerateTextures([0.016, 0.016, 0.02])
+    assert (H[1] == r.heightTexture).all() and (Nn[1] == r.normalTexture).all()
+    r.Update(0.02)
+    assert (q.heightTexture == r.heightTexture).all() and (q.whiteTexture == r.whiteTexture).all() and (H[2] == r.heightTexture).all()
     r.wind = mw.Vector2(3.0, 1.0)          # param change -> RenderInitial again (S/OceanRenderer.cs:98-109)
     r.Update(0.016)
     r.Update(0.016)
