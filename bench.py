@@ -1037,14 +1037,20 @@ def renderer(a, e, extra=False):
     T = max(1, a.tiles)
     F = 1 if T > 1 else max(1, min(a.batch, 32))
     kw = dict(resolution=128, length=434.48, wind=(14.45, 12.0), amplitude=0.41, choppiness=0.46, mult=1.5)
-    o = mw.Ocean(seed=1 + 64 * rank, semantics=mw.MW_SEM_OCEANRENDERER, device=dev.index, ntiles=T, **kw)
+    # N > 1: one independent ocean per rank (weak), or --shard steps: ONE ocean, rank r renders the contiguous block [lo, hi) of the K frames.
+    # In this semantics only the phase links the frames: a rank seeks to its block with the Dispersion pass alone (mw_ocean_advance_phase),
+    # renders it, and walks the phase on to frame K so that every region starts from the same state on every rank.
+    shard_steps = (a.shard == "steps" and world > 1 and T == 1)
+    lo, hi = par.shard_steps(a.steps, world, rank) if shard_steps else (0, a.steps)
+    o = mw.Ocean(seed=1 if shard_steps else 1 + 64 * rank, semantics=mw.MW_SEM_OCEANRENDERER, device=dev.index, ntiles=T, **kw)
     o.set_stream(stream.cuda_stream)
     M = o.N
     MM = M * M
     build_id = nat.build_id()
     DT = 1.0 / 60.0
     _lib = nat.lib()
-    B, sizes = batch_plan(max(a.steps, 1), F)
+    B, sizes = batch_plan(max(hi - lo, 1), F)
+    seek = (np.full(max(lo, 1), DT, np.float32), lo, np.full(max(a.steps - hi, 1), DT, np.float32), a.steps - hi)
     dest = None
     if F > 1:       # caller-owned destinations, [F][...] like the FFTMesh enqueue's
         dest = (torch.empty((B, M, M), dtype=torch.float32, device=dev), torch.empty((B, M, M, 2), dtype=torch.float32, device=dev),
@@ -1106,7 +1112,11 @@ def renderer(a, e, extra=False):
     def wall_region():
         barrier()
         t0 = time.perf_counter()
+        if shard_steps and seek[1]:
+            nat.check(_lib.mw_ocean_advance_phase(o.handle, seek[0].ctypes.data_as(C.c_void_p), seek[1]))
         run(sizes)
+        if shard_steps and seek[3]:
+            nat.check(_lib.mw_ocean_advance_phase(o.handle, seek[2].ctypes.data_as(C.c_void_p), seek[3]))
         while not stream.query():
             pass
         torch.cuda.synchronize()
@@ -1154,7 +1164,7 @@ def renderer(a, e, extra=False):
                          f"(+ numpy fft2 for the Stockham blits), {elc:.2f} s per frame; host has {os.cpu_count()} cores"}
     out = None
     if rank == 0:
-        v = world * a.steps * MM * T / el
+        v = (a.steps if shard_steps else world * a.steps) * MM * T / el
         bytes_frame = 96.0 + 24.0 / F           # per texel and frame
         # HBM-side bytes of ONE ENQUEUE from the committed counter pass: a call per frame = its three launches; a steps call = one spectrum
         # launch + per chunk of OR_STEPS_CHUNK frames one pass-2 and one normal-pass launch + the copy of the last frame
@@ -1217,7 +1227,7 @@ def renderer(a, e, extra=False):
         out = ({
             "metric": "OceanRenderer-semantics texels/sec (dispersion+spectrum -> 2-D Stockham -> normal -> whitecap), 1024^2",
             "value": v, "unit": "texels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if shard_steps else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "build_id": build_id, "preheat_ms": preheat_ms, "repeats": R, "timed_ms_total": sum(regions) * 1e3,
             "region_ms_stats": {k: (round(x * 1e3, 5) if k != "n" else x) for k, x in rpc.items()},
             "config": {"workload": "OceanRenderer GenerateTexture(), 1024x1024 textures, shipped demo parameters (D/Ocean Demo.unity:296-302: "
@@ -1226,6 +1236,8 @@ def renderer(a, e, extra=False):
                                       f"one ocean, {B} consecutive frames per enqueue (mw_ocean_generate_texture_steps_device), "
                                       f"the timed region is {len(sizes)} enqueue(s)"),
                        "semantics": "MW_SEM_OCEANRENDERER", "tiles_per_call": T, "frames_per_enqueue": B if T == 1 else 1,
+                       "parallelism": (f"steps{world}: ONE ocean, rank r renders frames [lo, hi) of the K after seeking there with mw_ocean_advance_phase"
+                                       if shard_steps else f"tile{world}"),
                        "enqueue_sizes_timed": sizes if len(sizes) <= 4 else [sizes[0], "...", sizes[-1]],
                        "us_per_tile_frame": el / a.steps / T * 1e6},
             "frame_at_a_time": frame, "parity": parity,

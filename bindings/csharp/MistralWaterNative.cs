@@ -105,6 +105,7 @@ public static class MistralWaterNative
     [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_steps_device(IntPtr ocean, float[] deltaTime, int nframes, IntPtr dHeight, IntPtr dDispXZ, IntPtr dNormal, IntPtr dWhite);
     [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_steps_rgba_device(IntPtr ocean, float[] deltaTime, int nframes, IntPtr dHeight, IntPtr dDisplacement, IntPtr dNormal, IntPtr dWhite);
     [DllImport(Lib)] public static extern int mw_ocean_max_frames(IntPtr ocean);
+    [DllImport(Lib)] public static extern Status mw_ocean_advance_phase(IntPtr ocean, float[] deltaTime, int nframes);
     [DllImport(Lib)] public static extern Status mw_ocean_frame_textures(IntPtr ocean, int frame, out IntPtr dHeight, out IntPtr dDispXZ, out IntPtr dNormal, out IntPtr dWhite);
     [DllImport(Lib)] public static extern Status mw_ocean_displace_mesh(IntPtr ocean, [Out] Vector3[] vertices, [Out] Vector3[] normals, [Out] float[] colors);
     [DllImport(Lib)] public static extern Status mw_ocean_displace_mesh_device(IntPtr ocean, IntPtr dVertices, IntPtr dNormals, IntPtr dColors);

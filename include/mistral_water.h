@@ -193,6 +193,10 @@ mw_status mw_ocean_generate_texture_device(mw_ocean* o, float delta_time, void* 
  * mw_ocean_create_batch fills the device with tiles instead: MW_ESTATE).  Asynchronous on the handle's stream.                        */
 mw_status mw_ocean_generate_texture_steps_device(mw_ocean* o, const float* delta_time, int32_t nframes, void* d_height,
                                                  void* d_disp_xz, void* d_normal_xyz, void* d_white);
+/* The phase texture after nframes MORE GenerateTexture() calls with these delta times, without producing textures (the Dispersion pass alone,
+ * F/Dispersion.shader:32-41; any nframes >= 0; delta_time is a HOST array): the handle then continues bit for bit like one that rendered
+ * those frames.  How a rank of a multi-GPU job seeks to its own block of a frame sequence, and how a recorder skips frames.  Asynchronous.  */
+mw_status mw_ocean_advance_phase(mw_ocean* o, const float* delta_time, int32_t nframes);
 int32_t mw_ocean_max_frames(const mw_ocean* o); /* largest nframes one enqueue accepts (0: not an OceanRenderer handle) */
 /* device pointers of frame `frame` of the LATEST steps call for the textures that call kept in the handle (NULL destination there);
  * a texture that went to a caller buffer reports NULL.  Valid until the next steps call of this handle.                              */

@@ -1401,6 +1401,16 @@ mw_status mw_ocean_generate_texture_steps_device(mw_ocean* o, const float* delta
     o->orr.frames_last = nframes;
     return MW_OK;
 }
+mw_status mw_ocean_advance_phase(mw_ocean* o, const float* delta_time, int32_t nframes) {
+    if (!o || (!delta_time && nframes > 0)) return fail(MW_EINVAL, "mw_ocean_advance_phase: NULL argument");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_advance_phase: OceanRenderer semantics only (FFTMesh time is mw_ocean_set_timer)");
+    if (nframes < 0) return fail(MW_EINVAL, "mw_ocean_advance_phase: nframes < 0");
+    if (nframes == 0) return MW_OK;
+    HIP_TRY(hipSetDevice(o->device));
+    mw_status s = or_advance_phase(o->orr, delta_time, nframes, o->stream);
+    if (s != MW_OK) return fail(s, or_last_error());
+    return MW_OK;
+}
 int32_t mw_ocean_max_frames(const mw_ocean* o) { return (o && o->sem == MW_SEM_OCEANRENDERER && o->orr.tiles == 1) ? MW_OR_MAX_FRAMES : 0; }
 mw_status mw_ocean_frame_textures(mw_ocean* o, int32_t frame, void** d_height, void** d_disp_xz, void** d_normal_xyz, void** d_white) {
     if (!o) return fail(MW_EINVAL, "NULL handle");

@@ -748,6 +748,34 @@ static inline mw_status or_generate_steps_rgba(OrState& s, const float* delta_ti
     return MW_OK;
 }
 
+// The Dispersion pass alone (F/Dispersion.shader:32-41) for n frames: the phase texture after n GenerateTexture() calls with these delta times,
+// no textures produced -- the same or_phase_step chain per texel, so a handle advanced this way continues bit for bit like one that rendered the
+// frames.  How a rank of a multi-GPU job seeks to ITS block of a frame sequence (time-steps shard across devices; in this
+// semantics only the phase links them), and how a recorder skips frames.
+struct OrAdvanceArgs {
+    float dt[MW_OR_MAX_FRAMES];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_or_advance(size_t MM, const float* omT, float* phase, OrAdvanceArgs A) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= MM) return;
+    const float om = omT[i];
+    float ph = phase[i + (size_t)blockIdx.y * MM];  // tile blockIdx.y
+    for (int k = 0; k < A.n; k++) ph = or_phase_step(om, ph, A.dt[k]);
+    phase[i + (size_t)blockIdx.y * MM] = ph;
+}
+static inline mw_status or_advance_phase(OrState& s, const float* delta_time, int n, hipStream_t st) {
+    const size_t MM = (size_t)s.M * s.M;
+    for (int k0 = 0; k0 < n; k0 += MW_OR_MAX_FRAMES) {
+        OrAdvanceArgs A;
+        A.n = (n - k0 < MW_OR_MAX_FRAMES) ? n - k0 : MW_OR_MAX_FRAMES;
+        for (int k = 0; k < MW_OR_MAX_FRAMES; k++) A.dt[k] = k < A.n ? delta_time[k0 + k] * s.mult : 0.f;  // S/OceanRenderer.cs:223
+        k_or_advance<<<dim3((unsigned)((MM + 255) / 256), s.tiles), dim3(256), 0, st>>>(MM, s.omT, s.phaseT, A);
+    }
+    if (hipGetLastError() != hipSuccess) { g_or_err = "k_or_advance launch failed"; return MW_EDEVICE; }
+    return MW_OK;
+}
+
 // the ocean material's vertex stage on the res x res mesh, from the textures of the latest GenerateTexture()
 static inline mw_status or_displace_mesh(OrState& s, int res, float unit_width, float* d_vert, float* d_nrm, float* d_col,
                                          hipStream_t st) {

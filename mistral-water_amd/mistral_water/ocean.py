@@ -242,6 +242,11 @@ class Ocean:
         nat.check(nat.lib().mw_ocean_generate_texture_rgba(self._h, C.c_float(delta_time), *[_p(a) for a in t]))
         return tuple(t)
 
+    def advance_phase(self, delta_times):
+        """The phase texture after len(delta_times) more frames, no textures produced (mw_ocean_advance_phase): seek / skip."""
+        dts = np.ascontiguousarray(delta_times, np.float32)
+        nat.check(nat.lib().mw_ocean_advance_phase(self._h, _p(dts), int(dts.size)))
+
     def max_frames(self) -> int:
         return nat.lib().mw_ocean_max_frames(self._h)
 

@@ -305,6 +305,41 @@ def test_gpu_generate_texture_steps_equal_single_calls(mw, oracle, resolution, n
 
 
 @pytest.mark.gpu
+def test_gpu_advance_phase_seeks_like_rendered_frames(mw, oracle):
+    """mw_ocean_advance_phase: the Dispersion pass alone (F/Dispersion.shader:32-41).  A handle advanced over 75 frames (three launches'
+    worth, a ten-minute jump among them) holds, bit for bit, the phase texture of a handle that rendered them and of the oracle's recurrence --
+    and renders the next frames identically: what lets rank r of a job start at frame lo of a sequence (time-steps shard)."""
+    rp = shipped(16)
+    M = rp.M
+    kw = dict(resolution=16, length=rp.length, wind=(rp.wind_x, rp.wind_y), amplitude=rp.amplitude, choppiness=rp.choppiness,
+              gravity=rp.gravity, mult=rp.mult, seed=4, semantics=mw.MW_SEM_OCEANRENDERER)
+    dts = _frame_dts(75)
+    with mw.Ocean(**kw) as a, mw.Ocean(**kw) as b, mw.Ocean(ntiles=2, **kw) as t:
+        init4 = np.concatenate(a.get_spectrum(), -1)
+        ph = np.zeros((M, M), np.float32)
+        for dt in dts:
+            a.generate_texture(float(dt))
+            oracle.renderer_advance_phase(rp, init4, ph, float(dt))
+        b.advance_phase(dts)
+        b.advance_phase([])                                       # zero frames: nothing happens
+        assert (a.get_phase() == ph).all() and (b.get_phase() == ph).all()
+        fa, fb = a.generate_texture_steps(dts[:5]), b.generate_texture_steps(dts[:5])
+        assert all((x == y).all() for x, y in zip(fa, fb))
+        t.advance_phase(dts[:40])                                 # a batched handle: every tile's phase
+        pt = t.get_phase()
+        with mw.Ocean(**kw) as c:
+            c.advance_phase(dts[:40])
+            assert (pt[0] == c.get_phase()).all() and (pt[1] == c.get_phase()).all()     # omega is the tiles' common table
+        with pytest.raises(mw.MistralWaterError) as e:
+            mw.check(mw.lib().mw_ocean_advance_phase(a.handle, None, 3))
+        assert e.value.status == mw.MW_EINVAL
+    with mw.Ocean(resolution=64, length=64.0) as f:
+        with pytest.raises(mw.MistralWaterError) as e:
+            f.advance_phase([0.1])
+        assert e.value.status == mw.MW_ESTATE
+
+
+@pytest.mark.gpu
 def test_gpu_generate_texture_steps_destinations_rgba_and_errors(mw):
     """Caller-owned device destinations ([n][M*M*...]), the ARGBFloat form, a second call that grows the frame buffers, and the
     argument errors of the steps entry points."""

@@ -729,6 +729,17 @@ def test_bench_two_rank_control_flow_on_one_device():
     assert abs(s["value"] - 64 * NN / (s["ms_per_step"] * 1e-3 * 64)) < 1e-6 * s["value"]
 
 
+def test_bench_renderer_frames_sharded_over_two_ranks():
+    """OceanRenderer semantics, N > 1, --shard steps: ONE ocean, rank r renders frames [lo, hi) of the K after seeking there with the
+    Dispersion pass alone (mw_ocean_advance_phase) -- in this semantics only the phase links the frames.  K frames in total, strong scaling."""
+    r = _run_bench(["--workload", "renderer1024", "--steps", "64", "--warmup", "32", "--no-cpu-baseline", "--preheat-ms", "20", "--shard", "steps"],
+                   {"MW_BENCH_BACKEND": "gloo", "MW_BENCH_SAME_DEVICE": "1"}, nproc=2)
+    NN = 1024 * 1024
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["parallelism"].startswith("steps2") and r["parity"].startswith("ok")
+    assert r["config"]["frames_per_enqueue"] == 32 and r["config"]["enqueue_sizes_timed"] == [32]              # each rank: its 32 of the 64 frames
+    assert abs(r["value"] - 64 * NN / (r["ms_per_step"] * 1e-3 * 64)) < 1e-6 * r["value"]
+
+
 def test_bench_times_what_it_prints_and_gates_the_tile_path():
     """The driver's command line (--steps 20 --warmup 5): ONE 20-step enqueue, pass-1 time group 5, roofline from 20-step
     launches, literal config-2 parameters, frame-at-a-time figures present; and the tile-API path keeps the parity gate."""
