@@ -102,6 +102,9 @@ __global__ void k_or_prep(int M, const f4* initT, f4* PQT) {
     const size_t toff = (size_t)blockIdx.y * M * M;  // tile blockIdx.y
     or_prep_element(M, idx / M, idx % M, initT + toff, PQT + toff);
 }
+#ifndef MW_OR_P1_LONE_CHUNK
+#define MW_OR_P1_LONE_CHUNK 4  // points whose loads the lone frame's spectrum workgroup requests together (1 / 2 / 4 / 8: 1024^2 34.4 / 34.1 / 34.0 /
+#endif                         // 34.7 us per frame, 512^2 19.9 / 19.0 / 18.9 / 18.9; the three-transform plan keeps point by point)
 #ifndef MW_OR_PACKED_MAX_M
 #define MW_OR_PACKED_MAX_M 4096  // textures from this size up keep the three-transform plan
 #endif
@@ -131,7 +134,7 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1_packed(
 #pragma unroll
     for (int q = 0; q < P; q++) h[q] = hh[q] = mk(0.f, 0.f);
     if (gridDim.y == 1) or_p1_animate_packed<N, P, MW_OR_P1_CHUNK>(A, jb, tid, true, true, true, h, hh);
-    else or_p1_animate_packed<N, P, 1>(A, jb, tid, f0 == 0, f0 == 0, f0 == 1, h, hh);
+    else or_p1_animate_packed<N, P, MW_OR_P1_LONE_CHUNK>(A, jb, tid, f0 == 0, f0 == 0, f0 == 1, h, hh);
     tws.store(lds, tid);
     for (int f = f0; f < f1; f++) {
         or_p1_build_packed<N, P>(A, jb, tid, f, h, hh, x);
