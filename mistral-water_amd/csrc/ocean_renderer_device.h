@@ -194,6 +194,7 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1(OrP1Arg
 
 // nframes consecutive frames of one ocean: grid (M/4 column jobs, 1, frame groups).  KEEP: the initial spectrum of the workgroup's
 // points stays in registers over the frames of its group (else re-read per frame: an L2 hit after the first).
+// (forcing 5 / 6 waves per SIMD with amdgpu_waves_per_eu: 44 / 108 B of scratch, 19.4 / 21.5 us per frame against 19.2: not kept)
 template <int N, int P, bool KEEP, bool PACKED = false>
 __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1_steps(OrP1StepsArgs S) {
     constexpr int NF = PACKED ? 2 : 3;  // planes of the exchange buffer per frame
@@ -213,7 +214,11 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1_steps(O
     f4 v[P], vn;
     const int fsel = PACKED ? (int)blockIdx.y : 0;  // packed plan: one field per workgroup (or_p1_steps_coeff)
     or_p1_steps_begin<N, P>(A, jb, tid, om, ph);
-    if constexpr (PACKED) { if (KEEP) or_p1_steps_coeff<N, P>(A, jb, tid, fsel, v, vn); }
+    float gain[PACKED ? P : 1];
+    if constexpr (PACKED) {
+        if (KEEP) or_p1_steps_coeff<N, P>(A, jb, tid, fsel, v, vn);
+        or_p1_steps_gain<N, P>(A, jb, tid, fsel, gain);  // (the choppiness of this enqueue: A.c is fixed for its frames)
+    }
     else { if (KEEP) or_p1_steps_spectrum<N, P>(A, jb, tid, v); }
     tws.store(lds, tid);  // behind the phase / spectrum requests; published by the first barrier
     for (int k = 0; k < k0; k++) or_p1_steps_advance<P>(om, ph, S.dt[k]);  // the chain over the frames of the groups before this one
@@ -228,7 +233,7 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1_steps(O
             or_p1_steps_animate<P>(v, ph, h);
         }
         for (int f = PACKED ? fsel : 0; f < (PACKED ? fsel + 1 : 3); f++) {
-            if constexpr (PACKED) or_p1_steps_build_split<N, P>(A, jb, tid, f, v, vn, ph, x);
+            if constexpr (PACKED) or_p1_steps_build_split<N, P>(tid, f, gain, v, vn, ph, x);
             else or_p1_build<N, P>(A, jb, tid, f, h, x);
             if ((!PACKED && f != 0) || k != k0) __syncthreads();  // the previous field's final-pass reads of the buffers are done
             stage0_store<N, P, -1>(x, u, set0 + w * G::BUFSTRIDE);

@@ -213,6 +213,12 @@ MW_HD void or_p1_steps_store_phase(const OrP1Args& A, int jb, int tid, const flo
     for (int q = 0; q < P; q++) (c_po + T * q)[uo] = ph[q];
 }
 
+// the real multiplier of a displacement field at one texel: chop * k_c / max(1e-4, |k|) (F/Spectrum.shader:47-49).  One function, its rounding
+// written out (one FMA under the root), for every kernel that forms it -- the steps kernel computes it ONCE per workgroup, the others per frame
+MW_HD float or_gain(float kc, float kx, float kz, float chop) {
+    const float wl = fmaxf(0.0001f, sqrtf(__builtin_fmaf(kx, kx, smul(kz, kz))));
+    return smul(sdiv(kc, wl), chop);
+}
 // f = 0: h (height);  f = 1: hx = -i h kx/w chop;  f = 2: hz   (F/Spectrum.shader:47-49)
 template <int N, int P>
 MW_HD void or_p1_build(const OrP1Args& A, int jb, int tid, int f, const cf (&h)[P], cf (&x)[P]) {
@@ -223,8 +229,7 @@ MW_HD void or_p1_build(const OrP1Args& A, int jb, int tid, int f, const cf (&h)[
     for (int q = 0; q < P; q++) {
         if (f == 0) { x[q] = h[q]; continue; }
         const float kz = or_wave(N, A.c.length, u + T * q);
-        const float wl = fmaxf(0.0001f, sqrtf(kx * kx + kz * kz));  // :47
-        const float g = ((f == 1) ? kx : kz) / wl * A.c.choppiness;
+        const float g = or_gain((f == 1) ? kx : kz, kx, kz, A.c.choppiness);  // :47
         // -MultByI(h * k/w) * chop.  Rounded products (smul): the first butterfly adds these values, and a kernel whose field index is a
         // compile-time constant would otherwise fuse product and sum into an FMA where the one-field-per-workgroup form (a select in
         // between) cannot -- the frames of a steps call must equal single calls bit for bit
@@ -261,8 +266,7 @@ MW_HD void or_p1_build_packed(const OrP1Args& A, int jb, int tid, int f, const c
     for (int q = 0; q < P; q++) {
         const int py = u + T * q;
         const float kz = or_wave(N, A.c.length, py);
-        const float wl = fmaxf(0.0001f, sqrtf(kx * kx + kz * kz));  // F/Spectrum.shader:47
-        const float g = ((f == 0) ? kx : kz) / wl * A.c.choppiness;
+        const float g = or_gain((f == 0) ? kx : kz, kx, kz, A.c.choppiness);
         if (f == 0) { x[q] = mk(smul(h[q].y, g), smul(-h[q].x, g)); continue; }
         const bool nyq = (py == N / 2);
         const float tx = nyq ? ssub(h[q].x, hh[q].x) : hh[q].x, ty = nyq ? ssub(h[q].y, hh[q].y) : hh[q].y;
@@ -319,20 +323,30 @@ MW_HD void or_p1_steps_coeff(const OrP1Args& A, int jb, int tid, int f, f4 (&c)[
     for (int q = 0; q < P; q++) c[q] = (c_c + T * q)[uo];
     vn = (A.initT + (size_t)px * N + T * (P / 2))[uo];
 }
+// the field's multipliers of this thread's P points: they do not depend on the frame (two divisions and a root per point -- as many
+// instructions as the point's share of the transform when formed per frame: 280 of a frame's ~860 VALU per thread)
 template <int N, int P>
-MW_HD void or_p1_steps_build_split(const OrP1Args& A, int jb, int tid, int f, const f4 (&c)[P], const f4& vn, const float (&ph)[P], cf (&x)[P]) {
+MW_HD void or_p1_steps_gain(const OrP1Args& A, int jb, int tid, int f, float (&g)[P]) {
     constexpr int T = FftGeom<N, P>::T;
     const int w = tid / T, u = tid % T, px = 4 * jb + w;
     const float kx = or_wave(N, A.c.length, px);
+#pragma unroll
+    for (int q = 0; q < P; q++) {
+        const float kz = or_wave(N, A.c.length, u + T * q);
+        g[q] = or_gain((f == 0) ? kx : kz, kx, kz, A.c.choppiness);
+    }
+}
+template <int N, int P>
+MW_HD void or_p1_steps_build_split(int tid, int f, const float (&g_)[P], const f4 (&c)[P], const f4& vn, const float (&ph)[P], cf (&x)[P]) {
+    constexpr int T = FftGeom<N, P>::T;
+    const int u = tid % T;
 #pragma unroll
     for (int q = 0; q < P; q++) {
         float sn, cs;
         mw_sincos(ph[q], &sn, &cs);
         const cf a = animate(c[q].x, c[q].y, c[q].z, c[q].w, cs, sn);
         const int py = u + T * q;
-        const float kz = or_wave(N, A.c.length, py);
-        const float wl = fmaxf(0.0001f, sqrtf(kx * kx + kz * kz));
-        const float g = ((f == 0) ? kx : kz) / wl * A.c.choppiness;
+        const float g = g_[q];
         if (f == 0) { x[q] = mk(smul(a.y, g), smul(-a.x, g)); continue; }
         float tx = a.x, ty = a.y;
         if (q == P / 2) {  // only slot P/2 can hold the Nyquist row (py = N/2 <=> u = 0): h there, from its own coefficients
