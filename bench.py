@@ -670,7 +670,7 @@ def ocean(a, e, N, extra=False):
     traffic, traffic_note, traffic1 = tr2["traffic"], tr2["note"], tr1["traffic"]
     stale = None
     if traffic is None:      # context only, never `traffic`: the last committed counter pass of this kernel, whatever build it was
-        for rnd in ("r05", "r04", "r02"):
+        for rnd in ("r06", "r05", "r04", "r02"):
             try:
                 j = json.load(open(os.path.join(REPO, "profiles", f"{rnd}_{wl_name}_b32_pmc.json")))["pmc_mean_per_launch"]
                 k = [v for name, v in j.items() if "k_pass2" in name][0]

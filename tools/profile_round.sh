@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence of the CURRENT build, every workload at the batch sizes bench.py reports (run through gpurun; ~6 min):
-#   tools/profile_round.sh r05     (then set PROFILE_ROUND = "r05" in bench.py)  ->  gpurun_out/prof_<tag>_<workload>/ and the condensed profiles/<tag>_<workload>_b<B>_{kernel_stats.csv,pmc.json}
+#   tools/profile_round.sh r06     (then set PROFILE_ROUND = "r06" in bench.py)  ->  gpurun_out/prof_<tag>_<workload>/ and the condensed profiles/<tag>_<workload>_b<B>_{kernel_stats.csv,pmc.json}
 # Each summary stores the bench line of the traced run (with mw_build_id()): bench.py quotes roofline.traffic from it only while
 # the library is that build.  Memory guard: a host-side bug once took the GPU boxes down -- every python
 # process below runs under `timeout`, and nothing here allocates more than a few GB.
