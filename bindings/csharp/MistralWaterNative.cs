@@ -104,6 +104,8 @@ public static class MistralWaterNative
     // nframes consecutive GenerateTexture() calls in one enqueue (bit-identical to nframes single calls, the phase included); device destinations [nframes][...]
     [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_steps_device(IntPtr ocean, float[] deltaTime, int nframes, IntPtr dHeight, IntPtr dDispXZ, IntPtr dNormal, IntPtr dWhite);
     [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_steps_rgba_device(IntPtr ocean, float[] deltaTime, int nframes, IntPtr dHeight, IntPtr dDisplacement, IntPtr dNormal, IntPtr dWhite);
+    [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_steps(IntPtr ocean, float[] deltaTime, int nframes, [Out] float[] height, [Out] Vector2[] dispXZ, [Out] Vector3[] normal, [Out] float[] white);
+    [DllImport(Lib)] public static extern Status mw_ocean_generate_texture_steps_rgba(IntPtr ocean, float[] deltaTime, int nframes, [Out] Color[] height, [Out] Color[] displacement, [Out] Color[] normal, [Out] Color[] white);
     [DllImport(Lib)] public static extern int mw_ocean_max_frames(IntPtr ocean);
     [DllImport(Lib)] public static extern Status mw_ocean_advance_phase(IntPtr ocean, float[] deltaTime, int nframes);
     [DllImport(Lib)] public static extern Status mw_ocean_frame_textures(IntPtr ocean, int frame, out IntPtr dHeight, out IntPtr dDispXZ, out IntPtr dNormal, out IntPtr dWhite);

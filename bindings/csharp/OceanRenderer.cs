@@ -126,6 +126,13 @@ public class OceanRenderer : MonoBehaviour
         Native.Check(Native.mw_ocean_generate_texture_steps_rgba_device(ocean, deltaTimes, deltaTimes.Length, dHeight, dDisplacement, dNormal, dWhite));
     }
 
+    // the same into managed arrays ([n * M * M] Color each; null skips a target): n frames over PCIe in one synchronous call
+    public void GenerateTextures(float[] deltaTimes, Color[] height, Color[] displacement, Color[] normal, Color[] white)
+    {
+        if (deltaTimes.Length > Native.mw_ocean_max_frames(ocean)) throw new ArgumentException("more frames than mw_ocean_max_frames");
+        Native.Check(Native.mw_ocean_generate_texture_steps_rgba(ocean, deltaTimes, deltaTimes.Length, height, displacement, normal, white));
+    }
+
     void GenerateTexture()
     {
         Native.Check(Native.mw_ocean_generate_texture_rgba(ocean, Time.deltaTime, heightPixels, displacementPixels, normalPixels, whitePixels));

@@ -197,6 +197,9 @@ mw_status mw_ocean_generate_texture_steps_device(mw_ocean* o, const float* delta
  * F/Dispersion.shader:32-41; any nframes >= 0; delta_time is a HOST array): the handle then continues bit for bit like one that rendered
  * those frames.  How a rank of a multi-GPU job seeks to its own block of a frame sequence, and how a recorder skips frames.  Asynchronous.  */
 mw_status mw_ocean_advance_phase(mw_ocean* o, const float* delta_time, int32_t nframes);
+/* host form: the same nframes frames into host arrays [nframes][M*M*...] (any may be NULL); synchronous, PCIe-bound (28 B per texel and frame) */
+mw_status mw_ocean_generate_texture_steps(mw_ocean* o, const float* delta_time, int32_t nframes, float* height, float* disp_xz,
+                                          float* normal_xyz, float* white);
 int32_t mw_ocean_max_frames(const mw_ocean* o); /* largest nframes one enqueue accepts (0: not an OceanRenderer handle) */
 /* device pointers of frame `frame` of the LATEST steps call for the textures that call kept in the handle (NULL destination there);
  * a texture that went to a caller buffer reports NULL.  Valid until the next steps call of this handle.                              */
@@ -226,6 +229,8 @@ mw_status mw_ocean_generate_texture_rgba_device(mw_ocean* o, float delta_time, v
 /* nframes consecutive frames (mw_ocean_generate_texture_steps_device) as the four ARGBFloat targets, [nframes][M*M*4] each.          */
 mw_status mw_ocean_generate_texture_steps_rgba_device(mw_ocean* o, const float* delta_time, int32_t nframes, void* d_height_rgba,
                                                       void* d_disp_rgba, void* d_normal_rgba, void* d_white_rgba);
+mw_status mw_ocean_generate_texture_steps_rgba(mw_ocean* o, const float* delta_time, int32_t nframes, float* height_rgba, float* disp_rgba,
+                                               float* normal_rgba, float* white_rgba); /* host arrays [nframes][M*M*4], synchronous */
 /* The ocean material's vertex stage on the resolution x resolution mesh of S/OceanRenderer.cs:172-207, sampling the
  * textures of the LATEST GenerateTexture() bilinearly at the vertex uv (tex2Dlod, clamp):
  *   vertex = rest + (_Anim.r, _Height.r, _Anim.b) / 8      W/TestOcean.shader:65-66, W/MistralWaterCommon.cginc:22-23

@@ -1401,6 +1401,48 @@ mw_status mw_ocean_generate_texture_steps_device(mw_ocean* o, const float* delta
     o->orr.frames_last = nframes;
     return MW_OK;
 }
+// host forms of the steps calls: the frames stay in the handle's frame buffers, then leave over PCIe into the caller's [nframes][...] arrays
+static mw_status steps_to_host(mw_ocean* o, const float* delta_time, int32_t nframes, bool rgba, float* const host[4], const char* who) {
+    if (!o || !delta_time) return fail(MW_EINVAL, std::string(who) + ": NULL argument");
+    if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, std::string(who) + ": OceanRenderer semantics only");
+    HIP_TRY(hipSetDevice(o->device));
+    const size_t MM = (size_t)o->N * o->N;
+    if (!rgba) {
+        mw_status s = mw_ocean_generate_texture_steps_device(o, delta_time, nframes, nullptr, nullptr, nullptr, nullptr);
+        if (s != MW_OK) return s;
+        void* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+        if ((s = mw_ocean_frame_textures(o, 0, &dev[0], &dev[1], &dev[2], &dev[3])) != MW_OK) return s;
+        const size_t per[4] = {MM, 2 * MM, 3 * MM, MM};
+        for (int k = 0; k < 4; k++)
+            if (host[k]) HIP_TRY(hipMemcpyAsync(host[k], dev[k], per[k] * (size_t)nframes * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+        HIP_TRY(hipStreamSynchronize(o->stream));
+        return MW_OK;
+    }
+    const size_t bytes = MM * 4 * sizeof(float) * (size_t)nframes, stride = align256(bytes);
+    void* buf = nullptr;
+    int wanted = 0;
+    for (int k = 0; k < 4; k++) wanted += host[k] ? 1 : 0;
+    mw_status s = scratch_reserve(o, (size_t)(wanted ? wanted : 1) * stride, &buf);
+    if (s != MW_OK) return s;
+    float* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0, j = 0; k < 4; k++)
+        if (host[k]) dev[k] = reinterpret_cast<float*>(static_cast<char*>(buf) + (size_t)(j++) * stride);
+    if ((s = mw_ocean_generate_texture_steps_rgba_device(o, delta_time, nframes, dev[0], dev[1], dev[2], dev[3])) != MW_OK) return s;
+    for (int k = 0; k < 4; k++)
+        if (host[k]) HIP_TRY(hipMemcpyAsync(host[k], dev[k], bytes, hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return MW_OK;
+}
+mw_status mw_ocean_generate_texture_steps(mw_ocean* o, const float* delta_time, int32_t nframes, float* height, float* disp_xz, float* normal_xyz,
+                                          float* white) {
+    float* const host[4] = {height, disp_xz, normal_xyz, white};
+    return steps_to_host(o, delta_time, nframes, false, host, "mw_ocean_generate_texture_steps");
+}
+mw_status mw_ocean_generate_texture_steps_rgba(mw_ocean* o, const float* delta_time, int32_t nframes, float* height_rgba, float* disp_rgba,
+                                               float* normal_rgba, float* white_rgba) {
+    float* const host[4] = {height_rgba, disp_rgba, normal_rgba, white_rgba};
+    return steps_to_host(o, delta_time, nframes, true, host, "mw_ocean_generate_texture_steps_rgba");
+}
 mw_status mw_ocean_advance_phase(mw_ocean* o, const float* delta_time, int32_t nframes) {
     if (!o || (!delta_time && nframes > 0)) return fail(MW_EINVAL, "mw_ocean_advance_phase: NULL argument");
     if (o->sem != MW_SEM_OCEANRENDERER) return fail(MW_ESTATE, "mw_ocean_advance_phase: OceanRenderer semantics only (FFTMesh time is mw_ocean_set_timer)");

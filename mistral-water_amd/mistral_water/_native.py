@@ -184,6 +184,8 @@ def lib():
         "mw_ocean_generate_texture_device": (C.c_int, [vp, C.c_float, vp, vp, vp, vp]),
         "mw_ocean_generate_texture_steps_device": (C.c_int, [vp, f32p, C.c_int32, vp, vp, vp, vp]),
         "mw_ocean_generate_texture_steps_rgba_device": (C.c_int, [vp, f32p, C.c_int32, vp, vp, vp, vp]),
+        "mw_ocean_generate_texture_steps": (C.c_int, [vp, f32p, C.c_int32, f32p, f32p, f32p, f32p]),
+        "mw_ocean_generate_texture_steps_rgba": (C.c_int, [vp, f32p, C.c_int32, f32p, f32p, f32p, f32p]),
         "mw_ocean_max_frames": (C.c_int32, [vp]),
         "mw_ocean_advance_phase": (C.c_int, [vp, f32p, C.c_int32]),
         "mw_ocean_frame_textures": (C.c_int, [vp, C.c_int32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
@@ -238,7 +240,7 @@ ABI_SYMBOLS = [
     "mw_ocean_grid_size", "mw_ocean_evaluate", "mw_ocean_update", "mw_ocean_timer", "mw_ocean_reset_timer",
     "mw_ocean_evaluate_device", "mw_ocean_max_batch", "mw_ocean_generate_texture",
     "mw_ocean_generate_texture_device", "mw_ocean_generate_texture_steps_device", "mw_ocean_generate_texture_steps_rgba_device",
-    "mw_ocean_max_frames", "mw_ocean_advance_phase", "mw_ocean_frame_textures", "mw_host_register", "mw_host_unregister", "mw_ocean_generate_texture_rgba", "mw_ocean_generate_texture_rgba_device",
+    "mw_ocean_generate_texture_steps", "mw_ocean_generate_texture_steps_rgba", "mw_ocean_max_frames", "mw_ocean_advance_phase", "mw_ocean_frame_textures", "mw_host_register", "mw_host_unregister", "mw_ocean_generate_texture_rgba", "mw_ocean_generate_texture_rgba_device",
     "mw_ocean_displace_mesh", "mw_ocean_displace_mesh_device", "mw_gerstner_displace",
     "mw_gerstner_displace_device", "mw_gerstner_displace_steps_device", "mw_gerstner_max_steps", "mw_pond_displace", "mw_pond_displace_device",
 ]

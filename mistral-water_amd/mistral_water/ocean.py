@@ -263,14 +263,16 @@ class Ocean:
         nat.check(nat.lib().mw_ocean_frame_textures(self._h, int(frame), *[C.byref(q) for q in ptrs]))
         return tuple(q.value for q in ptrs)
 
-    def generate_texture_steps(self, delta_times):
-        """Host form of the above for tests and small jobs: -> (height [n,M,M], disp [n,M,M,2], normal [n,M,M,3], white [n,M,M])."""
+    def generate_texture_steps(self, delta_times, rgba: bool = False):
+        """Host form (mw_ocean_generate_texture_steps[_rgba]): -> (height [n,M,M], disp [n,M,M,2], normal [n,M,M,3], white [n,M,M]), or the
+        four ARGBFloat targets [n,M,M,4] each with rgba=True."""
         dts = np.ascontiguousarray(delta_times, np.float32)
         n, M = int(dts.size), self.N
-        self.generate_texture_steps_device(dts)
-        self.synchronize()
-        base = self.frame_textures(0)
-        return tuple(_d2h(ptr, (n, M, M) + tail) for ptr, tail in zip(base, ((), (2,), (3,), ())))
+        tails = ((4,),) * 4 if rgba else ((), (2,), (3,), ())
+        out = tuple(np.empty((n, M, M) + t, np.float32) for t in tails)
+        fn = nat.lib().mw_ocean_generate_texture_steps_rgba if rgba else nat.lib().mw_ocean_generate_texture_steps
+        nat.check(fn(self._h, _p(dts), n, *[_p(a) for a in out]))
+        return out
 
     def displace_mesh(self):
         """The ocean material's vertex stage (W/TestOcean.shader:61-79) on the resolution^2 mesh, from the textures

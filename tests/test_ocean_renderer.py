@@ -368,6 +368,14 @@ def test_gpu_generate_texture_steps_destinations_rgba_and_errors(mw):
             for t, o in zip(tex, one):
                 assert (t[k].cpu().numpy() == o).all(), k
         assert (a.get_phase() == b.get_phase()).all()
+        # the host forms (what a C# host with managed arrays calls): the same frames, planar and ARGBFloat; a NULL array is skipped
+        hp = a.generate_texture_steps(dts[:4]); hb = [b.generate_texture(float(dt)) for dt in dts[:4]]
+        assert all((hp[c][k] == hb[k][c]).all() for k in range(4) for c in range(4))
+        hr = a.generate_texture_steps(dts[:2], rgba=True); rb = [b.generate_texture_rgba(float(dt)) for dt in dts[:2]]
+        assert all((hr[c][k] == rb[k][c]).all() for k in range(2) for c in range(4))
+        only_h = np.empty((2, M, M), np.float32)
+        mw.check(mw.lib().mw_ocean_generate_texture_steps(a.handle, _frame_dts(2).ctypes.data_as(C.c_void_p), 2, only_h.ctypes.data_as(C.c_void_p), None, None, None))
+        assert (only_h[1] == [b.generate_texture(float(dt)) for dt in _frame_dts(2)][1][0]).all()
         for bad in (0, 33):
             with pytest.raises(mw.MistralWaterError) as e:
                 a.generate_texture_steps_device(np.zeros(bad, np.float32))
