@@ -69,7 +69,20 @@ def _worker(rank, world, port, q):
             else np.zeros((0, 256))
         allrows = gather_step_blocks(torch.from_numpy(rows), 5, dist, parallel.shard_steps)
         slow = parallel.max_over_ranks(1.0 + rank, dist)
-        q.put((rank, None if tiles is None else [t.numpy() for t in tiles], allrows.numpy(), slow, (lo, hi)))
+        # --- OceanRenderer semantics, time axis: only the phase links the frames, so rank r SEEKS to frame lo with the Dispersion pass alone
+        #     (what mw_ocean_advance_phase does on the device) and renders its block (bench.py --workload renderer1024 --shard steps) ----------
+        rp = O.RendererParams(resolution=8, length=27.155, wind_x=14.45, wind_y=12.0, amplitude=0.41, choppiness=0.46, gravity=9.81, mult=1.5)
+        init4 = O.renderer_initial_spectrum(rp, 3)
+        dts = [0.016, 0.3, 0.0, 600.0, 0.02]
+        ph = np.zeros((rp.M, rp.M), np.float32)
+        for k in range(lo):
+            O.renderer_advance_phase(rp, init4, ph, dts[k])
+        frames = np.stack([O.renderer_step_f64(rp, init4, ph, dts[k], literal_passes=False)[0].ravel() for k in range(lo, hi)]) if hi > lo \
+            else np.zeros((0, rp.M * rp.M))
+        allframes = gather_step_blocks(torch.from_numpy(frames), 5, dist, parallel.shard_steps)
+        for k in range(hi, 5):
+            O.renderer_advance_phase(rp, init4, ph, dts[k])      # ... and walks on to frame K: every rank ends in the same state
+        q.put((rank, None if tiles is None else [t.numpy() for t in tiles], allrows.numpy(), slow, (lo, hi), allframes.numpy(), ph))
     finally:
         dist.destroy_process_group()
 
@@ -118,3 +131,11 @@ def test_two_rank_gloo_tiles_and_steps(oracle):
         assert np.array_equal(res[r][2], want)
         assert res[r][3] == 2.0  # max over ranks of (1 + rank)
     assert res[0][4] == (0, 3) and res[1][4] == (3, 5)
+    # OceanRenderer frames sharded over the ranks: the same five height textures as ONE process rendering them in sequence, and the same
+    # phase texture at the end on every rank
+    rp = oracle.RendererParams(resolution=8, length=27.155, wind_x=14.45, wind_y=12.0, amplitude=0.41, choppiness=0.46, gravity=9.81, mult=1.5)
+    init4 = oracle.renderer_initial_spectrum(rp, 3)
+    ph = np.zeros((rp.M, rp.M), np.float32)
+    seq = np.stack([oracle.renderer_step_f64(rp, init4, ph, dt, literal_passes=False)[0].ravel() for dt in (0.016, 0.3, 0.0, 600.0, 0.02)])
+    for r in range(2):
+        assert np.array_equal(res[r][5], seq) and np.array_equal(res[r][6], ph)
