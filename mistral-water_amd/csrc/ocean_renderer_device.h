@@ -252,15 +252,19 @@ __global__ __launch_bounds__((OrP1Geom<N, P>::NTHREADS)) void k_or_pass1_steps(O
     if (k1 == S.nframes && fsel == 0) or_p1_steps_store_phase<N, P>(A, jb, tid, ph);  // the last group holds the phase after every frame
 }
 
-// the textures of frame `last` of a steps call become the handle's latest frame (mw_ocean_displace_mesh, the tile gather, ...)
+// the textures of frame `last` of a steps call become the handle's latest frame (mw_ocean_displace_mesh, the tile gather, ...): every array as
+// float4 (M * M is a multiple of 4 and the frame offsets keep the 16-byte alignment), thread i copies element i of each array that has one
 __global__ __launch_bounds__(256) void k_or_copy_frame(size_t MM, const float* h, const cf* d, const float* dg, const float* n, const float* w,
                                                        const float* hg, const float* da, float* oh, cf* od, float* odg, float* on, float* ow,
                                                        float* ohg, float* oda) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= MM) return;
-    oh[i] = h[i]; od[i] = d[i]; odg[i] = dg[i]; ow[i] = w[i];
-    on[3 * i] = n[3 * i]; on[3 * i + 1] = n[3 * i + 1]; on[3 * i + 2] = n[3 * i + 2];
-    if (hg) { ohg[i] = hg[i]; oda[i] = da[i]; }
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, q = MM / 4;
+    auto cp = [i](const void* src, void* dst) { reinterpret_cast<f4*>(dst)[i] = reinterpret_cast<const f4*>(src)[i]; };
+    if (i < 3 * q) cp(n, on);
+    if (i < 2 * q) cp(d, od);
+    if (i < q) {
+        cp(h, oh); cp(dg, odg); cp(w, ow);
+        if (hg) { cp(hg, ohg); cp(da, oda); }
+    }
 }
 
 // workgroup b of nb (a multiple of 8, else the identity) -> index in an order that gives XCD b % 8 one contiguous eighth of the indices
@@ -345,6 +349,9 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2_packed(
 #ifndef MW_OR_NW_BANDS
 #define MW_OR_NW_BANDS 1  // one band of texel rows per XCD (0: rows round-robin over the XCDs, A/B)
 #endif
+#ifndef MW_OR_NW_LDS_TURN
+#define MW_OR_NW_LDS_TURN 1  // a wave's normals turned through LDS so that every store instruction writes 1 KiB contiguous (0: straight from the lane)
+#endif
 #ifndef MW_OR_NW_QUAD
 #define MW_OR_NW_QUAD 1  // four texels of a row per thread from 16-byte loads (0: one texel per thread, A/B)
 #endif
@@ -361,8 +368,36 @@ __global__ __launch_bounds__(256) void k_or_normal_white(OrConsts c, const float
     }
 #if MW_OR_NW_QUAD
     const int Q = c.M / 4;  // thread idx: texels 4 (idx % Q) .. + 3 of row idx / Q
-    if (idx >= c.M * Q) return;
-    or_normal_white_quad<NT>(c, 4 * (idx % Q), idx / Q, height, disp, disp_g, normal, white);
+    if (idx >= c.M * Q) return;  // whole waves (M^2 / 4 is a multiple of 64)
+    float n[4][3], w[4];
+    or_normal_white_quad_compute(c, 4 * (idx % Q), idx / Q, height, disp, disp_g, n, w);
+    f4 o;
+    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+    mw_store_stream<NT>(reinterpret_cast<f4*>(white) + idx, o);  // 64 lanes x 16 B = 1 KiB contiguous
+#if MW_OR_NW_LDS_TURN
+    // The normals: a lane owns 48 contiguous bytes (4 texels x 3), a wave 3 KiB (thread idx <-> texels 4 idx .. 4 idx + 3 of the row-major texture).
+    // Stored straight from the lane every instruction writes 16-byte pieces 48 bytes apart -- a third of every line, left to the L2 to merge, and
+    // slow with the non-temporal hint.  Turned through LDS inside the wave (as wave_store_3f4 does for the pond's vertices) every store
+    // instruction writes 64 consecutive float4 = 1 KiB.
+    __shared__ f4 tile[256 * 3];
+    const int lane = threadIdx.x & 63;
+    f4* wt = tile + (threadIdx.x - lane) * 3;
+    f4 r0, r1, r2;
+    r0.x = n[0][0]; r0.y = n[0][1]; r0.z = n[0][2]; r0.w = n[1][0];
+    r1.x = n[1][1]; r1.y = n[1][2]; r1.z = n[2][0]; r1.w = n[2][1];
+    r2.x = n[2][2]; r2.y = n[3][0]; r2.z = n[3][1]; r2.w = n[3][2];
+    wt[lane * 3] = r0; wt[lane * 3 + 1] = r1; wt[lane * 3 + 2] = r2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f4* dst = reinterpret_cast<f4*>(normal) + (size_t)3 * (idx - lane);
+#pragma unroll
+    for (int j = 0; j < 3; j++) mw_store_stream<NT>(&dst[j * 64 + lane], wt[j * 64 + lane]);
+#else
+    float* np_ = normal + (size_t)12 * idx;
+    o.x = n[0][0]; o.y = n[0][1]; o.z = n[0][2]; o.w = n[1][0]; mw_store_stream<NT>(reinterpret_cast<f4*>(np_), o);
+    o.x = n[1][1]; o.y = n[1][2]; o.z = n[2][0]; o.w = n[2][1]; mw_store_stream<NT>(reinterpret_cast<f4*>(np_ + 4), o);
+    o.x = n[2][2]; o.y = n[3][0]; o.z = n[3][1]; o.w = n[3][2]; mw_store_stream<NT>(reinterpret_cast<f4*>(np_ + 8), o);
+#endif
 #else
     if (idx >= c.M * c.M) return;
     float nxz[2];
@@ -733,7 +768,7 @@ static inline mw_status or_generate_steps(OrState& s, const float* delta_time, i
     }
     if (e != hipSuccess) { g_or_err = std::string("OceanRenderer steps launch: ") + hipGetErrorString(e); return MW_EDEVICE; }
     const size_t last = (size_t)(n - 1) * MM;
-    k_or_copy_frame<<<dim3((unsigned)((MM + 255) / 256)), dim3(256), 0, st>>>(MM, f_h + last, f_d + last, s.fr_disp_g + last, f_n + 3 * last, f_w + last,
+    k_or_copy_frame<<<dim3((unsigned)((3 * MM / 4 + 255) / 256)), dim3(256), 0, st>>>(MM, f_h + last, f_d + last, s.fr_disp_g + last, f_n + 3 * last, f_w + last,
                                                     s.want_imag ? s.fr_height_g + last : nullptr, s.want_imag ? s.fr_disp_a + last : nullptr,
                                                     s.out_height, s.out_disp_cf, s.out_disp_g, s.out_normal, s.out_white, s.out_height_g, s.out_disp_a);
     if (hipGetLastError() != hipSuccess) { g_or_err = "OceanRenderer normal/white launch failed"; return MW_EDEVICE; }

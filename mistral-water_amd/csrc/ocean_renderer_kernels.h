@@ -498,9 +498,9 @@ MW_HD void or_white_element(const OrConsts& c, int px, int py, const cf* disp, c
 }
 // Both passes for the FOUR texels px0 .. px0 + 3 (px0 a multiple of 4) of row py from 16-byte loads: 6 loads and 1 store instruction per
 // texel instead of 14 and 4, the normal leaves as three float4 (48 contiguous bytes per thread).  Same arithmetic per texel.
-template <bool NT = false>
-MW_HD void or_normal_white_quad(const OrConsts& c, int px0, int py, const float* height, const cf* disp, const float* disp_g, float* normal,
-                                float* white) {
+// (or_normal_white_quad_compute: the values; the device kernel turns a wave's normals through LDS before storing them, k_or_normal_white)
+MW_HD void or_normal_white_quad_compute(const OrConsts& c, int px0, int py, const float* height, const cf* disp, const float* disp_g,
+                                        float (&n)[4][3], float (&w)[4]) {
     const int M = c.M;
     const float ts = c.normal_length / (float)M;
     const size_t rc = (size_t)py * M, rt = (size_t)or_clamp(py - 1, M - 1) * M, rb = (size_t)or_clamp(py + 1, M - 1) * M;
@@ -526,13 +526,20 @@ MW_HD void or_normal_white_quad(const OrConsts& c, int px0, int py, const float*
     split(disp + rc + or_clamp(px0 + 8, M - 4), dxp);
     if (px0 < 8) { const cf e = disp[rc]; dxm[0] = dxm[1] = dxm[2] = dxm[3] = e; }
     if (px0 + 8 > M - 4) { const cf e = disp[rc + M - 1]; dxp[0] = dxp[1] = dxp[2] = dxp[3] = e; }
-    float n[4][3], w[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         or_normal_math(ts, dc[k + 1].x, gc[k], dc[k + 1].y, dc[k + 2].x, hc[k + 2], dc[k + 2].y, dc[k].x, hc[k], dc[k].y, dt[k].x, ht[k], dt[k].y,
                        db[k].x, hb[k], db[k].y, n[k]);
         w[k] = or_white_math(dym[k], dyp[k], dxm[k], dxp[k], n[k][0], n[k][2]);
     }
+}
+// the same with the stores straight from the lane (three float4 of the normal 48 bytes apart): host emulation / reference form
+template <bool NT = false>
+MW_HD void or_normal_white_quad(const OrConsts& c, int px0, int py, const float* height, const cf* disp, const float* disp_g, float* normal,
+                                float* white) {
+    float n[4][3], w[4];
+    or_normal_white_quad_compute(c, px0, py, height, disp, disp_g, n, w);
+    const size_t rc = (size_t)py * c.M;
     f4 o;
     float* np_ = normal + 3 * (rc + px0);
     o.x = n[0][0]; o.y = n[0][1]; o.z = n[0][2]; o.w = n[1][0]; mw_store_stream<NT>(reinterpret_cast<f4*>(np_), o);
