@@ -105,6 +105,9 @@ __global__ void k_or_prep(int M, const f4* initT, f4* PQT) {
 #ifndef MW_OR_P1_LONE_CHUNK
 #define MW_OR_P1_LONE_CHUNK 4  // points whose loads the lone frame's spectrum workgroup requests together (1 / 2 / 4 / 8: 1024^2 34.4 / 34.1 / 34.0 /
 #endif                         // 34.7 us per frame, 512^2 19.9 / 19.0 / 18.9 / 18.9; the three-transform plan keeps point by point)
+#ifndef MW_OR_P2_LONE_SPLIT
+#define MW_OR_P2_LONE_SPLIT 1  // lone frame, packed plan: pass 2 with one field per workgroup
+#endif
 #ifndef MW_OR_PACKED_MAX_M
 #define MW_OR_PACKED_MAX_M 4096  // textures from this size up keep the three-transform plan
 #endif
@@ -327,10 +330,13 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2_packed(
     cf* set0 = lds + G::TW_LDS;
     cf x[P];
     float dx[P];
-    for (int k = 0; k < 2; k++) {
-        if (k != 0) __syncthreads();
+    // gridDim.y == 2 (the lone frame: 256 row groups on 256 CUs, latency-bound): one field per workgroup, half the work on the critical path
+    const bool split = gridDim.y == 2;
+    const int k0 = split ? (int)blockIdx.y : 0, k1 = split ? k0 + 1 : 2;
+    for (int k = k0; k < k1; k++) {
+        if (k != k0) __syncthreads();
         or_p2_load<N, P>(A, ab, tid, k, x, set0);
-        if (k == 0) tws.store(lds, tid);
+        if (k == k0) tws.store(lds, tid);
         __syncthreads();
 #pragma unroll
         for (int s = 1; s < FftGeom<N, P>::S; s++) {
@@ -340,7 +346,7 @@ __global__ __launch_bounds__((OrP2Geom<N, P>::NTHREADS)) void k_or_pass2_packed(
             stage_store<N, P, -1, false>(x, um, set0 + rm * G::BUFSTRIDE, tw, s);
             __syncthreads();
         }
-        or_p2_finish<N, P>(A, tw, ab, tid, k == 0 ? 1 : 3, x, dx, set0);
+        or_p2_finish<N, P>(A, tw, ab, tid, split ? 4 + k : (k == 0 ? 1 : 3), x, dx, set0);
     }
 }
 
@@ -526,7 +532,7 @@ static hipError_t or_launch_passes(OrState& s, float dt, hipStream_t st, hipEven
         k_or_pass1_packed<N, P><<<dim3(N / 4, all_fields ? 1 : 2, s.tiles), dim3(NT1), LB1, st>>>(A1);
         if (ev) hipEventRecord(ev[1], st);
         std::swap(s.phaseT, s.phaseT2);
-        k_or_pass2_packed<N, P><<<dim3(N / 4, 1, s.tiles), dim3(NT2), LB2, st>>>(A2);
+        k_or_pass2_packed<N, P><<<dim3(N / 4, (all_fields || !MW_OR_P2_LONE_SPLIT) ? 1 : 2, s.tiles), dim3(NT2), LB2, st>>>(A2);
         if (ev) hipEventRecord(ev[2], st);
         return hipGetLastError();
     }

@@ -431,6 +431,9 @@ MW_HD void or_p2_finish(const OrP2Args& A, const Twiddles& tw, int ab, int tid, 
         if (f == 1) { dx[q] = x[q].x; (r_dg + T * q)[uo] = x[q].y; }
         else if (f == 2) { (r_d + T * q)[uo] = mk(dx[q], x[q].x); if (r_da) (r_da + T * q)[uo] = x[q].y; }
         else if (f == 3) { (r_d + T * q)[uo] = mk(dx[q], x[q].y); (r_h + T * q)[uo] = x[q].x; }  // packed plan: F(G) = height + i Dz
+        // packed plan, one FIELD per workgroup (the lone frame): each writes its half of displacement.rb -- 4-byte pieces 8 bytes apart
+        else if (f == 4) { (reinterpret_cast<float*>(r_d) + 2 * T * q)[2 * uo] = x[q].x; (r_dg + T * q)[uo] = x[q].y; }
+        else if (f == 5) { (reinterpret_cast<float*>(r_d) + 2 * T * q)[2 * uo + 1] = x[q].y; (r_h + T * q)[uo] = x[q].x; }
         else { (r_h + T * q)[uo] = x[q].x; if (r_hg) (r_hg + T * q)[uo] = x[q].y; }
     }
 }
